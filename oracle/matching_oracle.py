@@ -1,0 +1,342 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement of the reference Matching-Net forward.
+
+This is the oracle the HIP path is checked against.  It restates, as plain
+functions over a flat ``state_dict`` (reference key layout), the algorithm of
+chzhang18/RAG's stereo Matching Net:
+
+* cost-volume build          src/models/rag_model.py:375-383 (dup :694-702,
+                             src/automl/mdenas_basicmodel.py:83-91)
+* ConvBR_3d                  src/automl/operations_3d.py:31-47
+* Cell_3d                    src/models/rag_model.py:114-177
+* Network.matching           src/models/rag_model.py:325-366
+* Disp / DisparityRegression src/models/rag_model.py:18-44
+
+Arithmetic is fp32 PyTorch-CPU ATen (the reference's own arithmetic: Conv3d,
+BatchNorm3d, F.interpolate, Softmin).  Two primitives additionally have an
+explicit index-math restatement (`trilinear_explicit`, `conv3d_explicit`) that
+documents exactly what the HIP kernels implement; tests check the two agree.
+
+Parity pin: the reference ships no tests or golden vectors, so
+this oracle is pinned by fixtures generated from the reference itself, imported
+in the build container by ``tests/golden/make_golden.py`` (committed, with its
+outputs under ``tests/golden/``).  ``tests/test_oracle_golden.py`` checks every
+fixture.  Status: parity PINNED by those reference-generated fixtures.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm3d default, operations_3d.py:38
+
+# Matching-Net macro architecture, rag_model.py:238-261:
+# (prev_prev_fmultiplier, prev_filter_multiplier, filter_multiplier, downup_sample)
+CELL3D_ARCH: Tuple[Tuple[int, int, int, int], ...] = (
+    (4, 4, 4, 0),
+    (4, 4, 4, 0),
+    (4, 4, 4, 0),
+    (4, 4, 8, -1),
+    (4, 8, 16, -1),
+    (8, 16, 8, 1),
+    (16, 8, 16, -1),
+    (8, 16, 16, 0),
+)
+STEPS = 3             # rag_model.py:188
+BLOCK_MULTIPLIER = 3  # rag_model.py:190
+
+ALL_CONV = np.array([[0, 1], [1, 1], [2, 1], [3, 1], [5, 1], [6, 1]])
+ALL_SKIP = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [5, 0], [6, 0]])
+
+
+# --------------------------------------------------------------------------- A1
+def cost_volume(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """Concat-and-shift cost volume, rag_model.py:375-383.
+
+    cost[b, c,   i, y, x] = L[b, c, y, x]      for x >= i, else 0
+    cost[b, C+c, i, y, x] = R[b, c, y, x - i]  for x >= i, else 0,   i in [0, maxdisp/3)
+    """
+    B, C, h, w = left_fea.shape
+    d = int(maxdisp / 3)
+    cost = left_fea.new_zeros((B, 2 * C, d, h, w))
+    for i in range(d):
+        if i >= w:
+            # the reference's slice assignments become empty (x[..., i:] has width 0)
+            continue
+        if i > 0:
+            cost[:, :C, i, :, i:] = left_fea[:, :, :, i:]
+            cost[:, C:, i, :, i:] = right_fea[:, :, :, :-i]
+        else:
+            cost[:, :C, i, :, :] = left_fea
+            cost[:, C:, i, :, :] = right_fea
+    return cost
+
+
+# --------------------------------------------------------------------------- A2
+def conv_br_3d(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, *, padding: int,
+               bn: bool = True, relu: bool = True, training: bool = False) -> torch.Tensor:
+    """ConvBR_3d.forward, operations_3d.py:40-47: conv (no bias) -> BN -> ReLU.
+
+    `training=True` uses batch statistics (it does not update running stats here;
+    the oracle is functional).
+    """
+    y = F.conv3d(x, sd[prefix + "conv.weight"], None, stride=1, padding=padding)
+    if bn:
+        y = F.batch_norm(
+            y,
+            None if training else sd[prefix + "bn.running_mean"],
+            None if training else sd[prefix + "bn.running_var"],
+            sd[prefix + "bn.weight"], sd[prefix + "bn.bias"],
+            training=training, momentum=0.1, eps=BN_EPS)
+    if relu:
+        y = F.relu(y)
+    return y
+
+
+def scale_dimension(dim: int, scale: float) -> int:
+    """Cell_3d.scale_dimension, rag_model.py:140-141."""
+    return int((float(dim) - 1.0) * scale + 1.0) if dim % 2 == 1 else int(float(dim) * scale)
+
+
+def resolve_cell_ops(genotype_rows: np.ndarray, steps: int = STEPS):
+    """Positional op pairing of Cell_3d (rag_model.py:134-137 vs :160-170).
+
+    ops are CREATED in genotype-row order (op k has the type of row k) but
+    CONSUMED by a running ops_index in ascending-branch visit order.  Returns,
+    per step, a list of (state_index j, ops_index k, op_type) in visit order.
+    """
+    rows = np.asarray(genotype_rows)
+    selected = set(int(v) for v in rows[:, 0])
+    plan = []
+    offset, n_states, k = 0, 2, 0
+    for _ in range(steps):
+        step = []
+        for j in range(n_states):
+            if offset + j in selected:
+                step.append((j, k, int(rows[k, 1])))
+                k += 1
+        plan.append(step)
+        offset += n_states
+        n_states += 1
+    return plan
+
+
+# --------------------------------------------------------------------------- A4
+def cell_3d(prev_prev: torch.Tensor, prev: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str,
+            genotype_rows: np.ndarray, filter_multiplier: int, downup: int,
+            training: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Cell_3d.forward, rag_model.py:143-177."""
+    c_out = filter_multiplier
+    s0, s1 = prev_prev, prev
+    if downup != 0:
+        scale = 0.5 if downup == -1 else 2
+        size = [scale_dimension(s1.shape[2], scale), scale_dimension(s1.shape[3], scale),
+                scale_dimension(s1.shape[4], scale)]
+        s1 = F.interpolate(s1, size, mode="trilinear", align_corners=True)
+    if tuple(s0.shape[2:]) != tuple(s1.shape[2:]):
+        s0 = F.interpolate(s0, tuple(s1.shape[2:]), mode="trilinear", align_corners=True)
+    if s0.shape[1] != c_out:
+        s0 = conv_br_3d(s0, sd, prefix + "pre_preprocess.", padding=0, training=training)
+    s1 = conv_br_3d(s1, sd, prefix + "preprocess.", padding=0, training=training)
+
+    states = [s0, s1]
+    for step in resolve_cell_ops(genotype_rows):
+        new_states = []
+        for (j, k, op_type) in step:
+            h = states[j]
+            if op_type == 1:   # '3d_conv_3x3' = ConvBR_3d(C, C, 3, 1, 1), genotypes_3d.py:6-9
+                new_states.append(conv_br_3d(h, sd, prefix + f"_ops.{k}.", padding=1, training=training))
+            else:              # 'skip_connect_3d' = Identity_3d
+                new_states.append(h)
+        states.append(sum(new_states))
+    return prev, torch.cat(states[-BLOCK_MULTIPLIER:], dim=1)
+
+
+# --------------------------------------------------------------------------- A7
+def matching(cost: torch.Tensor, sd: Dict[str, torch.Tensor], genotype_rows: np.ndarray,
+             task_arch: Optional[Dict[str, Sequence[int]]] = None, training: bool = False,
+             head_index: Optional[int] = None, selected_ops: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Network.matching (rag_model.py:325-366) / search_matching (:663-685).
+
+    task_arch form: unit index per layer from task_arch[name][0].
+    selected_ops form (search_matching): stems use selected_ops[8], [9], cells
+    selected_ops[10+i], heads use `head_index` (= t).
+    """
+    def unit(name, pos):
+        if selected_ops is not None:
+            return int(selected_ops[pos])
+        if task_arch is None:
+            return 0
+        return int(task_arch[name][0])
+
+    def head(name):
+        if selected_ops is not None:
+            return int(head_index)
+        if task_arch is None:
+            return 0
+        return int(task_arch[name][0])
+
+    stem0 = conv_br_3d(cost, sd, f"stem3d0.{unit('stem_3d0', 8)}.", padding=1, training=training)
+    stem1 = conv_br_3d(stem0, sd, f"stem3d1.{unit('stem_3d1', 9)}.", padding=1, training=training)
+    out = (stem0, stem1)
+    for i, (_pp, _p, fm, downup) in enumerate(CELL3D_ARCH):
+        k = unit(f"cell_3d{i}", 10 + i)
+        out = cell_3d(out[0], out[1], sd, f"cells_3d.{i}.{k}.", genotype_rows, fm, downup, training)
+    last = out[-1]
+    d, h, w = cost.shape[2:]
+    p3, p6, p12 = (f"last_3_3d.{head('last_3_3d')}.", f"last_6_3d.{head('last_6_3d')}.",
+                   f"last_12_3d.{head('last_12_3d')}.")
+    if last.shape[3] == h:
+        mat = conv_br_3d(last, sd, p3, padding=1, bn=False, relu=False)
+    elif last.shape[3] == h // 2:
+        x = conv_br_3d(last, sd, p6, padding=0, training=training)
+        x = F.interpolate(x, (d, h, w), mode="trilinear", align_corners=True)
+        mat = conv_br_3d(x, sd, p3, padding=1, bn=False, relu=False)
+    elif last.shape[3] == h // 4:
+        x = conv_br_3d(last, sd, p12, padding=0, training=training)
+        x = F.interpolate(x, (d // 2, h // 2, w // 2), mode="trilinear", align_corners=True)
+        x = conv_br_3d(x, sd, p6, padding=0, training=training)
+        x = F.interpolate(x, (d, h, w), mode="trilinear", align_corners=True)
+        mat = conv_br_3d(x, sd, p3, padding=1, bn=False, relu=False)
+    else:
+        # the reference falls through to `return mat` with mat unbound (UnboundLocalError)
+        raise ValueError("unsupported shape: H/3 must be a multiple of 4 (SURVEY.md facts up front)")
+    return mat
+
+
+# ---------------------------------------------------------------------- A8 / A9
+def disparity_regression(prob: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """DisparityRegression.forward, rag_model.py:23-29: out = sum_d prob[:, d] * d."""
+    assert prob.is_contiguous()
+    disp = torch.arange(0, maxdisp, dtype=torch.float32).reshape(1, maxdisp, 1, 1)
+    disp = disp.repeat(prob.shape[0], 1, prob.shape[2], prob.shape[3])
+    return torch.sum(prob * disp, 1)
+
+
+def disp_head(x: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """Disp.forward, rag_model.py:39-44: trilinear x3 (align_corners=False) -> softmin -> expectation."""
+    x = F.interpolate(x, [maxdisp, x.shape[3] * 3, x.shape[4] * 3], mode="trilinear", align_corners=False)
+    x = torch.squeeze(x, 1)
+    x = F.softmin(x, dim=1)
+    return disparity_regression(x.contiguous(), maxdisp)
+
+
+def matching_net_forward(left_fea: torch.Tensor, right_fea: torch.Tensor, sd: Dict[str, torch.Tensor],
+                         genotype_rows: np.ndarray, maxdisp: int,
+                         task_arch: Optional[Dict[str, Sequence[int]]] = None,
+                         training: bool = False, return_intermediates: bool = False):
+    """(left_fea, right_fea) -> disp[B, 3h, 3w]: rag_model.py:375-386 minus the Feature Net."""
+    cost = cost_volume(left_fea, right_fea, maxdisp)
+    mat = matching(cost, sd, genotype_rows, task_arch, training)
+    out = disp_head(mat, maxdisp)
+    if return_intermediates:
+        return out, {"cost": cost, "mat": mat}
+    return out
+
+
+def epe(est: torch.Tensor, ref: torch.Tensor) -> float:
+    """EPE_metric with an all-true mask, src/utilstool/metrics.py:63-65: per-image mean |est-gt|, then batch mean."""
+    per_image = (est.double() - ref.double()).abs().flatten(1).mean(dim=1)
+    return float(per_image.mean())
+
+
+# ----------------------------------------------------------------- parameters
+def random_matching_state_dict(genotype_rows: np.ndarray, seed: int = 0, units: int = 1, heads: int = 1,
+                               randomize_bn: bool = True) -> Dict[str, torch.Tensor]:
+    """Reference-layout state_dict of the Matching-Net part with the reference init
+    (Kaiming-normal fan_out convs, BN gamma=1 beta=0, operations_3d.py:49-55) and, if
+    `randomize_bn`, the benchmark protocol's BN statistics."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(prefix, cout, cin, k):
+        fan_out = cout * k * k * k
+        std = math.sqrt(2.0 / fan_out)
+        sd[prefix + "conv.weight"] = torch.randn((cout, cin, k, k, k), generator=g) * std
+        if randomize_bn:
+            sd[prefix + "bn.weight"] = torch.rand(cout, generator=g) + 0.5
+            sd[prefix + "bn.bias"] = torch.randn(cout, generator=g) * 0.1
+            sd[prefix + "bn.running_mean"] = torch.randn(cout, generator=g) * 0.1
+            sd[prefix + "bn.running_var"] = torch.rand(cout, generator=g) + 0.5
+        else:
+            sd[prefix + "bn.weight"] = torch.ones(cout)
+            sd[prefix + "bn.bias"] = torch.zeros(cout)
+            sd[prefix + "bn.running_mean"] = torch.zeros(cout)
+            sd[prefix + "bn.running_var"] = torch.ones(cout)
+        sd[prefix + "bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    plan = resolve_cell_ops(genotype_rows)
+    for u in range(units):
+        conv(f"stem3d0.{u}.", 12, 24, 3)
+        conv(f"stem3d1.{u}.", 12, 12, 3)
+        for i, (pp, p, fm, _du) in enumerate(CELL3D_ARCH):
+            pre = f"cells_3d.{i}.{u}."
+            conv(pre + "pre_preprocess.", fm, 3 * pp, 1)
+            conv(pre + "preprocess.", fm, 3 * p, 1)
+            # keys exist only for ops created as convs: op k has the type of genotype row k
+            for k in range(len(genotype_rows)):
+                if int(genotype_rows[k][1]) == 1:
+                    conv(pre + f"_ops.{k}.", fm, fm, 3)
+    for t in range(heads):
+        conv(f"last_3_3d.{t}.", 1, 12, 3)
+        conv(f"last_6_3d.{t}.", 12, 24, 1)
+        conv(f"last_12_3d.{t}.", 24, 48, 1)
+    del plan
+    return sd
+
+
+# ----------------------------------------------- explicit index-math restatements
+def _linear_src_index(dst: int, in_size: int, out_size: int, align_corners: bool) -> Tuple[int, int, float]:
+    """ATen's linear source index (aten/src/ATen/native/UpSample.h area_pixel_compute_source_index),
+    evaluated in fp32 like the CPU/GPU kernels do."""
+    f = np.float32
+    if align_corners:
+        scale = f(in_size - 1) / f(out_size - 1) if out_size > 1 else f(0)
+        src = scale * f(dst)
+    else:
+        scale = f(in_size) / f(out_size)
+        src = scale * (f(dst) + f(0.5)) - f(0.5)
+        if src < 0:
+            src = f(0)
+    i0 = int(src)
+    i0 = min(i0, in_size - 1)
+    i1 = i0 + (1 if i0 < in_size - 1 else 0)
+    lam = f(src) - f(i0)
+    return i0, i1, float(lam)
+
+
+def trilinear_explicit(x: np.ndarray, size: Sequence[int], align_corners: bool) -> np.ndarray:
+    """Separable trilinear resample of x[B,C,D,H,W] -> [B,C,*size]; the index math the HIP
+    resample / Disp kernels implement.  Small inputs only (pure numpy gathers)."""
+    x = np.asarray(x, dtype=np.float32)
+    for axis, (n_in, n_out) in enumerate(zip(x.shape[2:], size)):
+        idx0 = np.empty(n_out, dtype=np.int64)
+        idx1 = np.empty(n_out, dtype=np.int64)
+        lam = np.empty(n_out, dtype=np.float32)
+        for o in range(n_out):
+            idx0[o], idx1[o], lam[o] = _linear_src_index(o, n_in, n_out, align_corners)
+        shape = [1] * x.ndim
+        shape[2 + axis] = n_out
+        lam_b = lam.reshape(shape)
+        x = (np.float32(1) - lam_b) * np.take(x, idx0, axis=2 + axis) + lam_b * np.take(x, idx1, axis=2 + axis)
+    return x.astype(np.float32)
+
+
+def conv3d_explicit(x: np.ndarray, w: np.ndarray, padding: int) -> np.ndarray:
+    """Direct stride-1 3-D cross-correlation in float64 accumulate (numpy), NCDHW; small inputs only."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    B, Cin, D, H, W = x.shape
+    Cout, _, k, _, _ = w.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (padding,) * 2, (padding,) * 2, (padding,) * 2))
+    Do, Ho, Wo = D + 2 * padding - k + 1, H + 2 * padding - k + 1, W + 2 * padding - k + 1
+    y = np.zeros((B, Cout, Do, Ho, Wo))
+    for dz in range(k):
+        for dy in range(k):
+            for dx in range(k):
+                patch = xp[:, :, dz:dz + Do, dy:dy + Ho, dx:dx + Wo]
+                y += np.einsum("bcdhw,oc->bodhw", patch, w[:, :, dz, dy, dx])
+    return y.astype(np.float32)

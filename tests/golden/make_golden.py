@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+Imports chzhang18/RAG from /root/reference/src (read-only), runs its own
+modules on seeded inputs on CPU, and writes inputs + state_dicts + outputs as
+small ``.npz`` fixtures next to this script.  The reference never travels to
+the GPU box; only these data files do.  On a machine without /root/reference
+this script exits with a message and changes nothing.
+
+The only harness-side shim is ``torch.cuda.current_device`` -> CPU, required by
+DisparityRegression (src/models/rag_model.py:26) to run without a GPU.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    if not os.path.isdir(REF):
+        print("reference not present; golden fixtures are used as committed")
+        sys.exit(0)
+    sys.path.insert(0, REF)
+    torch.cuda.current_device = lambda: torch.device("cpu")  # rag_model.py:26 shim
+    import models.rag_model as rm  # noqa
+    from automl.genotypes_2d import Genotype  # noqa
+    return rm, Genotype
+
+
+def randomize_bn(module, gen):
+    """Give every BatchNorm non-trivial affine + running stats so folding is exercised."""
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+
+
+def sd_np(module, prefix="sd::"):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+ALL_CONV = np.array([[0, 1], [1, 1], [2, 1], [3, 1], [5, 1], [6, 1]])
+ALL_SKIP = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [5, 0], [6, 0]])
+MIXED_UNSORTED = np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]])   # SURVEY §8 A6 probe
+MIXED_DEEP = np.array([[1, 1], [0, 0], [4, 1], [2, 0], [7, 1], [8, 1]])       # uses s2 and s3 as inputs
+
+
+def main():
+    rm, Genotype = _import_reference()
+    torch.set_num_threads(8)
+
+    def genotype(rows):
+        return Genotype(normal=rows, normal_concat=None, reduce=rows, reduce_concat=None)
+
+    def network(rows, maxdisp, seed):
+        torch.manual_seed(seed)
+        net = rm.Network(genotype(rows), "cpu")
+        randomize_bn(net, torch.Generator().manual_seed(seed + 1000))
+        net.maxdisp = maxdisp             # reference hard-codes 192 (rag_model.py:274)
+        net.disp = rm.Disp(maxdisp)
+        net.eval()
+        return net
+
+    # ---- G1: cost volume, produced by the reference's inline loop (rag_model.py:375-383).
+    # Features are fed straight in by bypassing feature(); the loop's output is captured
+    # at the entrance of stem3d0.
+    for tag, (B, C, h, w, d) in {"a": (2, 12, 6, 20, 8), "b": (1, 12, 4, 5, 8)}.items():
+        net = network(ALL_SKIP, 3 * d, seed=1)
+        g = torch.Generator().manual_seed(11)
+        L = torch.randn((B, C, h, w), generator=g)
+        R = torch.randn((B, C, h, w), generator=g)
+        captured = {}
+        net.feature = lambda x, ta, p: x
+        hook = net.stem3d0[0].register_forward_pre_hook(lambda m, inp: captured.__setitem__("cost", inp[0].clone()))
+        try:
+            with torch.no_grad():
+                net.forward(L, R, 0, net.arch_init)
+        except Exception:
+            pass  # shapes this small may fail later in matching(); only the captured cost matters
+        hook.remove()
+        save(f"g1_costvol_{tag}", left_fea=L.numpy(), right_fea=R.numpy(), maxdisp=np.int64(3 * d),
+             cost=captured["cost"].numpy())
+
+    # ---- G2: Disp / DisparityRegression (rag_model.py:18-44)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((2, 1, 8, 4, 8), generator=g) * 3
+    with torch.no_grad():
+        out = rm.Disp(24)(x)
+        prob = torch.softmax(torch.randn((2, 24, 5, 7), generator=g), dim=1).contiguous()
+        reg = rm.DisparityRegression(24)(prob)
+        x2 = torch.randn((1, 1, 5, 3, 4), generator=g) * 2          # maxdisp not 3*d: generic D scale
+        out2 = rm.Disp(13)(x2)
+    save("g2_disp", x=x.numpy(), maxdisp=np.int64(24), out=out.numpy(), prob=prob.numpy(), reg=reg.numpy(),
+         x2=x2.numpy(), maxdisp2=np.int64(13), out2=out2.numpy())
+
+    # ---- G3: ConvBR_3d eval + train mode (operations_3d.py:31-47)
+    arrays = {}
+    cases = {"k3": (4, 4, 3, 1, True, True), "k3_wide": (24, 12, 3, 1, True, True),
+             "k1": (12, 4, 1, 0, True, True), "k3_nobn": (12, 1, 3, 1, False, False)}
+    for name, (cin, cout, k, pad, bn, relu) in cases.items():
+        torch.manual_seed(31)
+        m = rm.ConvBR_3d(cin, cout, k, 1, pad, bn=bn, relu=relu)
+        randomize_bn(m, torch.Generator().manual_seed(32))
+        g = torch.Generator().manual_seed(33)
+        x = torch.randn((2, cin, 5, 6, 9), generator=g)
+        m.eval()
+        with torch.no_grad():
+            y_eval = m(x.clone())
+        m.train()
+        with torch.no_grad():
+            y_train = m(x.clone())
+        arrays.update({f"{name}::x": x.numpy(), f"{name}::y_eval": y_eval.numpy(), f"{name}::y_train": y_train.numpy(),
+                       f"{name}::cfg": np.array([cin, cout, k, pad, int(bn), int(relu)])})
+        # state_dict BEFORE the train-mode call mutated running stats is what eval used; re-create it
+        torch.manual_seed(31)
+        m0 = rm.ConvBR_3d(cin, cout, k, 1, pad, bn=bn, relu=relu)
+        randomize_bn(m0, torch.Generator().manual_seed(32))
+        arrays.update({f"{name}::" + k_: v for k_, v in sd_np(m0).items()})
+    save("g3_convbr", **arrays)
+
+    # ---- G4: Cell_3d for each downup, even and odd dims, sorted + unsorted genotypes
+    arrays = {}
+    cell_cases = {
+        "same_conv": (4, 4, 4, 0, ALL_CONV, (6, 8, 10), (6, 8, 10)),
+        "same_unsorted": (4, 4, 4, 0, MIXED_UNSORTED, (5, 6, 7), (5, 6, 7)),
+        "same_deep": (4, 4, 4, 0, MIXED_DEEP, (4, 6, 9), (4, 6, 9)),
+        "down_even": (4, 4, 8, -1, ALL_CONV, (8, 12, 16), (8, 12, 16)),
+        "down_odd": (4, 8, 16, -1, MIXED_UNSORTED, (8, 12, 20), (7, 9, 13)),
+        "up": (8, 16, 8, 1, MIXED_DEEP, (6, 8, 10), (3, 4, 5)),
+        "skip": (8, 16, 16, 0, ALL_SKIP, (4, 6, 8), (4, 6, 8)),
+    }
+    for name, (pp, p, fm, du, rows, size0, size1) in cell_cases.items():
+        torch.manual_seed(41)
+        cell = rm.Cell_3d(3, 3, pp, p, genotype(rows), fm, du)
+        randomize_bn(cell, torch.Generator().manual_seed(42))
+        cell.eval()
+        g = torch.Generator().manual_seed(43)
+        s0 = torch.randn((2, 3 * pp) + size0, generator=g)
+        s1 = torch.randn((2, 3 * p) + size1, generator=g)
+        with torch.no_grad():
+            prev, cat = cell(s0, s1)
+        assert prev is s1
+        arrays.update({f"{name}::s0": s0.numpy(), f"{name}::s1": s1.numpy(), f"{name}::out": cat.numpy(),
+                       f"{name}::rows": rows, f"{name}::cfg": np.array([pp, p, fm, du])})
+        arrays.update({f"{name}::" + k_: v for k_, v in sd_np(cell).items()})
+    save("g4_cell3d", **arrays)
+
+    # ---- G5: full matching() and forward() (rag_model.py:325-387); B=2
+    for name, (rows, H, W, D, seed) in {"conv_48x96_d48": (ALL_CONV, 48, 96, 48, 51),
+                                        "unsorted_36x60_d24": (MIXED_UNSORTED, 36, 60, 24, 52),
+                                        "skip_48x72_d24": (ALL_SKIP, 48, 72, 24, 53)}.items():
+        net = network(rows, D, seed)
+        g = torch.Generator().manual_seed(seed + 1)
+        left = torch.randn((2, 3, H, W), generator=g)
+        right = torch.randn((2, 3, H, W), generator=g)
+        cap = {}
+        h1 = net.stem3d0[0].register_forward_pre_hook(lambda m, inp: cap.__setitem__("cost", inp[0].clone()))
+        h2 = net.disp.register_forward_pre_hook(lambda m, inp: cap.__setitem__("mat", inp[0].clone()))
+        with torch.no_grad():
+            lf = net.feature(left, net.arch_init, None)
+            rf = net.feature(right, net.arch_init, None)
+            disp = net.forward(left, right, 0, net.arch_init)
+        h1.remove(); h2.remove()
+        arrays = {"left": left.numpy(), "right": right.numpy(), "left_fea": lf.numpy(), "right_fea": rf.numpy(),
+                  "mat": cap["mat"].numpy(), "disp": disp.numpy(), "rows": rows, "maxdisp": np.int64(D)}
+        arrays.update(sd_np(net))
+        save("g5_forward_" + name, **arrays)
+
+    # ---- G6: one fwd+bwd training step as in approaches/rag.py:155-219 (smooth-L1 on 0<gt<192 mask)
+    net = network(ALL_CONV, 24, 61)
+    net.train()
+    net.stem3d0[0].eval()         # a "reused" unit keeps BN in eval (rag.py:159-200)
+    g = torch.Generator().manual_seed(62)
+    left = torch.randn((2, 3, 36, 48), generator=g)
+    right = torch.randn((2, 3, 36, 48), generator=g)
+    gt = torch.rand((2, 36, 48), generator=g) * 30
+    sd_before = sd_np(net)
+    out = net.forward(left, right, 0, net.arch_init)
+    mask = (gt < 24) & (gt > 0)
+    loss = torch.nn.functional.smooth_l1_loss(out[mask], gt[mask], reduction="mean")
+    loss.backward()
+    arrays = {"left": left.numpy(), "right": right.numpy(), "gt": gt.numpy(), "disp": out.detach().numpy(),
+              "loss": np.float64(loss.item()), "rows": ALL_CONV, "maxdisp": np.int64(24)}
+    arrays.update(sd_before)
+    for k_, p_ in net.named_parameters():
+        if p_.grad is not None and (k_.startswith("stem3d") or k_.startswith("last_") or k_.startswith("cells_3d.0.")
+                                    or k_.startswith("cells_3d.7.")):
+            arrays["grad::" + k_] = p_.grad.numpy()
+    save("g6_train_step", **arrays)
+
+    # ---- G7: plumbing config (BASELINE configs[0]): 256x512 padded to 264x516, D=48, B=1.
+    # Full output is too big to commit: keep a 64x64 centre crop + checksums.
+    net = network(ALL_CONV, 48, 71)
+    g = torch.Generator().manual_seed(72)
+    left = torch.randn((1, 3, 264, 516), generator=g)
+    right = torch.randn((1, 3, 264, 516), generator=g)
+    with torch.no_grad():
+        lf = net.feature(left, net.arch_init, None)
+        rf = net.feature(right, net.arch_init, None)
+        disp = net.forward(left, right, 0, net.arch_init)
+    crop = disp[:, 100:164, 226:290].contiguous()
+    arrays = {"left_fea": lf.numpy().astype(np.float32), "right_fea": rf.numpy().astype(np.float32),
+              "disp_crop": crop.numpy(), "crop_box": np.array([100, 164, 226, 290]),
+              "disp_mean": np.float64(disp.double().mean().item()),
+              "disp_abs_sum": np.float64(disp.double().abs().sum().item()),
+              "disp_row_means": disp.double().mean(dim=2).numpy()[0],
+              "rows": ALL_CONV, "maxdisp": np.int64(48)}
+    arrays.update({k_: v for k_, v in sd_np(net).items()
+                   if any(s in k_ for s in ("stem3d", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d"))})
+    save("g7_plumbing_264x516_d48", **arrays)
+
+
+if __name__ == "__main__":
+    main()
