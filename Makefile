@@ -1,0 +1,22 @@
+# Builds librag_amd.so (HIP kernels + C ABI) for gfx950, in-tree.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := rag_amd/csrc
+SRCS  := $(wildcard $(CSRC)/*.hip)
+OBJS  := $(SRCS:.hip=.o)
+LIB   := rag_amd/lib/librag_amd.so
+CXXFLAGS := -O3 -std=c++20 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rag_amd.h
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p rag_amd/lib
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+clean:
+	rm -f $(OBJS) $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,144 @@
+/*
+ * rag_amd.h — C ABI of librag_amd.so: the MI355X (gfx950) kernels behind the
+ * RAG stereo Matching-Net forward path.
+ *
+ * The reference (chzhang18/RAG) is pure PyTorch and offers no FFI; its "plugin
+ * API" for this path is the nn.Module composition in src/models/rag_model.py.
+ * Each entry point below replaces the ATen op sequence of one reference
+ * construct (cited per function); rag_amd/modules.py mirrors the reference's
+ * module names/signatures on top of these calls.
+ *
+ * Conventions:
+ *  - plain pointers and sizes, no torch types; all tensors are device pointers
+ *    owned by the caller (PyTorch allocates), contiguous N-C-D-H-W planes;
+ *    "bstride" arguments are batch strides in ELEMENTS so that a call may read
+ *    or write a channel slice of a wider buffer (this is how torch.cat and the
+ *    running sum in Cell_3d are folded into the producing kernels);
+ *  - every function returns 0 on success and a negative RAGMI_E* code on
+ *    failure; no C++ exception crosses the ABI; ragmi_last_error() gives a
+ *    thread-local message for the last failure on this thread;
+ *  - stateless and re-entrant; kernels are enqueued on the hipStream_t passed
+ *    as `stream` (void*), never synchronise, never allocate device memory;
+ *  - dtype: RAGMI_F32 = fp32 storage+math (fp32 MFMA, exact fmaf chains).
+ */
+#ifndef RAG_AMD_H
+#define RAG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAGMI_OK 0
+#define RAGMI_EINVAL (-1)       /* bad argument (null pointer, non-positive size, ...) */
+#define RAGMI_EUNSUPPORTED (-2) /* shape / dtype combination not built */
+#define RAGMI_ELAUNCH (-3)      /* hipLaunch / runtime error */
+
+#define RAGMI_F32 0
+
+#define RAGMI_MAX_GROUPS 16 /* output-channel groups of 4 per conv call */
+
+/* Library version (major*10000 + minor*100 + patch) and last error text. */
+int ragmi_version(void);
+const char* ragmi_last_error(void);
+
+/*
+ * Cost-volume build.  Replaces the inline slice-copy loop of
+ * src/models/rag_model.py:375-383 (dups :694-702, src/automl/mdenas_basicmodel.py:83-91):
+ *   cost[b, c,   i, y, x] = L[b, c, y, x]      if x >= i else 0
+ *   cost[b, C+c, i, y, x] = R[b, c, y, x - i]  if x >= i else 0,      i in [0, d)
+ * L, R: [B, C, h, w]; cost: [B, 2C, d, h, w] (fully written, no memset needed).
+ */
+int ragmi_costvol_fwd(const void* left_fea, const void* right_fea, void* cost,
+                      int B, int C, int d, int h, int w, int dtype, void* stream);
+
+/*
+ * Weight pre-pack for ragmi_conv3d_k3_fwd: reorders an nn.Conv3d weight
+ * [Cout, Cin, 3, 3, 3] (src/automl/operations_3d.py:37) into the per-lane
+ * broadcast fragments of v_mfma_f32_4x4x1_16b_f32.  `packed` must hold
+ * ragmi_conv3d_k3_packed_elems(Cout, Cin) elements.
+ */
+int64_t ragmi_conv3d_k3_packed_elems(int Cout, int Cin);
+int ragmi_conv3d_k3_pack(const void* weight, void* packed, int Cout, int Cin, int dtype, void* stream);
+
+/*
+ * Fused ConvBR_3d, 3x3x3 / stride 1 / pad 1 (src/automl/operations_3d.py:31-47),
+ * plus the running sum and channel concat of Cell_3d (src/models/rag_model.py:160-176):
+ *   v    = conv3d(x, W)[co]                      (fp32, bias-free)
+ *   v    = v * scale[co] + shift[co]             (folded eval BatchNorm3d; NULL scale => skip)
+ *   v    = max(v, 0)                  if relu
+ *   v   += res[b, res_ch(co), ...]    if res != NULL   (res may alias y: accumulate in place)
+ *   y[b, y_ch(co), z, y, x] = v
+ * Output channel co belongs to group g = co/4; y_ch(co) = y_group_ch[g] + co%4 when
+ * y_group_ch != NULL (host array of ceil(Cout/4) ints), else co; same for res_group_ch.
+ * Sibling convolutions that read the same input are fused by concatenating their
+ * weights along Cout and pointing each group at its own destination channels.
+ * x: [B, Cin, D, H, W] with batch stride x_bstride; y/res likewise.
+ */
+int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride,
+                        const void* packed_weight, const void* scale, const void* shift, int relu,
+                        void* y, int64_t y_bstride, const int32_t* y_group_ch,
+                        const void* res, int64_t res_bstride, const int32_t* res_group_ch,
+                        int B, int Cin, int Cout, int D, int H, int W,
+                        int dtype, void* stream);
+
+/*
+ * Introspection for profiling: which kernel instantiation(s) ragmi_conv3d_k3_fwd will launch
+ * for this shape.  Writes the x-tile log2 width and rows per lane, and the output-group count
+ * (G) of each launch into launch_groups[0..max_launches); returns the number of launches
+ * (kernel name: conv3d_k3_kernel<G, log_tx, rows_per_lane>) or a negative error code.
+ */
+int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int32_t* log_tx, int32_t* rows_per_lane,
+                         int32_t* launch_groups, int32_t max_launches);
+
+/*
+ * Fused ConvBR_3d, 1x1x1 (Cell_3d.pre_preprocess / preprocess, rag_model.py:125-126,
+ * last_6_3d / last_12_3d :270-271): channel mix + folded BN + ReLU, HBM-bound.
+ * weight: raw nn.Conv3d weight [Cout, Cin] (1x1x1 squeezed), row-major.
+ * Writes y[b, y_ch0 + co, ...].
+ */
+int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride,
+                        const void* weight, const void* scale, const void* shift, int relu,
+                        void* y, int64_t y_bstride, int y_ch0,
+                        int B, int Cin, int Cout, int64_t DHW,
+                        int dtype, void* stream);
+
+/*
+ * Trilinear resample, F.interpolate(mode='trilinear') with ATen's source-index
+ * rule for align_corners = 1 (rag_model.py:150-153, 357-358) or 0.
+ * x: [B, C, Di, Hi, Wi] -> y: [B, C, Do, Ho, Wo] (contiguous).
+ */
+int ragmi_trilinear3d_fwd(const void* x, void* y, int B, int C,
+                          int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                          int align_corners, int dtype, void* stream);
+
+/*
+ * y[b, y_ch0 + c] = a[b, a_ch0 + c] + b[b, b_ch0 + c]   (sum of two Identity_3d branches,
+ * rag_model.py:172 with operations_3d.py:84-90).
+ */
+int ragmi_add_fwd(const void* a, int64_t a_bstride, int a_ch0,
+                  const void* b, int64_t b_bstride, int b_ch0,
+                  void* y, int64_t y_bstride, int y_ch0,
+                  int B, int C, int64_t DHW, int dtype, void* stream);
+
+/*
+ * Fused Disp.forward (rag_model.py:39-44): trilinear upsample of cost[B,1,d,h,w] to
+ * [maxdisp, Ho, Wo] (align_corners=False) -> Softmin over the disparity axis ->
+ * DisparityRegression (sum_d p_d * d).  The reference always uses Ho=3h, Wo=3w.
+ * out: [B, Ho, Wo] fp32.  Nothing of size maxdisp*Ho*Wo is materialised.
+ */
+int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int d, int h, int w,
+                              int maxdisp, int Ho, int Wo, int dtype, void* stream);
+
+/*
+ * DisparityRegression.forward (rag_model.py:23-29): out[b,y,x] = sum_d prob[b,d,y,x] * d.
+ * prob: [B, D, H, W] contiguous -> out [B, H, W] fp32.
+ */
+int ragmi_disparity_regression_fwd(const void* prob, void* out, int B, int D, int H, int W,
+                                   int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAG_AMD_H */

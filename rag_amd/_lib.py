@@ -1,0 +1,65 @@
+"""ctypes binding of librag_amd.so (C ABI declared in include/rag_amd.h)."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_LOCK = threading.Lock()
+
+c_void_p, c_int, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+# name -> (restype, argtypes); mirrors include/rag_amd.h one-to-one
+SIGNATURES = {
+    "ragmi_version": (c_int, []),
+    "ragmi_last_error": (ctypes.c_char_p, []),
+    "ragmi_costvol_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k3_packed_elems": (c_int64, [c_int, c_int]),
+    "ragmi_conv3d_k3_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k3_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_int64, c_int32_p, c_void_p, c_int64, c_int32_p,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int32_p, c_int32_p, c_int32_p, c_int]),
+    "ragmi_conv3d_k1_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "ragmi_trilinear3d_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+    "ragmi_add_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
+                              c_int, c_int, c_int64, c_int, c_void_p]),
+    "ragmi_disp_softargmin_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_void_p]),
+    "ragmi_disparity_regression_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return os.environ.get("RAG_AMD_LIB", os.path.join(_HERE, "lib", "librag_amd.so"))
+
+
+def load_library():
+    """Load librag_amd.so and bind every exported entry point.  Raises if the HIP library
+    has not been built (there is deliberately no fallback path)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LOCK:
+        if _LIB is None:
+            path = lib_path()
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    f"rag_amd: HIP library not found at {path}. Build it with `make` at the repo root "
+                    "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+            lib = ctypes.CDLL(path)
+            for name, (restype, argtypes) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _LIB = lib
+    return _LIB
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load_library().ragmi_last_error()
+        raise RuntimeError(f"rag_amd.{what} failed with status {status}: {msg.decode() if msg else ''}")

@@ -1,0 +1,445 @@
+"""Host-side mirror of the reference's Matching-Net modules, running on librag_amd.so.
+
+Names, constructor signatures, attribute names and state_dict key layout follow
+chzhang18/RAG (src/models/rag_model.py, src/automl/operations_3d.py,
+src/automl/genotypes_{2d,3d}.py) so a reference checkpoint loads unchanged and the
+approaches/automl growth loop can poke the same attributes.  The arithmetic is NOT
+PyTorch: every forward below enqueues hand-written HIP kernels through ``rag_amd.ops``.
+
+New seam (named by BASELINE.json north_star; the reference inlines it in Network.forward,
+rag_model.py:375-386): ``MatchingNet.forward(left_fea, right_fea) -> disp[B, 3h, 3w]``.
+
+Round-1 scope: inference (eval-mode BatchNorm, no autograd).  Train-mode BN / backward
+raise NotImplementedError rather than falling back to PyTorch.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+# src/automl/genotypes_2d.py:4-8 — the genotype handed to Network / Cell_3d; 3-D cells read `.reduce`
+Genotype = namedtuple("Genotype_2D", "normal normal_concat reduce reduce_concat")
+# src/automl/genotypes_3d.py:6-9
+PRIMITIVES_3D = ["skip_connect_3d", "3d_conv_3x3"]
+
+ALL_CONV_ROWS = np.array([[0, 1], [1, 1], [2, 1], [3, 1], [5, 1], [6, 1]])
+ALL_SKIP_ROWS = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [5, 0], [6, 0]])
+ALL_CONV_GENOTYPE = Genotype(normal=ALL_CONV_ROWS, normal_concat=None, reduce=ALL_CONV_ROWS, reduce_concat=None)
+ALL_SKIP_GENOTYPE = Genotype(normal=ALL_SKIP_ROWS, normal_concat=None, reduce=ALL_SKIP_ROWS, reduce_concat=None)
+
+
+def _require_inference(*tensors_or_params) -> None:
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors_or_params):
+        raise NotImplementedError(
+            "rag_amd: the HIP Matching-Net path is forward/inference only in this round (no autograd); "
+            "call it under torch.no_grad(). There is no PyTorch fallback by design.")
+
+
+class Identity_3d(nn.Module):
+    """src/automl/operations_3d.py:84-90."""
+
+    def forward(self, x):
+        return x
+
+
+class ConvBR_3d(nn.Module):
+    """Conv3d(bias=False) -> BatchNorm3d -> ReLU as ONE fused HIP kernel.
+
+    Mirrors src/automl/operations_3d.py:31-47 (same ctor, same sub-module names `conv`/`bn`,
+    `bn` constructed even when bn=False, same init :49-55).  Supported on the HIP path:
+    kernel_size 3 (padding 1) and 1 (padding 0), stride 1 — all the reference instantiates.
+    """
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, bn=True, relu=True):
+        super().__init__()
+        self.relu = relu
+        self.use_bn = bn
+        self.conv = nn.Conv3d(C_in, C_out, kernel_size, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm3d(C_out)
+        self._initialize_weights()
+        self._cache = None
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    # -- HIP-side parameters: packed weights + folded eval-mode BN, cached on tensor versions
+    def _geometry(self) -> int:
+        k = self.conv.kernel_size
+        if k not in ((1, 1, 1), (3, 3, 3)) or self.conv.stride != (1, 1, 1) or \
+                self.conv.padding != tuple((ki - 1) // 2 for ki in k) or self.conv.dilation != (1, 1, 1) or self.conv.groups != 1:
+            raise NotImplementedError("rag_amd.ConvBR_3d: only 1x1x1/pad0 and 3x3x3/pad1, stride 1 are built "
+                                      "(everything the reference's Matching Net instantiates)")
+        return k[0]
+
+    def stamp(self) -> tuple:
+        w, bn = self.conv.weight, self.bn
+        return (w.data_ptr(), w._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+                bn.running_var._version, bn.weight.data_ptr(), str(w.device), self.use_bn)
+
+    def prepared(self) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """(weights in kernel layout, scale, shift); scale/shift None when bn=False."""
+        if self.use_bn and self.bn.training:
+            raise NotImplementedError("rag_amd.ConvBR_3d: train-mode BatchNorm (batch statistics) is not built yet; "
+                                      "put the module in eval() — no PyTorch fallback by design")
+        stamp = self.stamp()
+        if self._cache is None or self._cache[0] != stamp:
+            k = self._geometry()
+            w = self.conv.weight.detach()
+            with torch.no_grad():
+                wk = ops.conv3d_k3_pack(w) if k == 3 else w.reshape(w.shape[0], w.shape[1]).contiguous()
+                if self.use_bn:
+                    bn = self.bn
+                    # same folding ATen's eval batch_norm uses: alpha = gamma * rsqrt(var + eps); beta = b - mean * alpha
+                    scale = (bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)).float().contiguous()
+                    shift = (bn.bias.detach() - bn.running_mean.detach() * scale).float().contiguous()
+                else:
+                    scale = shift = None
+            self._cache = (stamp, wk, scale, shift)
+        return self._cache[1], self._cache[2], self._cache[3]
+
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_ch0: int = 0) -> torch.Tensor:
+        _require_inference(x, self.conv.weight)
+        k = self._geometry()
+        wk, scale, shift = self.prepared()
+        cout = self.conv.out_channels
+        if out is None:
+            out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+        if k == 3:
+            groups = [out_ch0 + 4 * g for g in range(ops.packed_groups(cout))]
+            ops.conv3d_k3(x, wk, cout, scale, shift, self.relu, out, groups)
+        else:
+            ops.conv3d_k1(x, wk, scale, shift, self.relu, out, out_ch0)
+        return out
+
+
+# src/automl/operations_3d.py:5-8 (stride is always 1 on the hot path)
+def _skip(C, stride):
+    if stride != 1:
+        raise NotImplementedError("skip_connect_3d with stride != 1 is dead code in the reference (FactorizedReduce typo)")
+    return Identity_3d()
+
+
+OPS_3d = {
+    "skip_connect_3d": _skip,
+    "3d_conv_3x3": lambda C, stride: ConvBR_3d(C, C, 3, stride, 1),
+}
+
+
+class DisparityRegression(nn.Module):
+    """src/models/rag_model.py:18-29: out[b,y,x] = sum_d x[b,d,y,x] * d."""
+
+    def __init__(self, maxdisp):
+        super().__init__()
+        self.maxdisp = maxdisp
+
+    def forward(self, x):
+        assert x.is_contiguous() is True
+        _require_inference(x)
+        return ops.disparity_regression(x, self.maxdisp)
+
+
+class Disp(nn.Module):
+    """src/models/rag_model.py:32-44, fused: trilinear x3 (align_corners=False) -> Softmin -> regression."""
+
+    def __init__(self, maxdisp=192):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.softmax = nn.Softmin(dim=1)                            # kept for attribute parity; unused
+        self.disparity = DisparityRegression(maxdisp=self.maxdisp)  # idem
+
+    def forward(self, x):
+        _require_inference(x)
+        return ops.disp_softargmin(x, self.maxdisp)
+
+
+class Cell_3d(nn.Module):
+    """src/models/rag_model.py:114-177 on HIP kernels.
+
+    forward(prev_prev_input, prev_input) -> (prev_input, concat).  The 1x1x1 preprocess convs
+    write s0|s1 into one buffer, every selected op writes/accumulates straight into its
+    channel slice of the concat buffer (no `sum`, no `torch.cat` passes), and sibling
+    3x3x3 convs that read the same state run as one launch.  Op/branch pairing is
+    positional like the reference (ops created in genotype-row order, consumed in
+    ascending-branch visit order: SURVEY.md §8 A6).
+    """
+
+    def __init__(self, steps, block_multiplier, prev_prev_fmultiplier, prev_filter_multiplier, genotype,
+                 filter_multiplier, downup_sample):
+        super().__init__()
+        self.genotype = genotype
+        self.C_in = block_multiplier * filter_multiplier
+        self.C_out = filter_multiplier
+        self.C_prev = int(block_multiplier * prev_filter_multiplier)
+        self.C_prev_prev = int(block_multiplier * prev_prev_fmultiplier)
+        self.downup_sample = downup_sample
+        self.pre_preprocess = ConvBR_3d(self.C_prev_prev, self.C_out, 1, 1, 0)
+        self.preprocess = ConvBR_3d(self.C_prev, self.C_out, 1, 1, 0)
+        self._steps = steps
+        self.block_multiplier = block_multiplier
+        self._ops = nn.ModuleList()
+        if downup_sample == -1:
+            self.scale = 0.5
+        elif downup_sample == 1:
+            self.scale = 2
+        for x in self.genotype.reduce:
+            primitive = PRIMITIVES_3D[x[1]]
+            self._ops.append(OPS_3d[primitive](self.C_out, stride=1))
+        self._fused_cache: Dict[tuple, tuple] = {}
+
+    def scale_dimension(self, dim, scale):
+        return int((float(dim) - 1.0) * scale + 1.0) if dim % 2 == 1 else int(float(dim) * scale)
+
+    def _contributions(self) -> Dict[int, List[Tuple[int, nn.Module]]]:
+        """new-state index -> [(source state j, op module)] in the reference's visit order."""
+        selected = set(int(v) for v in np.asarray(self.genotype.reduce)[:, 0])
+        contribs: Dict[int, List[Tuple[int, nn.Module]]] = {}
+        offset, n_states, ops_index = 0, 2, 0
+        for _ in range(self._steps):
+            lst = []
+            for j in range(n_states):
+                if offset + j in selected:
+                    lst.append((j, self._ops[ops_index]))
+                    ops_index += 1
+            contribs[n_states] = lst
+            offset += n_states
+            n_states += 1
+        return contribs
+
+    def _fused(self, mods: Sequence[ConvBR_3d]):
+        """Concatenated packed weights / scale / shift of sibling convs (cached on their stamps)."""
+        key = tuple(id(m) for m in mods)
+        stamps = tuple(m.stamp() for m in mods)
+        hit = self._fused_cache.get(key)
+        if hit is None or hit[0] != stamps:
+            prep = [m.prepared() for m in mods]
+            if len(mods) == 1:
+                fused = prep[0]
+            else:
+                fused = (torch.cat([p[0] for p in prep]), torch.cat([p[1] for p in prep]), torch.cat([p[2] for p in prep]))
+            hit = (stamps, fused)
+            self._fused_cache[key] = hit
+        return hit[1]
+
+    def forward(self, prev_prev_input, prev_input):
+        _require_inference(prev_prev_input, prev_input)
+        C = self.C_out
+        if C % 4 != 0 or self.block_multiplier > self._steps:
+            raise NotImplementedError("rag_amd.Cell_3d: filter_multiplier must be a multiple of 4 and "
+                                      "block_multiplier <= steps (true for every cell the reference builds)")
+        s0, s1 = prev_prev_input, prev_input
+        if self.downup_sample != 0:
+            size = [self.scale_dimension(s1.shape[2], self.scale), self.scale_dimension(s1.shape[3], self.scale),
+                    self.scale_dimension(s1.shape[4], self.scale)]
+            s1 = ops.trilinear3d(s1, size, True)
+        if tuple(s0.shape[2:]) != tuple(s1.shape[2:]):
+            s0 = ops.trilinear3d(s0, s1.shape[2:], True)
+        B, _, D, H, W = s1.shape
+        dev = s1.device
+
+        pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=torch.float32)
+        n_states = 2 + self._steps
+        first_cat = n_states - self.block_multiplier             # first state that lands in the concat buffer
+        cat = torch.empty((B, self.block_multiplier * C, D, H, W), device=dev, dtype=torch.float32)
+        scratch = (torch.empty((B, (first_cat - 2) * C, D, H, W), device=dev, dtype=torch.float32)
+                   if first_cat > 2 else None)
+
+        # (buffer, first channel) of every state
+        where: List[Tuple[torch.Tensor, int]] = []
+        if s0.shape[1] != C:
+            self.pre_preprocess(s0, out=pre, out_ch0=0)
+            where.append((pre, 0))
+        else:
+            where.append((s0.contiguous(), 0))
+        self.preprocess(s1, out=pre, out_ch0=C)
+        where.append((pre, C))
+        for k in range(2, n_states):
+            where.append((cat, (k - first_cat) * C) if k >= first_cat else (scratch, (k - 2) * C))
+
+        contribs = self._contributions()
+        written = {k: False for k in contribs}
+        pending_id = {k: [j for (j, op) in lst if not isinstance(op, ConvBR_3d)] for k, lst in contribs.items()}
+        for k, lst in contribs.items():
+            if not lst:
+                raise ValueError("Cell_3d: a step with no selected branch (the reference fails in torch.cat here too)")
+
+        def finalize(k: int) -> None:
+            buf, ch = where[k]
+            ids = pending_id[k]
+            while ids:
+                if not written[k]:
+                    if len(ids) >= 2:
+                        (ba, ca), (bb, cb) = where[ids[0]], where[ids[1]]
+                        ops.add(ba, ca, bb, cb, buf, ch, C)
+                        del ids[:2]
+                    else:
+                        bs, cs = where[ids.pop(0)]
+                        buf[:, ch:ch + C].copy_(bs[:, cs:cs + C])   # lone identity: plain device copy
+                    written[k] = True
+                else:
+                    bs, cs = where[ids.pop(0)]
+                    ops.add(buf, ch, bs, cs, buf, ch, C)
+
+        for j in range(n_states):
+            if j >= 2:
+                finalize(j)
+            parts: Dict[object, list] = {}
+            for k, lst in contribs.items():
+                for (src, op) in lst:
+                    if src != j or not isinstance(op, ConvBR_3d):
+                        continue
+                    if written[k]:
+                        res = where[k]                                   # running sum: accumulate in place
+                    else:
+                        ready = [i for i in pending_id[k] if i <= j]     # identity partner already complete
+                        if ready:
+                            pending_id[k].remove(ready[0])
+                            res = where[ready[0]]
+                        else:
+                            res = None
+                    written[k] = True
+                    parts.setdefault(None if res is None else id(res[0]), []).append((k, op, res))
+            if not parts:
+                continue
+            xbuf, xch = where[j]
+            x = xbuf[:, xch:xch + C]
+            for items in parts.values():
+                mods = [op for (_k, op, _r) in items]
+                packed, scale, shift = self._fused(mods)
+                out_groups, res_groups = [], []
+                for (k, _op, res) in items:
+                    out_groups += [where[k][1] + 4 * g for g in range(C // 4)]
+                    if res is not None:
+                        res_groups += [res[1] + 4 * g for g in range(C // 4)]
+                res_buf = items[0][2][0] if items[0][2] is not None else None
+                # all destinations of one launch live in one buffer except when a scratch state is involved
+                by_buf: Dict[int, list] = {}
+                for idx, (k, _op, _res) in enumerate(items):
+                    by_buf.setdefault(id(where[k][0]), []).append(idx)
+                if len(by_buf) == 1:
+                    ops.conv3d_k3(x, packed, C * len(mods), scale, shift, True, where[items[0][0]][0], out_groups,
+                                  res_buf, res_groups if res_buf is not None else None)
+                else:
+                    for idxs in by_buf.values():
+                        sub = [items[i] for i in idxs]
+                        p2, s2, h2 = self._fused([op for (_k, op, _r) in sub])
+                        og = [where[k][1] + 4 * g for (k, _o, _r) in sub for g in range(C // 4)]
+                        rg = [r[1] + 4 * g for (_k, _o, r) in sub if r is not None for g in range(C // 4)]
+                        ops.conv3d_k3(x, p2, C * len(sub), s2, h2, True, where[sub[0][0]][0], og,
+                                      res_buf, rg if res_buf is not None else None)
+        for k in contribs:
+            finalize(k)
+        concat_feature = cat
+        return prev_input, concat_feature
+
+
+# Matching-Net macro architecture, src/models/rag_model.py:238-261:
+# (prev_prev_fmultiplier, prev_filter_multiplier, filter_multiplier, downup_sample)
+_CELL3D_ARCH = ((4, 4, 4, 0), (4, 4, 4, 0), (4, 4, 4, 0), (4, 4, 8, -1),
+                (4, 8, 16, -1), (8, 16, 8, 1), (16, 8, 16, -1), (8, 16, 16, 0))
+
+
+class MatchingNet(nn.Module):
+    """The Matching-Net half of the reference `Network` (src/models/rag_model.py:230-275, 325-387).
+
+    forward(left_fea[B,C,h,w], right_fea[B,C,h,w], task_arch=None) -> disp[B,3h,3w] wraps the three
+    hot pieces the reference runs inline: cost-volume loop (:375-383) -> matching() (:325-366) ->
+    Disp (:32-44).  Sub-module names (stem3d0, stem3d1, cells_3d, last_3_3d, last_6_3d, last_12_3d,
+    disp) and therefore state_dict keys are the reference's; units are nn.ModuleLists indexed by
+    task_arch[name][0] exactly like Network.matching.  `maxdisp` is a ctor argument (the reference
+    hard-codes 192, rag_model.py:274).
+    """
+
+    def __init__(self, genotype=ALL_CONV_GENOTYPE, maxdisp: int = 192):
+        super().__init__()
+        self._init_matching(genotype, maxdisp)
+
+    def _init_matching(self, genotype, maxdisp):
+        self._step = 3
+        self._block_multiplier = 3
+        self._filter_multiplier = 4
+        self._num_layers_3d = 8
+        initial_fm = self._filter_multiplier * self._block_multiplier
+        if not hasattr(self, "length"):
+            self.length, self.arch_init = {}, {}
+        for name in ("stem_3d0", "stem_3d1", "last_3_3d", "last_6_3d", "last_12_3d"):
+            self.length[name] = 1
+            self.arch_init[name] = [0]
+        self.cells_3d = nn.ModuleList()
+        self.stem3d0 = nn.ModuleList([ConvBR_3d(initial_fm * 2, initial_fm, 3, stride=1, padding=1)])
+        self.stem3d1 = nn.ModuleList([ConvBR_3d(initial_fm, initial_fm, 3, stride=1, padding=1)])
+        for i in range(self._num_layers_3d):
+            self.cells_3d.append(nn.ModuleList([self._new_cell_3d(i, genotype)]))
+            self.arch_init["cell_3d" + str(i)] = [0]
+            self.length["cell_3d" + str(i)] = 1
+        self.last_3_3d = nn.ModuleList([ConvBR_3d(initial_fm, 1, 3, 1, 1, bn=False, relu=False)])
+        self.last_6_3d = nn.ModuleList([ConvBR_3d(initial_fm * 2, initial_fm, 1, 1, 0)])
+        self.last_12_3d = nn.ModuleList([ConvBR_3d(initial_fm * 4, initial_fm * 2, 1, 1, 0)])
+        self.maxdisp = maxdisp
+        self.disp = Disp(self.maxdisp)
+
+    def _new_cell_3d(self, i: int, genotype) -> Cell_3d:
+        pp, p, fm, du = _CELL3D_ARCH[i]
+        return Cell_3d(self._step, self._block_multiplier, pp, p, genotype, fm, du)
+
+    # -- rag_model.py:325-366
+    def matching(self, x, task_arch, path=None):
+        def unit(name):
+            return task_arch[name][0] if task_arch is not None else None
+
+        stem0 = self.stem3d0[unit("stem_3d0")](x)
+        stem1 = self.stem3d1[unit("stem_3d1")](stem0)
+        out = (stem0, stem1)
+        for i, cell in enumerate(self.cells_3d):
+            arch_cell = None
+            if task_arch is not None:
+                arch_cell = task_arch["cell_3d" + str(i)][0]
+            elif path is not None:
+                arch_cell = path[i + 1]
+            out = cell[arch_cell](out[0], out[1])
+        return self._head(x, out[-1], unit("last_3_3d"), unit("last_6_3d"), unit("last_12_3d"))
+
+    # -- rag_model.py:663-685
+    def search_matching(self, x, selected_ops, t):
+        stem0 = self.stem3d0[selected_ops[8]](x)
+        stem1 = self.stem3d1[selected_ops[9]](stem0)
+        out = (stem0, stem1)
+        for i, cell in enumerate(self.cells_3d):
+            out = cell[selected_ops[i + 10]](out[0], out[1])
+        return self._head(x, out[-1], t, t, t)
+
+    def _head(self, x, last_output, i3, i6, i12):
+        d, h, w = x.size()[2], x.size()[3], x.size()[4]
+        if last_output.size()[3] == h:
+            return self.last_3_3d[i3](last_output)
+        if last_output.size()[3] == h // 2:
+            y = ops.trilinear3d(self.last_6_3d[i6](last_output), (d, h, w), True)
+            return self.last_3_3d[i3](y)
+        if last_output.size()[3] == h // 4:
+            y = ops.trilinear3d(self.last_12_3d[i12](last_output), (d // 2, h // 2, w // 2), True)
+            y = ops.trilinear3d(self.last_6_3d[i6](y), (d, h, w), True)
+            return self.last_3_3d[i3](y)
+        # the reference reaches `return mat` with mat unbound here (UnboundLocalError)
+        raise ValueError("MatchingNet: feature height must be a multiple of 4 (input H a multiple of 12)")
+
+    def cost_volume(self, left_fea, right_fea):
+        """The inline loop of rag_model.py:375-383 as one kernel."""
+        return ops.costvol(left_fea, right_fea, self.maxdisp)
+
+    def forward(self, left_fea, right_fea, task_arch=None):
+        _require_inference(left_fea, right_fea)
+        if task_arch is None:
+            task_arch = self.arch_init
+        cost = self.cost_volume(left_fea, right_fea)
+        cost = self.matching(cost, task_arch, None)
+        return self.disp(cost)

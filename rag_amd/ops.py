@@ -1,0 +1,190 @@
+"""Thin tensor-level wrappers over the C ABI (include/rag_amd.h).
+
+Every function takes CUDA(=HIP) fp32 tensors, passes raw device pointers, sizes and the
+current torch stream to librag_amd.so and returns the output tensor.  No arithmetic
+happens in Python/PyTorch here: torch only allocates.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from ._lib import check, load_library
+
+F32 = 0
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("rag_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"rag_amd ops: dtype {t.dtype} not built (fp32 only)")
+
+
+def _planes(t: torch.Tensor) -> int:
+    """Check t is [B, C, ...] with dense channel planes (a channel-slice view of a contiguous
+    buffer is fine) and return its batch stride in elements."""
+    inner = 1
+    for i in range(t.dim() - 1, 0, -1):
+        if t.shape[i] != 1 and t.stride(i) != inner:
+            raise RuntimeError(f"rag_amd ops: planes must be dense N-C-D-H-W, got strides {t.stride()} for {tuple(t.shape)}")
+        inner *= t.shape[i]
+    return int(t.stride(0))
+
+
+def _i32_array(vals: Optional[Sequence[int]]):
+    if vals is None:
+        return None
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def costvol(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cost[B,2C,maxdisp/3,h,w] of src/models/rag_model.py:375-383."""
+    _need_gpu(left_fea, right_fea)
+    if left_fea.shape != right_fea.shape or left_fea.dim() != 4:
+        raise ValueError("costvol: left/right features must both be [B, C, h, w]")
+    left_fea, right_fea = left_fea.contiguous(), right_fea.contiguous()
+    B, C, h, w = left_fea.shape
+    d = int(maxdisp / 3)
+    if out is None:
+        out = torch.empty((B, 2 * C, d, h, w), device=left_fea.device, dtype=torch.float32)
+    check(load_library().ragmi_costvol_fwd(left_fea.data_ptr(), right_fea.data_ptr(), out.data_ptr(),
+                                           B, C, d, h, w, F32, _stream()), "costvol")
+    return out
+
+
+def conv3d_k3_pack(weight: torch.Tensor) -> torch.Tensor:
+    """Pre-pack an nn.Conv3d weight [Cout, Cin, 3, 3, 3] for conv3d_k3."""
+    _need_gpu(weight)
+    Cout, Cin = weight.shape[:2]
+    if tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError("conv3d_k3_pack: weight must be [Cout, Cin, 3, 3, 3]")
+    lib = load_library()
+    n = lib.ragmi_conv3d_k3_packed_elems(Cout, Cin)
+    packed = torch.empty((n,), device=weight.device, dtype=torch.float32)
+    w = weight.detach().contiguous()
+    check(lib.ragmi_conv3d_k3_pack(w.data_ptr(), packed.data_ptr(), Cout, Cin, F32, _stream()), "conv3d_k3_pack")
+    return packed
+
+
+def conv3d_k3_plan(cout: int, B: int, D: int, H: int, W: int):
+    """(log2 x-tile, rows per lane, [G of each launch]) that conv3d_k3 will use for this shape;
+    the kernel instantiation is conv3d_k3_kernel<G, log_tx, rows>."""
+    log_tx, rows = ctypes.c_int32(), ctypes.c_int32()
+    groups = (ctypes.c_int32 * 16)()
+    n = load_library().ragmi_conv3d_k3_plan(cout, B, D, H, W, ctypes.byref(log_tx), ctypes.byref(rows), groups, 16)
+    if n < 0:
+        check(n, "conv3d_k3_plan")
+    return log_tx.value, rows.value, [groups[i] for i in range(n)]
+
+
+def packed_groups(cout: int) -> int:
+    return (cout + 3) // 4
+
+
+def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+              relu: bool, out: torch.Tensor, out_group_ch: Optional[Sequence[int]] = None,
+              res: Optional[torch.Tensor] = None, res_group_ch: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Fused 3x3x3 ConvBR_3d (+ running sum / concat): see ragmi_conv3d_k3_fwd in include/rag_amd.h.
+    `out` (and `res`) are [B, C*, D, H, W] buffers; group g of 4 output channels lands at channel
+    out_group_ch[g] (default 4g)."""
+    _need_gpu(x, packed, scale, shift, out, res)
+    B, Cin, D, H, W = x.shape
+    xb = _planes(x)
+    yb = _planes(out)
+    rb = _planes(res) if res is not None else 0
+    ng = packed_groups(cout)
+    if out_group_ch is not None and len(out_group_ch) != ng:
+        raise ValueError("conv3d_k3: out_group_ch needs one entry per group of 4 output channels")
+    if res is not None and res_group_ch is None:
+        res_group_ch = out_group_ch
+    if tuple(out.shape[2:]) != (D, H, W) or out.shape[0] != B:
+        raise ValueError("conv3d_k3: out must be [B, C, D, H, W] of the input's spatial size")
+    max_ch = max(out_group_ch) + 4 if out_group_ch is not None else cout
+    if max_ch > out.shape[1] + (3 if cout % 4 else 0):
+        raise ValueError("conv3d_k3: destination channels exceed the output buffer")
+    check(load_library().ragmi_conv3d_k3_fwd(
+        x.data_ptr(), xb, packed.data_ptr(),
+        scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
+        out.data_ptr(), yb, _i32_array(out_group_ch),
+        res.data_ptr() if res is not None else None, rb, _i32_array(res_group_ch),
+        B, Cin, cout, D, H, W, F32, _stream()), "conv3d_k3")
+    return out
+
+
+def conv3d_k1(x: torch.Tensor, weight2d: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+              relu: bool, out: torch.Tensor, out_ch0: int = 0) -> torch.Tensor:
+    """Fused 1x1x1 ConvBR_3d writing out[:, out_ch0:out_ch0+Cout]."""
+    _need_gpu(x, weight2d, scale, shift, out)
+    B, Cin = x.shape[:2]
+    Cout = weight2d.shape[0]
+    dhw = 1
+    for s in x.shape[2:]:
+        dhw *= s
+    if out_ch0 + Cout > out.shape[1] or tuple(out.shape[2:]) != tuple(x.shape[2:]):
+        raise ValueError("conv3d_k1: output buffer too small / wrong spatial size")
+    check(load_library().ragmi_conv3d_k1_fwd(
+        x.data_ptr(), _planes(x), weight2d.data_ptr(),
+        scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
+        out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, dhw, F32, _stream()), "conv3d_k1")
+    return out
+
+
+def trilinear3d(x: torch.Tensor, size: Sequence[int], align_corners: bool) -> torch.Tensor:
+    """F.interpolate(x, size, mode='trilinear', align_corners=...) for x[B,C,D,H,W]."""
+    _need_gpu(x)
+    x = x.contiguous()
+    B, C, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = [int(s) for s in size]
+    out = torch.empty((B, C, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+    check(load_library().ragmi_trilinear3d_fwd(x.data_ptr(), out.data_ptr(), B, C, Di, Hi, Wi, Do, Ho, Wo,
+                                               int(bool(align_corners)), F32, _stream()), "trilinear3d")
+    return out
+
+
+def add(a: torch.Tensor, a_ch0: int, b: torch.Tensor, b_ch0: int, out: torch.Tensor, out_ch0: int, channels: int) -> torch.Tensor:
+    """out[:, out_ch0:+C] = a[:, a_ch0:+C] + b[:, b_ch0:+C]."""
+    _need_gpu(a, b, out)
+    dhw = 1
+    for s in a.shape[2:]:
+        dhw *= s
+    check(load_library().ragmi_add_fwd(a.data_ptr(), _planes(a), a_ch0, b.data_ptr(), _planes(b), b_ch0,
+                                       out.data_ptr(), _planes(out), out_ch0, a.shape[0], channels, dhw, F32, _stream()), "add")
+    return out
+
+
+def disp_softargmin(cost: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """Fused Disp.forward: cost[B,1,d,h,w] (or [B,d,h,w]) -> disparity [B,3h,3w]."""
+    _need_gpu(cost)
+    if cost.dim() == 5:
+        if cost.shape[1] != 1:
+            raise ValueError("disp_softargmin: expected a single-channel cost volume")
+        cost = cost[:, 0]
+    cost = cost.contiguous()
+    B, d, h, w = cost.shape
+    out = torch.empty((B, 3 * h, 3 * w), device=cost.device, dtype=torch.float32)
+    check(load_library().ragmi_disp_softargmin_fwd(cost.data_ptr(), out.data_ptr(), B, d, h, w, int(maxdisp),
+                                                   3 * h, 3 * w, F32, _stream()), "disp_softargmin")
+    return out
+
+
+def disparity_regression(prob: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """DisparityRegression.forward: prob[B,D,H,W] -> [B,H,W]."""
+    _need_gpu(prob)
+    assert prob.is_contiguous()  # the reference asserts this too (rag_model.py:24)
+    B, D, H, W = prob.shape
+    if D != maxdisp:
+        raise ValueError("disparity_regression: prob.shape[1] must equal maxdisp")
+    out = torch.empty((B, H, W), device=prob.device, dtype=torch.float32)
+    check(load_library().ragmi_disparity_regression_fwd(prob.data_ptr(), out.data_ptr(), B, D, H, W, F32, _stream()),
+          "disparity_regression")
+    return out

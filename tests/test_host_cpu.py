@@ -1,0 +1,121 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header
+declares, the host mirror keeps the reference's interface / state_dict layout, and the
+product path refuses to run without the GPU (no silent fallback)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, split_sd
+from oracle import matching_oracle as O
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    import rag_amd
+    if not os.path.exists(rag_amd.lib_path()):
+        subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True)
+    return rag_amd.load_library()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "rag_amd.h")).read()
+    declared = set(re.findall(r"\b(ragmi_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 11
+    from rag_amd._lib import SIGNATURES
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    for name in declared:
+        assert hasattr(built_lib, name), name
+    assert built_lib.ragmi_version() >= 100
+    assert built_lib.ragmi_conv3d_k3_packed_elems(12, 24) == 3 * 6 * 7 * 64
+
+
+def test_abi_rejects_bad_arguments_without_gpu(built_lib):
+    # argument validation happens before any launch, so it is checkable on CPU
+    assert built_lib.ragmi_costvol_fwd(None, None, None, 1, 12, 8, 4, 4, 0, None) == -1
+    assert b"null" in built_lib.ragmi_last_error()
+    assert built_lib.ragmi_conv3d_k3_pack(None, None, 4, 4, 0, None) == -1
+
+
+def test_ops_refuse_cpu_tensors(built_lib):
+    import rag_amd
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rag_amd.ops.costvol(torch.zeros(1, 12, 4, 4), torch.zeros(1, 12, 4, 4), 24)
+    net = rag_amd.MatchingNet(rag_amd.ALL_SKIP_GENOTYPE, 24).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 12, 8, 12), torch.zeros(1, 12, 8, 12))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import rag_amd._lib as L
+    monkeypatch.setattr(L, "_LIB", None)
+    monkeypatch.setenv("RAG_AMD_LIB", "/nonexistent/librag_amd.so")
+    with pytest.raises(RuntimeError, match="HIP library not found"):
+        L.load_library()
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "rag_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("fixture", ["g5_forward_conv_48x96_d48", "g5_forward_unsorted_36x60_d24", "g5_forward_skip_48x72_d24"])
+def test_state_dict_layout_matches_reference(fixture):
+    """Matching-Net keys and shapes of rag_amd.MatchingNet == the reference Network's (checkpoint drop-in)."""
+    import rag_amd
+    g = load_golden(fixture)
+    rows = g["rows"]
+    ref = {k: tuple(v.shape) for k, v in split_sd(g).items()
+           if k.split(".")[0] in ("stem3d0", "stem3d1", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d")}
+    net = rag_amd.MatchingNet(rag_amd.Genotype(rows, None, rows, None), maxdisp=int(g["maxdisp"]))
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert mine == ref
+    net.load_state_dict({k: v for k, v in split_sd(g).items() if k in ref}, strict=True)
+
+
+@pytest.mark.parametrize("rows", [O.ALL_CONV, O.ALL_SKIP, np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]]),
+                                  np.array([[1, 1], [0, 0], [4, 1], [2, 0], [7, 1], [8, 1]])])
+def test_cell_positional_op_pairing_matches_oracle(rows):
+    import rag_amd
+    cell = rag_amd.Cell_3d(3, 3, 4, 4, rag_amd.Genotype(rows, None, rows, None), 4, 0)
+    plan = O.resolve_cell_ops(rows)
+    contribs = cell._contributions()
+    for step, lst in enumerate(plan):
+        mine = contribs[2 + step]
+        assert [j for (j, _k, _t) in lst] == [j for (j, _op) in mine]
+        for (j, k, op_type), (_j, op) in zip(lst, mine):
+            assert op is cell._ops[k]
+            assert isinstance(op, rag_amd.ConvBR_3d) == (op_type == 1)
+
+
+def test_reference_interface_names():
+    import rag_amd
+    net = rag_amd.MatchingNet(rag_amd.ALL_CONV_GENOTYPE)
+    assert net.maxdisp == 192 and isinstance(net.disp, rag_amd.Disp)
+    for attr in ("stem3d0", "stem3d1", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d", "matching", "search_matching"):
+        assert hasattr(net, attr)
+    assert set(net.arch_init) == {"stem_3d0", "stem_3d1", "last_3_3d", "last_6_3d", "last_12_3d"} | {f"cell_3d{i}" for i in range(8)}
+    c = rag_amd.Cell_3d(3, 3, 4, 8, rag_amd.ALL_CONV_GENOTYPE, 16, -1)
+    assert (c.C_in, c.C_out, c.C_prev, c.C_prev_prev, c.scale) == (48, 16, 24, 12, 0.5)
+    assert c.scale_dimension(64, 0.5) == 32 and c.scale_dimension(7, 0.5) == 4 and c.scale_dimension(3, 2) == 5
+    m = rag_amd.ConvBR_3d(12, 1, 3, 1, 1, bn=False, relu=False)
+    assert "bn.weight" in m.state_dict()           # bn constructed even when unused (operations_3d.py:38)
+    assert list(rag_amd.OPS_3d) == ["skip_connect_3d", "3d_conv_3x3"] == rag_amd.PRIMITIVES_3D
+
+
+def test_training_mode_is_refused_not_emulated():
+    import rag_amd
+    m = rag_amd.ConvBR_3d(4, 4, 3, 1, 1)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m.prepared()
+    with pytest.raises(NotImplementedError):   # autograd through the HIP path is not silently dropped
+        m.eval()(torch.zeros(1, 4, 2, 2, 2, requires_grad=True))
