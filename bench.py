@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — disparity maps/sec of the Matching-Net forward (left_fea, right_fea) -> disp.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+torch.distributed.run with one rank per GPU.  A "step" is one pass of the hot path
+(cost volume -> 3-D conv aggregation -> soft-argmin) over one batch of synthetic stereo
+features already resident in HBM.  Workload at every N: BASELINE.json configs[1] per GPU
+(B=1, 384x1248, D=192, fp32, all-conv genotype, seeded weights with randomised BN —
+SURVEY.md §8(d)); pairs are independent, so ranks shard the batch with NO data-path
+collective (weak scaling).  Rank 0 prints ONE JSON line on stdout.
+
+Extra objects in that line:
+  roofline      the dominant kernel (conv3d_k3_kernel<3,5,4>: stems + level-3 cell convs),
+                bracketed by HIP events on the launch stream inside the timed region;
+                achieved = algorithmic FLOPs per launch / mean launch duration, peak = fp32
+                MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (a port of the reference's ATen op sequence) timed on the
+                host cores of this box on ONE pair of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, MAXDISP, FEA_C = 384, 1248, 192, 12
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_net(device, seed=0):
+    """Benchmark protocol of SURVEY.md §8(d): reference init (Kaiming fan_out, done by the module
+    ctor), then BN gamma~U(.5,1.5), beta~N(0,.1), running_mean~N(0,.1), running_var~U(.5,1.5)."""
+    import rag_amd
+    torch.manual_seed(seed)
+    net = rag_amd.MatchingNet(rag_amd.ALL_CONV_GENOTYPE, maxdisp=MAXDISP)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    return net.to(device).eval()
+
+
+class K3Profiler:
+    """Brackets every ragmi_conv3d_k3_fwd call with HIP events on the launch stream and
+    attributes it to the kernel instantiation the library reports (ragmi_conv3d_k3_plan)."""
+
+    def __init__(self, ops):
+        self.ops, self.records, self.enabled = ops, [], False
+        self._orig = ops.conv3d_k3
+
+        def wrapped(x, packed, cout, *a, **kw):
+            if not self.enabled:
+                return self._orig(x, packed, cout, *a, **kw)
+            B, Cin, D, Hh, Ww = x.shape
+            log_tx, rows, groups = ops.conv3d_k3_plan(cout, B, D, Hh, Ww)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._orig(x, packed, cout, *a, **kw)
+            e1.record()
+            self.records.append((e0, e1, (tuple(groups), log_tx, rows), 2.0 * 27 * Cin * cout * B * D * Hh * Ww,
+                                 4.0 * (Cin + cout) * B * D * Hh * Ww, len(groups)))
+            return out
+
+        ops.conv3d_k3 = wrapped
+
+    def summary(self):
+        by = {}
+        for e0, e1, key, flops, nbytes, nl in self.records:
+            d = by.setdefault(key, [0.0, 0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += flops
+            d[2] += nbytes
+            d[3] += nl
+        return by
+
+
+def cpu_baseline(net, lf, rf):
+    """Oracle leg (checker code, allowed here only): one pair of the same workload on host cores."""
+    from oracle import matching_oracle as O
+    cores = min(16, os.cpu_count() or 1)   # the 1-GPU box's CPU share
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    rows = O.ALL_CONV
+    O.matching_net_forward(lf[:, :, :16, :32].cpu().contiguous(), rf[:, :, :16, :32].cpu().contiguous(), sd, rows, 48)  # thread-pool warm-up
+    lc, rc = lf[:1].cpu(), rf[:1].cpu()
+    t0 = time.perf_counter()
+    ref = O.matching_net_forward(lc, rc, sd, rows, MAXDISP)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "disparity maps/s", "cores": cores, "kind": "port",
+            "sample": f"1 pair B=1 {H}x{W} D={MAXDISP} fp32, single timed run after a small-shape warm-up ({dt:.2f} s)"}, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (configs[1]: 1)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else args.gpus
+    if world == 1 and args.gpus > 1:
+        log(f"bench: --gpus {args.gpus} without a torch.distributed launcher: running 1 rank")
+        n_gpus = 1
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import rag_amd
+    rag_amd.load_library()          # fail loudly if the HIP extension is missing
+    net = build_net(device)
+    B, h, w = args.batch, H // 3, W // 3
+    g = torch.Generator().manual_seed(1234 + rank)
+    lf = torch.randn((B, FEA_C, h, w), generator=g).to(device)
+    rf = torch.randn((B, FEA_C, h, w), generator=g).to(device)
+
+    prof = K3Profiler(rag_amd.ops)
+
+    def step():
+        with torch.no_grad():
+            return net(lf, rf)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if args.graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        graph.replay()
+        torch.cuda.synchronize()
+
+    prof.enabled = graph is None and rank == 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if graph is not None and rank == 0:   # per-kernel events need eager launches: same kernels, extra pass
+        prof.enabled = True
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        prof.enabled = False
+
+    if rank == 0:
+        torch.cuda.synchronize()
+        by = prof.summary()
+        dom_key = max(by, key=lambda k: by[k][0]) if by else None
+        roofline = None
+        if dom_key is not None:
+            secs, flops, nbytes, nlaunch = by[dom_key]
+            groups, log_tx, rows = dom_key
+            ach = flops / secs * 1e-12
+            roofline = {"kernel": f"conv3d_k3_kernel<{groups[0]},{log_tx},{rows}>", "bound": "mfma",
+                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": nlaunch // args.steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
+                        "flops_per_launch": flops / nlaunch,
+                        "share_of_step": round(secs / args.steps / (dt / args.steps), 3)}
+            for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
+                log(f"  conv3d_k3 G={k[0]} tx=2^{k[1]} R={k[2]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
+                    f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
+        cpu = None
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cpu, ref = cpu_baseline(net, lf, rf)
+            from oracle import matching_oracle as O
+            epe = O.epe(out[:1].float().cpu(), ref)
+            log(f"  EPE of the timed GPU path vs the CPU oracle on the same pair: {epe:.3e} px")
+            cpu["epe_gpu_vs_cpu_px"] = epe
+        ms = dt / args.steps * 1e3
+        line = {
+            "metric": "disparity maps/sec at 384x1248 D=192 (Matching-Net forward)",
+            "value": round(n_gpus * B * args.steps / dt, 3), "unit": "disparity maps/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, fp32, "
+                                   "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
+                       "global_batch": n_gpus * B, "sharding": "batch split, no collective",
+                       "launch": "hipGraph" if graph is not None else "eager"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
