@@ -17,6 +17,8 @@
 //  * Epilogue fuses folded BatchNorm (scale/shift), ReLU, the Cell_3d running sum (res, may
 //    alias y) and torch.cat (per-group destination channel), so none of them is a pass.
 //  * Measured ceiling of the 4x4x1 form: 134 TFLOP/s (tools/probe_mfma.hip) vs 157 spec.
+#include <algorithm>
+
 #include "common.h"
 
 namespace ragmi {
@@ -36,7 +38,7 @@ struct K3Args {
   int64_t y_bstride;
   const float* res;
   int64_t res_bstride;
-  int Cin, Cout, D, H, W;
+  int B, Cin, Cout, D, H, W;
   int nchunks;     // ceil(Cin / 4)
   int co0;         // first output channel of this launch (multiple of 4)
   int relu;
@@ -67,27 +69,33 @@ __global__ void conv3d_k3_pack_kernel(const float* __restrict__ w, float* __rest
 }
 
 template <int G, int LOG_TX, int R>
-__global__ __launch_bounds__(256) void conv3d_k3_kernel(K3Args a) {
+__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(K3Args a) {
   constexpr int TX = 1 << LOG_TX;
   constexpr int YS = 64 / TX;      // lane sub-rows per wave
   constexpr int TY = YS * R;       // output rows per tile
   constexpr int TZ = 4;            // one z-plane per wave
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
   constexpr int TILE = CK * HZ * HY * HX;
+  // staging map: thread -> (sy, zz, xx) of the halo; passes over compile-time (c, k): yy = k*SY + sy
+  constexpr int SY = 256 / (HZ * HX);
+  constexpr int KY = (HY + SY - 1) / SY;
+  constexpr int NP = CK * KY;      // staging registers per thread
+  static_assert(SY >= 1, "tile too wide for the staging map");
   __shared__ float tile[TILE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
-  const int tx_i = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty_i = bid % a.tiles_y; bid /= a.tiles_y;
-  const int tz_i = bid % a.tiles_z;
-  const int b = bid / a.tiles_z;
-  const int x0 = tx_i * TX, y0 = ty_i * TY, z0 = tz_i * TZ;
-  const int64_t HW = (int64_t)a.H * a.W, DHW = HW * a.D;
+  const int HW = a.H * a.W;
+  const int64_t DHW = (int64_t)HW * a.D;
+  const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z * a.B;
 
+  // compute-side lane geometry
   const int xl = lane & (TX - 1), ysub = lane >> LOG_TX;
-  const float* rd = tile + (wave * HY + ysub * R) * HX + xl;  // lane's (dz=0, rr=0, dx=0) tap of channel 0
+  const float* rd = tile + (wave * HY + ysub * R) * HX + xl;  // lane's (c=0, dz=0, rr=0, dx=0) tap
+  // staging-side thread geometry
+  const int sxx = tid % HX, szz = (tid / HX) % HZ, ssy = tid / (HX * HZ);
+  const bool sactive = ssy < SY;
+  float* wr = tile + (szz * HY + ssy) * HX + sxx;             // + (c*HZ*HY + k*SY) * HX per pass
 
   f32x4 acc[R][G];
 #pragma unroll
@@ -95,33 +103,108 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(K3Args a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[r][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  float st[NP];  // next stage's halo elements, in flight during the MFMA phase
 
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    // weights of this chunk: NVG coalesced dword loads per group (L2-resident, tiny)
-    float wreg[G][NVG];
+  auto decode = [&](int t, int& b, int& x0, int& y0, int& z0) {
+    const int tx_i = t % a.tiles_x; t /= a.tiles_x;
+    const int ty_i = t % a.tiles_y; t /= a.tiles_y;
+    const int tz_i = t % a.tiles_z;
+    b = t / a.tiles_z;
+    x0 = tx_i * TX; y0 = ty_i * TY; z0 = tz_i * TZ;
+  };
+
+  // issue the global loads of stage (t, chunk): always in-bounds (clamped); validity is applied at write time
+  auto prefetch = [&](int t, int chunk) {
+    int b, x0, y0, z0;
+    decode(t, b, x0, y0, z0);
+    const float* xb = a.x + (int64_t)b * a.x_bstride;
+    const int gzc = min(max(z0 - 1 + szz, 0), a.D - 1), gxc = min(max(x0 - 1 + sxx, 0), a.W - 1);
+    const int zx = gzc * HW + gxc;
+    const int gy0 = y0 - 1 + ssy;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const float* xc = xb + (int64_t)min(chunk * CK + c, a.Cin - 1) * DHW;   // wave-uniform base
+#pragma unroll
+      for (int k = 0; k < KY; ++k) {
+        const int gyc = min(max(gy0 + k * SY, 0), a.H - 1);
+        st[c * KY + k] = xc[(unsigned)(zx + gyc * a.W)];
+      }
+    }
+  };
+
+  // write the staged stage (t, chunk) into LDS, zeroing everything outside the volume / past Cin
+  auto commit = [&](int t, int chunk) {
+    int b, x0, y0, z0;
+    decode(t, b, x0, y0, z0);
+    const bool zx_ok = sactive && (unsigned)(z0 - 1 + szz) < (unsigned)a.D && (unsigned)(x0 - 1 + sxx) < (unsigned)a.W;
+    const int gy0 = y0 - 1 + ssy;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const bool c_ok = chunk * CK + c < a.Cin;
+#pragma unroll
+      for (int k = 0; k < KY; ++k) {
+        const bool ok = zx_ok && c_ok && (unsigned)(gy0 + k * SY) < (unsigned)a.H;
+        if (sactive && k * SY + ssy < HY) wr[(c * HZ * HY + k * SY) * HX] = ok ? st[c * KY + k] : 0.f;
+      }
+    }
+  };
+
+  float wreg[G][NVG];
+  auto load_weights = [&](int chunk) {
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int v = 0; v < NVG; ++v)
-        wreg[g][v] = a.wp[((int64_t)(g * a.nchunks + chunk) * NVG + v) * 64 + lane];
+        wreg[g][v] = a.wp[((g * a.nchunks + chunk) * NVG + v) * 64 + lane];
+  };
 
-    if (chunk > 0) __syncthreads();  // previous chunk's reads are done before the tile is overwritten
-    // stage the halo tile: zero outside the volume (= conv zero padding) and past Cin
-#pragma unroll 8
-    for (int e = tid; e < TILE; e += 256) {
-      const int xx = e % HX;
-      int t = e / HX;
-      const int yy = t % HY;
-      t /= HY;
-      const int zz = t % HZ;
-      const int c = t / HZ;
-      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx, gc = chunk * CK + c;
-      const bool inb = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
-                       gc < a.Cin;
-      tile[e] = inb ? xb[(int64_t)gc * DHW + (int64_t)gz * HW + (int64_t)gy * a.W + gx] : 0.f;
+  auto epilogue = [&](int t, auto full_) {
+    constexpr bool FULL = decltype(full_)::value;
+    int b, x0, y0, z0;
+    decode(t, b, x0, y0, z0);
+    const int gz = z0 + wave, gx = x0 + xl, gy0 = y0 + ysub * R;
+    if (!FULL && (gz >= a.D || gx >= a.W)) return;
+    const unsigned off0 = (unsigned)(gz * HW + gy0 * a.W + gx);
+    float* yb = a.y + (int64_t)b * a.y_bstride;
+    const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int co = a.co0 + g * 4 + m;
+        if (!FULL && co >= a.Cout) continue;
+        const float sc = a.scale ? a.scale[co] : 1.f;
+        const float sh = a.scale ? a.shift[co] : 0.f;
+        float* yc = yb + (int64_t)(a.y_ch[g] + m) * DHW;                    // wave-uniform bases
+        const float* rc = rb ? rb + (int64_t)(a.res_ch[g] + m) * DHW : nullptr;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!FULL && gy0 + r >= a.H) continue;
+          float val = fmaf(acc[r][g][m], sc, sh);
+          if (a.relu) val = fmaxf(val, 0.f);
+          if (rc) val += rc[off0 + (unsigned)(r * a.W)];
+          yc[off0 + (unsigned)(r * a.W)] = val;
+        }
+      }
     }
+  };
+
+  int t = blockIdx.x, chunk = 0;
+  if (t >= ntiles) return;
+  prefetch(t, 0);
+  if (a.nchunks == 1) load_weights(0);
+
+  while (true) {
+    __syncthreads();  // every wave is done reading the previous stage's tile
+    commit(t, chunk);
     __syncthreads();
+
+    // next stage: same tile / next chunk, or this workgroup's next tile (grid-stride)
+    int nt = t, nchunk = chunk + 1;
+    if (nchunk == a.nchunks) { nchunk = 0; nt += gridDim.x; }
+    const bool has_next = nt < ntiles;
+    if (has_next) prefetch(nt, nchunk);   // global loads stay in flight under the MFMA phase below
+    if (a.nchunks > 1) load_weights(chunk);
 
     static_for<CK>([&](auto c_) {
       constexpr int c = decltype(c_)::value;
@@ -148,33 +231,20 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(K3Args a) {
         });
       });
     });
-  }
 
-  // epilogue: folded BN -> ReLU -> (+ residual / running sum) -> channel-slice store
-  const int gz = z0 + wave, gx = x0 + xl;
-  if (gz >= a.D || gx >= a.W) return;
-  float* yb = a.y + (int64_t)b * a.y_bstride + (int64_t)gz * HW + gx;
-  const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride + (int64_t)gz * HW + gx : nullptr;
+    if (chunk == a.nchunks - 1) {
+      int b, x0, y0, z0;
+      decode(t, b, x0, y0, z0);
+      const bool full = x0 + TX <= a.W && y0 + TY <= a.H && z0 + TZ <= a.D && a.co0 + 4 * G <= a.Cout;
+      if (full) epilogue(t, std::true_type{}); else epilogue(t, std::false_type{});
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int co = a.co0 + g * 4 + m;
-      if (co >= a.Cout) break;
-      const float sc = a.scale ? a.scale[co] : 1.f;
-      const float sh = a.scale ? a.shift[co] : 0.f;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int gy = y0 + ysub * R + r;
-        if (gy >= a.H) break;
-        float val = acc[r][g][m];
-        if (a.scale) val = fmaf(val, sc, sh);
-        if (a.relu) val = fmaxf(val, 0.f);
-        const int64_t off = (int64_t)gy * a.W;
-        if (rb) val += rb[(int64_t)(a.res_ch[g] + m) * DHW + off];
-        yb[(int64_t)(a.y_ch[g] + m) * DHW + off] = val;
-      }
+        for (int g = 0; g < G; ++g) acc[r][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (!has_next) break;
+    t = nt;
+    chunk = nchunk;
   }
 }
 
@@ -188,6 +258,17 @@ static int choose_cfg(int B, int D, int H, int W) {
   return 2;
 }
 // output groups per launch: at most 4, split evenly-ish (6 -> 3+3, 5 -> 3+2, 8 -> 4+4)
+// persistent grid: as many workgroups as the chip holds at once (occupancy x CUs) stride over the tiles
+template <class K>
+static int persistent_slots(K kernel) {
+  int dev = 0, cus = 256, per_cu = 2;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  (void)hipGetLastError();
+  return per_cu * cus;
+}
 static int split_groups(int left) { return left > 4 ? (left == 5 || left == 6 ? 3 : 4) : left; }
 
 template <int LOG_TX, int R>
@@ -210,7 +291,9 @@ static int launch_cfg(K3Args a, int B, int ngroups, const int32_t* y_group_ch, c
       a.y_ch[g] = y_group_ch ? y_group_ch[g0 + g] : (g0 + g) * 4;
       a.res_ch[g] = res_group_ch ? res_group_ch[g0 + g] : (g0 + g) * 4;
     }
-    dim3 grid((unsigned)nblk), blk(256);
+    static const int slots[4] = {persistent_slots(conv3d_k3_kernel<1, LOG_TX, R>), persistent_slots(conv3d_k3_kernel<2, LOG_TX, R>),
+                                 persistent_slots(conv3d_k3_kernel<3, LOG_TX, R>), persistent_slots(conv3d_k3_kernel<4, LOG_TX, R>)};
+    dim3 grid((unsigned)std::min<int64_t>(nblk, slots[G - 1])), blk(256);
     switch (G) {
       case 1: hipLaunchKernelGGL((conv3d_k3_kernel<1, LOG_TX, R>), grid, blk, 0, s, a); break;
       case 2: hipLaunchKernelGGL((conv3d_k3_kernel<2, LOG_TX, R>), grid, blk, 0, s, a); break;
@@ -252,13 +335,13 @@ extern "C" int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride, const void*
   RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3: dtype %d not built", dtype);
   const int ngroups = (Cout + 3) / 4;
   RAGMI_REQUIRE(ngroups <= RAGMI_MAX_GROUPS, RAGMI_EUNSUPPORTED, "conv3d_k3: Cout %d > %d", Cout, 4 * RAGMI_MAX_GROUPS);
-  RAGMI_REQUIRE((int64_t)D * H * W < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k3: volume too large");
+  RAGMI_REQUIRE((int64_t)D * H * W < (1ll << 30), RAGMI_EUNSUPPORTED, "conv3d_k3: volume too large (32-bit plane offsets)");
   K3Args a{};
   a.x = (const float*)x; a.x_bstride = x_bstride;
   a.wp = (const float*)packed_weight; a.scale = (const float*)scale; a.shift = (const float*)shift;
   a.y = (float*)y; a.y_bstride = y_bstride;
   a.res = (const float*)res; a.res_bstride = res_bstride;
-  a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
   a.nchunks = (Cin + CK - 1) / CK; a.relu = relu;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (choose_cfg(B, D, H, W)) {
