@@ -9,7 +9,7 @@ CXXFLAGS := -O3 -std=c++20 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wal
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rag_amd.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv3d_k3.h include/rag_amd.h
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -72,11 +72,27 @@ class K3Profiler:
             e0.record()
             out = self._orig(x, packed, cout, *a, **kw)
             e1.record()
-            self.records.append((e0, e1, (tuple(groups), log_tx, rows), 2.0 * 27 * Cin * cout * B * D * Hh * Ww,
+            self.records.append((e0, e1, (tuple(groups), log_tx, rows, 1), 2.0 * 27 * Cin * cout * B * D * Hh * Ww,
                                  4.0 * (Cin + cout) * B * D * Hh * Ww, len(groups)))
             return out
 
         ops.conv3d_k3 = wrapped
+        self._orig_dual = ops.conv3d_k3_dual
+
+        def wrapped_dual(x, cin_a, pa, sa, ha, pb, sb, hb, cout, *a, **kw):
+            if not self.enabled:
+                return self._orig_dual(x, cin_a, pa, sa, ha, pb, sb, hb, cout, *a, **kw)
+            B, Cin, D, Hh, Ww = x.shape
+            log_tx, rows, groups = ops.conv3d_k3_plan(cout, B, D, Hh, Ww, 2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._orig_dual(x, cin_a, pa, sa, ha, pb, sb, hb, cout, *a, **kw)
+            e1.record()
+            self.records.append((e0, e1, (tuple(groups), log_tx, rows, 2), 2.0 * 27 * Cin * cout * B * D * Hh * Ww,
+                                 4.0 * (Cin + cout) * B * D * Hh * Ww, len(groups)))
+            return out
+
+        ops.conv3d_k3_dual = wrapped_dual
 
     def summary(self):
         by = {}
@@ -192,16 +208,16 @@ def main():
         roofline = None
         if dom_key is not None:
             secs, flops, nbytes, nlaunch = by[dom_key]
-            groups, log_tx, rows = dom_key
+            groups, log_tx, rows, nset = dom_key
             ach = flops / secs * 1e-12
-            roofline = {"kernel": f"conv3d_k3_kernel<{groups[0]},{log_tx},{rows}>", "bound": "mfma",
+            roofline = {"kernel": f"conv3d_k3_kernel<{groups[0]},{log_tx},{rows},{nset},*>", "bound": "mfma",
                         "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                         "launches_per_step": nlaunch // args.steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
                         "flops_per_launch": flops / nlaunch,
                         "share_of_step": round(secs / args.steps / (dt / args.steps), 3)}
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
-                log(f"  conv3d_k3 G={k[0]} tx=2^{k[1]} R={k[2]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
+                log(f"  conv3d_k3 G={k[0]} tx=2^{k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
         cpu = None
         if n_gpus == 1 and not args.no_cpu_baseline:

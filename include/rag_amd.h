@@ -84,13 +84,28 @@ int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride,
                         int dtype, void* stream);
 
 /*
- * Introspection for profiling: which kernel instantiation(s) ragmi_conv3d_k3_fwd will launch
- * for this shape.  Writes the x-tile log2 width and rows per lane, and the output-group count
- * (G) of each launch into launch_groups[0..max_launches); returns the number of launches
- * (kernel name: conv3d_k3_kernel<G, log_tx, rows_per_lane>) or a negative error code.
+ * Two sibling ConvBR_3d groups fused into one launch (Cell_3d with two conv branches per new
+ * state, rag_model.py:160-172):
+ *   y[b, y_ch(co)] = act(bnA(convA(x[:, 0:CinA])))[co] + act(bnB(convB(x[:, CinA:CinA+CinB])))[co] (+ res)
+ * x holds both inputs as consecutive channels (CinA a multiple of 4); packedA / packedB are
+ * ragmi_conv3d_k3_pack outputs for [Cout, CinA, 3,3,3] and [Cout, CinB, 3,3,3].  Other arguments
+ * as ragmi_conv3d_k3_fwd.  The running sum never touches HBM.
  */
-int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int32_t* log_tx, int32_t* rows_per_lane,
-                         int32_t* launch_groups, int32_t max_launches);
+int ragmi_conv3d_k3_dual_fwd(const void* x, int64_t x_bstride,
+                             int CinA, const void* packedA, const void* scaleA, const void* shiftA,
+                             int CinB, const void* packedB, const void* scaleB, const void* shiftB,
+                             int relu, void* y, int64_t y_bstride, const int32_t* y_group_ch,
+                             const void* res, int64_t res_bstride, const int32_t* res_group_ch,
+                             int B, int Cout, int D, int H, int W, int dtype, void* stream);
+
+/*
+ * Introspection for profiling: which kernel instantiation(s) ragmi_conv3d_k3_fwd will launch
+ * for this shape (nset = 1, or 2 for ragmi_conv3d_k3_dual_fwd).  Writes the x-tile log2 width and rows per lane, and the output groups per
+ * workgroup (G) into launch_groups[0]; returns the number of launches (1) or a negative error
+ * code.  Kernel name: conv3d_k3_kernel<G, log_tx, rows_per_lane, NSET> (NSET 1, or 2 for _dual).
+ */
+int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int nset, int32_t* log_tx,
+                         int32_t* rows_per_lane, int32_t* launch_groups, int32_t max_launches);
 
 /*
  * Fused ConvBR_3d, 1x1x1 (Cell_3d.pre_preprocess / preprocess, rag_model.py:125-126,

@@ -1,0 +1,405 @@
+// K3 (kernel template) — fused 3x3x3 ConvBR_3d (+ Cell_3d running sum / channel concat) on the CDNA4 matrix cores.
+// Reference: ConvBR_3d src/automl/operations_3d.py:31-47; call sites stem3d0/1
+// (src/models/rag_model.py:234-235, 341-343), Cell_3d._ops (:134-137, 160-176), last_3_3d (:269).
+//
+// Design (gfx950, fp32 exact):
+//  * The contraction runs on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products
+//    per instruction = "64 voxels x 4 output channels += w[4] * x[64]" for one (cin, tap).
+//    B operand: lane l holds the input value of ITS voxel (thread-per-voxel, NCDHW-natural,
+//    coalesced).  D: lane l holds the 4 output channels of its voxel.  Output-channel counts
+//    of 4/8/12/16 map with zero padding waste (a 16x16x4 tile would idle 25-75% of its N).
+//  * A operand via CBSZ=4/ABID broadcast: all 16 blocks take A from block ABID, so ONE VGPR
+//    holds the weight fragments of 16 different (cin, tap) pairs and the 108 pairs of a
+//    4-channel chunk live in 7 VGPRs per output group — weights are register-resident for
+//    the whole tile and cost no LDS traffic (pre-packed by ragmi_conv3d_k3_pack).
+//  * Input halo tile (4 ch x 6 x (TY+2) x (TX+2)) staged through LDS once per tile; each lane
+//    then reads (R+2) rows x 3 dx per (cin, dz) and reuses them for its R output rows.
+//  * Epilogue fuses folded BatchNorm (scale/shift), ReLU, the Cell_3d running sum (res, may
+//    alias y) and torch.cat (per-group destination channel), so none of them is a pass.
+//  * Measured ceiling of the 4x4x1 form: 134 TFLOP/s (tools/probe_mfma.hip) vs 157 spec.
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace ragmi {
+
+constexpr int CK = 4;                        // input channels per LDS chunk
+constexpr int NPAIR = CK * 27;               // (cin, tap) pairs per chunk = 108
+constexpr int NVG = (NPAIR + 15) / 16;       // VGPRs per output group per chunk = 7
+constexpr int PACK_PER_GC = NVG * 64;        // packed floats per (group, chunk) = 448
+
+struct K3Args {
+  const float* x;
+  int64_t x_bstride;
+  const float* wp[2];     // per accumulator set: packed [groups][nchunks[s]][NVG][64]
+  const float* scale[2];  // per set, indexed by output channel
+  const float* shift[2];
+  float* y;
+  int64_t y_bstride;
+  const float* res;
+  int64_t res_bstride;
+  int B, Cin, Cout, D, H, W;
+  int nchunks[2];  // input-channel chunks feeding set 0, then set 1 (consecutive channels of x)
+  int relu;
+  int tiles_x, tiles_y, tiles_z;
+  int w_in_lds;    // 1: the workgroup's weights (all chunks, both sets) are cached in LDS behind the tile
+  int y_ch[RAGMI_MAX_GROUPS];    // destination channel base of each output group
+  int res_ch[RAGMI_MAX_GROUPS];
+};
+
+constexpr int K3_MAX_WLDS_BYTES = 36 * 1024;   // weight cache budget per workgroup (stem3d0: 6 chunks x 3 groups = 32 KB)
+
+// G output groups (4 channels each) per workgroup, selected by blockIdx.y; NSET accumulator sets:
+// NSET=2 fuses two sibling-group convolutions that feed the same destinations from two inputs
+// (Cell_3d: out = relu(bn_a(conv_a(s0))) + relu(bn_b(conv_b(s1)))) so the running sum never
+// round-trips through HBM.  WPS = waves per SIMD the register budget is sized for.
+template <int G, int LOG_TX, int R, int NSET, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
+  constexpr int TX = 1 << LOG_TX;
+  constexpr int YS = 64 / TX;      // lane sub-rows per wave
+  constexpr int TY = YS * R;       // output rows per tile
+  constexpr int TZ = 4;            // one z-plane per wave
+  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+  constexpr int TILE = CK * HZ * HY * HX;
+  // staging map: thread -> (sy, zz, xx) of the halo; passes over compile-time (c, k): yy = k*SY + sy
+  constexpr int SY = 256 / (HZ * HX);
+  constexpr int KY = (HY + SY - 1) / SY;
+  constexpr int NP = CK * KY;      // staging registers per thread
+  static_assert(SY >= 1, "tile too wide for the staging map");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;              // [CK][HZ][HY][HX] halo tile
+  float* wlds = smem + TILE;       // optional weight cache: set 0 block then set 1 block, [g][chunk][NVG][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int HW = a.H * a.W;
+  const int64_t DHW = (int64_t)HW * a.D;
+  const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  const int gbase = blockIdx.y * G;                       // first output group of this workgroup
+  const int nch0 = a.nchunks[0];
+  const int nch = nch0 + (NSET == 2 ? a.nchunks[1] : 0);  // stages per tile
+
+  // compute-side lane geometry
+  const int xl = lane & (TX - 1), ysub = lane >> LOG_TX;
+  const float* rd = tile + (wave * HY + ysub * R) * HX + xl;  // lane's (c=0, dz=0, rr=0, dx=0) tap
+  // staging-side thread geometry
+  const int sxx = tid % HX, szz = (tid / HX) % HZ, ssy = tid / (HX * HZ);
+  const bool sactive = ssy < SY;
+  float* wr = tile + (szz * HY + ssy) * HX + sxx;             // + (c*HZ*HY + k*SY) * HX per pass
+
+  // folded-BN parameters of this workgroup's output channels, staged once into LDS: the epilogue must not
+  // re-read them from global memory (its stores may alias them, which would serialise every element)
+  __shared__ __attribute__((aligned(16))) float bnp[NSET][2][G * 4];
+  if (tid < NSET * G * 4) {
+    const int s = tid / (G * 4), j = tid % (G * 4), co = gbase * 4 + j;
+    const bool ok = a.scale[s] != nullptr && co < a.Cout;
+    bnp[s][0][j] = ok ? a.scale[s][co] : 1.f;   // identity affine when there is no BN: fma(x, 1, 0) == x exactly
+    bnp[s][1][j] = ok ? a.shift[s][co] : 0.f;
+  }
+  int ych[G], rch[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    ych[g] = a.y_ch[gbase + g];
+    rch[g] = a.res_ch[gbase + g];
+  }
+  const bool has_res = a.res != nullptr;
+  const bool do_relu = a.relu != 0;
+
+  f32x4 acc[NSET][R][G];
+#pragma unroll
+  for (int s = 0; s < NSET; ++s)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[s][r][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float st[NP];  // next stage's halo elements, in flight during the MFMA phase
+
+  auto decode = [&](int t, int& b, int& x0, int& y0, int& z0) {
+    const int tx_i = t % a.tiles_x; t /= a.tiles_x;
+    const int ty_i = t % a.tiles_y; t /= a.tiles_y;
+    const int tz_i = t % a.tiles_z;
+    b = t / a.tiles_z;
+    x0 = tx_i * TX; y0 = ty_i * TY; z0 = tz_i * TZ;
+  };
+
+  // issue the global loads of stage (t, chunk): always in-bounds (clamped); validity is applied at write time
+  auto prefetch = [&](int t, int chunk) {
+    int b, x0, y0, z0;
+    decode(t, b, x0, y0, z0);
+    const float* xb = a.x + (int64_t)b * a.x_bstride;
+    const int gzc = min(max(z0 - 1 + szz, 0), a.D - 1), gxc = min(max(x0 - 1 + sxx, 0), a.W - 1);
+    const int zx = gzc * HW + gxc;
+    const int gy0 = y0 - 1 + ssy;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const float* xc = xb + (int64_t)min(chunk * CK + c, a.Cin - 1) * DHW;   // wave-uniform base
+#pragma unroll
+      for (int k = 0; k < KY; ++k) {
+        const int gyc = min(max(gy0 + k * SY, 0), a.H - 1);
+        st[c * KY + k] = xc[(unsigned)(zx + gyc * a.W)];
+      }
+    }
+  };
+
+  // write the staged stage (t, chunk) into LDS, zeroing everything outside the volume / past Cin
+  auto commit = [&](int t, int chunk) {
+    int b, x0, y0, z0;
+    decode(t, b, x0, y0, z0);
+    const bool zx_ok = sactive && (unsigned)(z0 - 1 + szz) < (unsigned)a.D && (unsigned)(x0 - 1 + sxx) < (unsigned)a.W;
+    const int gy0 = y0 - 1 + ssy;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const bool c_ok = chunk * CK + c < a.Cin;
+#pragma unroll
+      for (int k = 0; k < KY; ++k) {
+        const bool ok = zx_ok && c_ok && (unsigned)(gy0 + k * SY) < (unsigned)a.H;
+        if (sactive && k * SY + ssy < HY) wr[(c * HZ * HY + k * SY) * HX] = ok ? st[c * KY + k] : 0.f;
+      }
+    }
+  };
+
+  float wreg[G][NVG];
+  auto load_weights = [&](int chunk) {   // chunk is the tile-level stage index
+    const int set = (NSET == 2 && chunk >= nch0) ? 1 : 0;
+    const int lc = chunk - (set ? nch0 : 0), nc = a.nchunks[set];
+    if (a.w_in_lds) {
+      const float* wl = wlds + (set ? G * nch0 * PACK_PER_GC : 0) + lane;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int v = 0; v < NVG; ++v) wreg[g][v] = wl[((g * nc + lc) * NVG + v) * 64];
+    } else {
+      const float* wp = a.wp[set];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int v = 0; v < NVG; ++v)
+          wreg[g][v] = wp[(((gbase + g) * nc + lc) * NVG + v) * 64 + lane];
+    }
+  };
+
+  auto epilogue = [&](int t, auto full_, auto res_) {
+    constexpr bool FULL = decltype(full_)::value;
+    constexpr bool RES = decltype(res_)::value;
+    int b, x0, y0, z0;
+    decode(t, b, x0, y0, z0);
+    const int gz = z0 + wave, gx = x0 + xl, gy0 = y0 + ysub * R;
+    if (!FULL && (gz >= a.D || gx >= a.W)) return;
+    const unsigned off0 = (unsigned)(gz * HW + gy0 * a.W + gx);
+    float* yb = a.y + (int64_t)b * a.y_bstride;
+    const float* rb = RES ? a.res + (int64_t)b * a.res_bstride : nullptr;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      f32x4 sc[NSET], sh[NSET];
+#pragma unroll
+      for (int s = 0; s < NSET; ++s) {
+        sc[s] = *reinterpret_cast<const f32x4*>(&bnp[s][0][g * 4]);   // LDS broadcast reads
+        sh[s] = *reinterpret_cast<const f32x4*>(&bnp[s][1][g * 4]);
+      }
+      float rv[4][R];
+      if (RES) {   // all residual loads of this group first, then the arithmetic and the stores
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float* rc = rb + (int64_t)(rch[g] + m) * DHW;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const bool ok = FULL || ((gbase + g) * 4 + m < a.Cout && gy0 + r < a.H);
+            rv[m][r] = ok ? rc[off0 + (unsigned)(r * a.W)] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (!FULL && (gbase + g) * 4 + m >= a.Cout) continue;
+        float* yc = yb + (int64_t)(ych[g] + m) * DHW;   // wave-uniform base
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!FULL && gy0 + r >= a.H) continue;
+          float val = fmaf(acc[0][r][g][m], sc[0][m], sh[0][m]);
+          if (do_relu) val = fmaxf(val, 0.f);
+          if (NSET == 2) {
+            float v1 = fmaf(acc[NSET - 1][r][g][m], sc[NSET - 1][m], sh[NSET - 1][m]);
+            if (do_relu) v1 = fmaxf(v1, 0.f);
+            val += v1;
+          }
+          if (RES) val += rv[m][r];
+          yc[off0 + (unsigned)(r * a.W)] = val;
+        }
+      }
+    }
+  };
+
+  // 12 (channel, dz) blocks per stage; the (R+2) x 3 LDS operands of block i+1 are fetched into the other
+  // half of vbuf while block i's 9*G*R MFMAs issue, so no MFMA waits on an LDS read it has just issued
+  auto load_v = [&](float (&v)[R + 2][3], auto blk_) {
+    constexpr int blk = decltype(blk_)::value;
+    constexpr int c = blk / 3, dz = blk % 3;
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) v[rr][dx] = rd[((c * HZ + dz) * HY + rr) * HX + dx];
+  };
+  auto mfma_block = [&](auto set_) {
+    constexpr int S = decltype(set_)::value;
+    float vbuf[2][R + 2][3];
+    load_v(vbuf[0], std::integral_constant<int, 0>{});
+    static_for<CK * 3>([&](auto blk_) {
+      constexpr int blk = decltype(blk_)::value;
+      constexpr int c = blk / 3, dz = blk % 3;
+      if constexpr (blk + 1 < CK * 3) load_v(vbuf[(blk + 1) & 1], std::integral_constant<int, blk + 1>{});
+      static_for<3>([&](auto dy_) {
+        constexpr int dy = decltype(dy_)::value;
+        static_for<3>([&](auto dx_) {
+          constexpr int dx = decltype(dx_)::value;
+          constexpr int q = c * 27 + (dz * 3 + dy) * 3 + dx;
+          static_for<G>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            static_for<R>([&](auto r_) {
+              constexpr int r = decltype(r_)::value;
+              acc[S][r][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[g][q / 16], vbuf[blk & 1][r + dy][dx], acc[S][r][g], 4, q % 16, 0);
+            });
+          });
+        });
+      });
+    });
+  };
+
+  int t = blockIdx.x, chunk = 0;
+  if (t >= ntiles) return;
+  prefetch(t, 0);
+  if (a.w_in_lds) {
+    // the G groups of this workgroup are one contiguous block per set in the packed array
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) {
+      const int n = G * a.nchunks[s] * PACK_PER_GC;
+      const float* src = a.wp[s] + (int64_t)gbase * a.nchunks[s] * PACK_PER_GC;
+      float* dst = wlds + (s ? G * nch0 * PACK_PER_GC : 0);
+      for (int i = tid * 4; i < n; i += 1024) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+    }
+  }
+  if (nch == 1 && !a.w_in_lds) load_weights(0);
+
+  while (true) {
+    __syncthreads();  // every wave is done reading the previous stage's tile
+    commit(t, chunk);
+    __syncthreads();
+
+    // next stage: same tile / next chunk, or this workgroup's next tile (grid-stride)
+    int nt = t, nchunk = chunk + 1;
+    if (nchunk == nch) { nchunk = 0; nt += gridDim.x; }
+    const bool has_next = nt < ntiles;
+    if (has_next) prefetch(nt, nchunk);   // global loads stay in flight under the MFMA phase below
+    if (nch > 1 || a.w_in_lds) load_weights(chunk);   // from LDS: visible after the barrier above
+
+    if (NSET == 2 && chunk >= nch0) mfma_block(std::integral_constant<int, NSET - 1>{});
+    else mfma_block(std::integral_constant<int, 0>{});
+
+    if (chunk == nch - 1) {
+      int b, x0, y0, z0;
+      decode(t, b, x0, y0, z0);
+      const bool full = x0 + TX <= a.W && y0 + TY <= a.H && z0 + TZ <= a.D && (gbase + G) * 4 <= a.Cout;
+      if (full) {
+        if (has_res) epilogue(t, std::true_type{}, std::true_type{}); else epilogue(t, std::true_type{}, std::false_type{});
+      } else {
+        if (has_res) epilogue(t, std::false_type{}, std::true_type{}); else epilogue(t, std::false_type{}, std::false_type{});
+      }
+#pragma unroll
+      for (int s = 0; s < NSET; ++s)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[s][r][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (!has_next) break;
+    t = nt;
+    chunk = nchunk;
+  }
+}
+
+// persistent grid: as many workgroups as the chip holds at once (occupancy x CUs) stride over the tiles
+template <class K>
+static int persistent_slots(K kernel, size_t lds_bytes) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  int per_cu = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+  (void)hipGetLastError();
+  return per_cu * cus;
+}
+
+// output groups per workgroup: the largest of {4,3,2,1} dividing the group count (12 -> 4, 6 -> 3)
+inline int split_groups(int ngroups) {
+  for (int g = 4; g > 1; --g)
+    if (ngroups % g == 0) return g;
+  return 1;
+}
+
+template <int G, int LOG_TX, int R, int NSET, int WPS>
+static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
+  constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
+  constexpr size_t tile_bytes = (size_t)CK * 6 * (TY + 2) * (TX + 2) * sizeof(float);
+  const size_t wbytes = (size_t)G * (a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0)) * PACK_PER_GC * sizeof(float);
+  // cache the weights in LDS when they fit the budget (policy switch for experiments: RAGMI_K3_WLDS=0 never,
+  // 1 whenever they fit, 2 (default) only for multi-stage tiles)
+  static const int policy = [] { const char* e = getenv("RAGMI_K3_WLDS"); return e ? atoi(e) : 2; }();
+  const int nstages = a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0);
+  a.w_in_lds = (policy != 0 && wbytes <= (size_t)K3_MAX_WLDS_BYTES && (policy == 1 || nstages > 1)) ? 1 : 0;
+  const size_t lds = tile_bytes + (a.w_in_lds ? wbytes : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(tile_bytes + K3_MAX_WLDS_BYTES));
+    attr_set = true;
+  }
+  // occupancy depends on the dynamic LDS size: cache per size (a handful of distinct sizes per instantiation)
+  static size_t cached_lds[8];
+  static int cached_slots[8];
+  static int ncached = 0;
+  int slots = 0;
+  for (int i = 0; i < ncached; ++i)
+    if (cached_lds[i] == lds) slots = cached_slots[i];
+  if (slots == 0) {
+    slots = persistent_slots(conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS>, lds);
+    if (ncached < 8) { cached_lds[ncached] = lds; cached_slots[ncached] = slots; ++ncached; }
+  }
+  const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
+  hipLaunchKernelGGL((conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
+}
+
+// one tile configuration: sets the tile counts and launches with G = split_groups(ngroups)
+template <int LOG_TX, int R, int NSET, int WPS>
+static int launch_cfg(K3Args a, int ngroups, hipStream_t s) {
+  constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
+  a.tiles_x = (int)ceil_div(a.W, TX);
+  a.tiles_y = (int)ceil_div(a.H, TY);
+  a.tiles_z = (int)ceil_div(a.D, 4);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
+  const int G = split_groups(ngroups), nsplits = ngroups / G;
+  switch (G) {
+    case 1: launch_one<1, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    case 2: launch_one<2, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    case 3: launch_one<3, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    default: launch_one<4, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+  }
+  return check_launch("conv3d_k3");
+}
+
+// instantiated one per translation unit (conv3d_k3_inst_*.hip) so the build parallelises
+int launch_k3_s1_cfg0(const K3Args& a, int ngroups, hipStream_t s);   // TX=32 R=4
+int launch_k3_s1_cfg1(const K3Args& a, int ngroups, hipStream_t s);   // TX=16 R=2
+int launch_k3_s1_cfg2(const K3Args& a, int ngroups, hipStream_t s);   // TX=8  R=1
+int launch_k3_s2_cfg0(const K3Args& a, int ngroups, hipStream_t s);   // dual, TX=32 R=2, 2 waves/SIMD
+int launch_k3_s2_cfg0b(const K3Args& a, int ngroups, hipStream_t s);  // dual, TX=32 R=4, 1 wave/SIMD
+int launch_k3_s2_cfg1(const K3Args& a, int ngroups, hipStream_t s);
+int launch_k3_s2_cfg2(const K3Args& a, int ngroups, hipStream_t s);
+
+}  // namespace ragmi

@@ -290,13 +290,32 @@ class Cell_3d(nn.Module):
                     bs, cs = where[ids.pop(0)]
                     ops.add(buf, ch, bs, cs, buf, ch, C)
 
+        # Fast path: the conv branches from s0 and from s1 feed the same new states and nothing else does
+        # (e.g. the all-conv genotype): ONE dual-input launch computes relu(bn(conv(s0))) + relu(bn(conv(s1)))
+        # for all of them, so the running sum never goes through HBM.
+        done = set()
+        conv_from = {j: [(k, op) for k, lst in contribs.items() for (src, op) in lst
+                         if src == j and isinstance(op, ConvBR_3d)] for j in (0, 1)}
+        if (conv_from[0] and where[0][0] is pre and [k for k, _ in conv_from[0]] == [k for k, _ in conv_from[1]]
+                and all(len(contribs[k]) == 2 and not pending_id[k] for k, _ in conv_from[0])
+                and len({id(where[k][0]) for k, _ in conv_from[0]}) == 1):
+            pa, sa, ha = self._fused([op for _k, op in conv_from[0]])
+            pb, sb, hb = self._fused([op for _k, op in conv_from[1]])
+            groups = [where[k][1] + 4 * g for k, _op in conv_from[0] for g in range(C // 4)]
+            ops.conv3d_k3_dual(pre, C, pa, sa, ha, pb, sb, hb, C * len(conv_from[0]), True,
+                               where[conv_from[0][0][0]][0], groups)
+            for j in (0, 1):
+                for k, op in conv_from[j]:
+                    written[k] = True
+                    done.add((j, id(op)))
+
         for j in range(n_states):
             if j >= 2:
                 finalize(j)
             parts: Dict[object, list] = {}
             for k, lst in contribs.items():
                 for (src, op) in lst:
-                    if src != j or not isinstance(op, ConvBR_3d):
+                    if src != j or not isinstance(op, ConvBR_3d) or (j, id(op)) in done:
                         continue
                     if written[k]:
                         res = where[k]                                   # running sum: accumulate in place

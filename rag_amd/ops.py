@@ -76,12 +76,12 @@ def conv3d_k3_pack(weight: torch.Tensor) -> torch.Tensor:
     return packed
 
 
-def conv3d_k3_plan(cout: int, B: int, D: int, H: int, W: int):
-    """(log2 x-tile, rows per lane, [G of each launch]) that conv3d_k3 will use for this shape;
-    the kernel instantiation is conv3d_k3_kernel<G, log_tx, rows>."""
+def conv3d_k3_plan(cout: int, B: int, D: int, H: int, W: int, nset: int = 1):
+    """(log2 x-tile, rows per lane, [G per workgroup]) that conv3d_k3 (nset=1) / conv3d_k3_dual (nset=2)
+    will use for this shape; the kernel instantiation is conv3d_k3_kernel<G, log_tx, rows, nset, *>."""
     log_tx, rows = ctypes.c_int32(), ctypes.c_int32()
     groups = (ctypes.c_int32 * 16)()
-    n = load_library().ragmi_conv3d_k3_plan(cout, B, D, H, W, ctypes.byref(log_tx), ctypes.byref(rows), groups, 16)
+    n = load_library().ragmi_conv3d_k3_plan(cout, B, D, H, W, nset, ctypes.byref(log_tx), ctypes.byref(rows), groups, 16)
     if n < 0:
         check(n, "conv3d_k3_plan")
     return log_tx.value, rows.value, [groups[i] for i in range(n)]
@@ -118,6 +118,31 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
         out.data_ptr(), yb, _i32_array(out_group_ch),
         res.data_ptr() if res is not None else None, rb, _i32_array(res_group_ch),
         B, Cin, cout, D, H, W, F32, _stream()), "conv3d_k3")
+    return out
+
+
+def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a, shift_a,
+                   packed_b: torch.Tensor, scale_b, shift_b, cout: int, relu: bool, out: torch.Tensor,
+                   out_group_ch: Optional[Sequence[int]] = None, res: Optional[torch.Tensor] = None,
+                   res_group_ch: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Two sibling ConvBR_3d groups in one launch: out = act(bnA(convA(x[:, :cin_a]))) + act(bnB(convB(x[:, cin_a:])))
+    (+ res): see ragmi_conv3d_k3_dual_fwd in include/rag_amd.h."""
+    _need_gpu(x, packed_a, packed_b, scale_a, shift_a, scale_b, shift_b, out, res)
+    B, Cx, D, H, W = x.shape
+    ng = packed_groups(cout)
+    if out_group_ch is not None and len(out_group_ch) != ng:
+        raise ValueError("conv3d_k3_dual: out_group_ch needs one entry per group of 4 output channels")
+    if res is not None and res_group_ch is None:
+        res_group_ch = out_group_ch
+    if tuple(out.shape[2:]) != (D, H, W) or out.shape[0] != B or not 0 < cin_a < Cx:
+        raise ValueError("conv3d_k3_dual: bad shapes")
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(load_library().ragmi_conv3d_k3_dual_fwd(
+        x.data_ptr(), _planes(x), cin_a, packed_a.data_ptr(), ptr(scale_a), ptr(shift_a),
+        Cx - cin_a, packed_b.data_ptr(), ptr(scale_b), ptr(shift_b), int(relu),
+        out.data_ptr(), _planes(out), _i32_array(out_group_ch),
+        ptr(res), _planes(res) if res is not None else 0, _i32_array(res_group_ch),
+        B, cout, D, H, W, F32, _stream()), "conv3d_k3_dual")
     return out
 
 

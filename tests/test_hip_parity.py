@@ -143,6 +143,27 @@ def test_conv3d_k3_slices_residual_and_accumulate(ra):
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), **TOL)
 
 
+@pytest.mark.parametrize("ca,cb,cout,shape", [(4, 4, 12, (1, 5, 9, 33)), (8, 8, 24, (2, 4, 8, 20)), (16, 16, 48, (1, 4, 8, 13)),
+                                              (4, 4, 4, (1, 3, 5, 7)), (4, 3, 8, (1, 6, 10, 40)), (4, 4, 12, (1, 64, 24, 96))])
+def test_conv3d_k3_dual_vs_oracle(ra, ca, cb, cout, shape):
+    """out = relu(bnA(convA(x[:, :ca]))) + relu(bnB(convB(x[:, ca:]))) + res, in one launch."""
+    B, D, H, W = shape
+    x = torch.randn((B, ca + cb, D, H, W), generator=gen(20))
+    wa = torch.randn((cout, ca, 3, 3, 3), generator=gen(21)) * (2.0 / (27 * ca)) ** 0.5
+    wb = torch.randn((cout, cb, 3, 3, 3), generator=gen(22)) * (2.0 / (27 * cb)) ** 0.5
+    sa, ha = torch.rand(cout, generator=gen(23)) + 0.5, torch.randn(cout, generator=gen(24)) * 0.1
+    sb, hb = torch.rand(cout, generator=gen(25)) + 0.5, torch.randn(cout, generator=gen(26)) * 0.1
+    res = torch.randn((B, cout, D, H, W), generator=gen(27))
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    ref = F.relu(F.conv3d(x[:, :ca], wa, padding=1) * v(sa) + v(ha)) + F.relu(F.conv3d(x[:, ca:], wb, padding=1) * v(sb) + v(hb))
+    out = torch.full((B, cout, D, H, W), float("nan"), device=DEV)
+    pa, pb = ra.ops.conv3d_k3_pack(gpu(wa)), ra.ops.conv3d_k3_pack(gpu(wb))
+    ra.ops.conv3d_k3_dual(gpu(x), ca, pa, gpu(sa), gpu(ha), pb, gpu(sb), gpu(hb), cout, True, out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), **TOL)
+    ra.ops.conv3d_k3_dual(gpu(x), ca, pa, gpu(sa), gpu(ha), pb, gpu(sb), gpu(hb), cout, True, out, None, gpu(res), None)
+    np.testing.assert_allclose(out.cpu().numpy(), (ref + res).numpy(), **TOL)
+
+
 def test_conv3d_linearity_full_size(ra):
     """Size-independent property at the headline level-3 shape: conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
     D, H, W = 64, 128, 416
