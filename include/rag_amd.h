@@ -84,6 +84,17 @@ int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride,
                         int dtype, void* stream);
 
 /*
+ * Same operation as ragmi_conv3d_k3_fwd for Cout <= 2 (last_3_3d: 12 -> 1, rag_model.py:269), computed with
+ * v_fma and wave-uniform weights instead of MFMA (a 4-row MFMA tile would idle 3 rows at Cout = 1).
+ * `weight` is the RAW nn.Conv3d weight [Cout, Cin, 3, 3, 3]; Cin must be a multiple of 4.
+ * Writes y[b, y_ch0 + co]; res (optional) is read at res_ch0 + co.
+ */
+int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const void* weight, const void* scale,
+                              const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0,
+                              const void* res, int64_t res_bstride, int res_ch0,
+                              int B, int Cin, int Cout, int D, int H, int W, int dtype, void* stream);
+
+/*
  * Two sibling ConvBR_3d groups fused into one launch (Cell_3d with two conv branches per new
  * state, rag_model.py:160-172):
  *   y[b, y_ch(co)] = act(bnA(convA(x[:, 0:CinA])))[co] + act(bnB(convB(x[:, CinA:CinA+CinB])))[co] (+ res)

@@ -20,6 +20,8 @@ SIGNATURES = {
     "ragmi_conv3d_k3_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_int64, c_int32_p, c_void_p, c_int64, c_int32_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k3_small_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
+                                          c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k3_dual_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int32_p,
                                          c_void_p, c_int64, c_int32_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

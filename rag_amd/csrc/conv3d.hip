@@ -53,12 +53,6 @@ static int choose_cfg(int B, int D, int H, int W) {
   if (W > 8 && waste(16) <= waste(8) + 1e-9 && vol >= (1 << 17)) return 1;
   return 2;
 }
-// experiment switch for the level-3 dual kernel: 0 -> TX=32,R=2 at 2 waves/SIMD; 1 -> TX=32,R=4 at 1 wave/SIMD
-static bool dual_cfg0b() {
-  static const bool v = [] { const char* e = getenv("RAGMI_K3_DUAL_CFG0B"); return e && e[0] == '1'; }();
-  return v;
-}
-
 static int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int64_t y_bstride,
                        const int32_t* y_group_ch, const void* res, int64_t res_bstride, const int32_t* res_group_ch,
                        int B, int Cin, int Cout, int D, int H, int W, int relu) {
@@ -117,6 +111,26 @@ extern "C" int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride, const void*
   }
 }
 
+extern "C" int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const void* weight, const void* scale,
+                                         const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0,
+                                         const void* res, int64_t res_bstride, int res_ch0, int B, int Cin, int Cout,
+                                         int D, int H, int W, int dtype, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k3_small: null pointer");
+  RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k3_small: scale/shift must both be given or both NULL");
+  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3_small: dtype %d not built", dtype);
+  RAGMI_REQUIRE(Cout >= 1 && Cout <= 2 && Cin % CK == 0 && (size_t)Cout * Cin * 27 * sizeof(float) <= (size_t)K3_MAX_WLDS_BYTES,
+                RAGMI_EUNSUPPORTED, "conv3d_k3_small: needs Cout <= 2 and Cin a multiple of %d, <= %d (use ragmi_conv3d_k3_fwd otherwise)",
+                CK, K3_MAX_WLDS_BYTES / (2 * 27 * 4));
+  K3Args a{};
+  const int32_t ych = y_ch0, rch = res_ch0;
+  const int rc = fill_common(a, x, x_bstride, y, y_bstride, &ych, res, res_bstride, &rch, B, Cin, Cout, D, H, W, relu);
+  if (rc != RAGMI_OK) return rc;
+  a.wp[0] = (const float*)weight; a.scale[0] = (const float*)scale; a.shift[0] = (const float*)shift;
+  a.nchunks[0] = Cin / CK;
+  return launch_k3_valu(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));
+}
+
 extern "C" int ragmi_conv3d_k3_dual_fwd(const void* x, int64_t x_bstride, int CinA, const void* packedA,
                                         const void* scaleA, const void* shiftA, int CinB, const void* packedB,
                                         const void* scaleB, const void* shiftB, int relu, void* y, int64_t y_bstride,
@@ -138,9 +152,8 @@ extern "C" int ragmi_conv3d_k3_dual_fwd(const void* x, int64_t x_bstride, int Ci
   a.nchunks[0] = CinA / CK;
   a.nchunks[1] = (CinB + CK - 1) / CK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool cfg0b = dual_cfg0b();
   switch (choose_cfg(B, D, H, W)) {
-    case 0: return cfg0b ? launch_k3_s2_cfg0b(a, (Cout + 3) / 4, s) : launch_k3_s2_cfg0(a, (Cout + 3) / 4, s);
+    case 0: return launch_k3_s2_cfg0(a, (Cout + 3) / 4, s);
     case 1: return launch_k3_s2_cfg1(a, (Cout + 3) / 4, s);
     default: return launch_k3_s2_cfg2(a, (Cout + 3) / 4, s);
   }
@@ -155,7 +168,7 @@ extern "C" int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int ns
   static const int cfgs[3][2] = {{5, 4}, {4, 2}, {3, 1}};
   const int c = choose_cfg(B, D, H, W);
   *log_tx = cfgs[c][0];
-  *rows_per_lane = (nset == 2 && c == 0 && !dual_cfg0b()) ? 2 : cfgs[c][1];
+  *rows_per_lane = (nset == 2 && c == 0) ? 2 : cfgs[c][1];   // the level-3 dual kernel uses 2 rows/lane (register budget)
   launch_groups[0] = split_groups((Cout + 3) / 4);   // one launch; blockIdx.y covers ngroups / G splits
   return 1;
 }

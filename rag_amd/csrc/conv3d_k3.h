@@ -55,8 +55,13 @@ constexpr int K3_MAX_WLDS_BYTES = 36 * 1024;   // weight cache budget per workgr
 // NSET=2 fuses two sibling-group convolutions that feed the same destinations from two inputs
 // (Cell_3d: out = relu(bn_a(conv_a(s0))) + relu(bn_b(conv_b(s1)))) so the running sum never
 // round-trips through HBM.  WPS = waves per SIMD the register budget is sized for.
-template <int G, int LOG_TX, int R, int NSET, int WPS>
+//
+// VCO > 0 selects the VALU form for Cout = VCO <= 2 (last_3_3d has Cout = 1): a 4x4x1 MFMA would idle 3 of its
+// 4 rows there, while v_fma with wave-uniform (SGPR) weights does the same per-lane work at 2.5x the issue
+// rate.  Same tiles, staging pipeline and epilogue; a.wp[0] is then the RAW weight [Cout][Cin][27].
+template <int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
 __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
+  static_assert(VCO == 0 || (G == 1 && NSET == 1 && VCO <= 4), "VALU form: one output group, one set");
   constexpr int TX = 1 << LOG_TX;
   constexpr int YS = 64 / TX;      // lane sub-rows per wave
   constexpr int TY = YS * R;       // output rows per tile
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     rch[g] = a.res_ch[gbase + g];
   }
   const bool has_res = a.res != nullptr;
-  const bool do_relu = a.relu != 0;
+  const bool do_relu = (a.relu & 1) != 0;
 
   f32x4 acc[NSET][R][G];
 #pragma unroll
@@ -117,20 +122,45 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
 
   float st[NP];  // next stage's halo elements, in flight during the MFMA phase
 
-  auto decode = [&](int t, int& b, int& x0, int& y0, int& z0) {
+  // tile coordinates are decoded ONCE per tile (three integer divisions by run-time values are a few hundred
+  // dependent cycles) and carried in scalars: `cur` for the stage being computed, `nxt` for the one in flight
+  struct TC { int b, x0, y0, z0; };
+  auto decode_tc = [&](int t) -> TC {
     const int tx_i = t % a.tiles_x; t /= a.tiles_x;
     const int ty_i = t % a.tiles_y; t /= a.tiles_y;
     const int tz_i = t % a.tiles_z;
-    b = t / a.tiles_z;
-    x0 = tx_i * TX; y0 = ty_i * TY; z0 = tz_i * TZ;
+    return TC{t / a.tiles_z, tx_i * TX, ty_i * TY, tz_i * TZ};
+  };
+  auto decode = [&](const TC& c, int& b, int& x0, int& y0, int& z0) { b = c.b; x0 = c.x0; y0 = c.y0; z0 = c.z0; };
+
+  // A stage whose halo lies inside the volume and whose 4 channels exist needs no clamping and no zero fill.
+  // The vector-issue port is the scarce resource here (a 4x4x1 MFMA holds it for most of its 8 cycles, so every
+  // VALU instruction in staging is serialised with the MFMAs): the interior path uses wave-uniform (SGPR) row
+  // bases and immediate LDS offsets, i.e. one VMEM + one DS instruction per element and NO VALU work.
+  auto interior = [&](const TC& t, int chunk) -> bool {
+    int b, x0, y0, z0;
+    decode(t, b, x0, y0, z0);
+    return x0 >= 1 && x0 + TX + 1 <= a.W && y0 >= 1 && y0 + TY + 1 <= a.H && z0 >= 1 && z0 + TZ + 1 <= a.D &&
+           chunk * CK + CK <= a.Cin;
   };
 
   // issue the global loads of stage (t, chunk): always in-bounds (clamped); validity is applied at write time
-  auto prefetch = [&](int t, int chunk) {
+  auto prefetch = [&](const TC& t, int chunk) {
     int b, x0, y0, z0;
     decode(t, b, x0, y0, z0);
     const float* xb = a.x + (int64_t)b * a.x_bstride;
-    const int gzc = min(max(z0 - 1 + szz, 0), a.D - 1), gxc = min(max(x0 - 1 + sxx, 0), a.W - 1);
+    if (SY == 1 && interior(t, chunk)) {
+      const unsigned zx = (unsigned)((z0 - 1 + szz) * HW + x0 - 1 + sxx);   // the only per-lane quantity
+      const float* xr = xb + (int64_t)(chunk * CK) * DHW + (int64_t)(y0 - 1) * a.W;   // wave-uniform
+#pragma unroll
+      for (int c = 0; c < CK; ++c)
+#pragma unroll
+        for (int k = 0; k < KY; ++k) st[c * KY + k] = (xr + (int64_t)c * DHW + (int64_t)k * a.W)[sactive ? zx : 0u];
+      return;
+    }
+    int gzc = min(max(z0 - 1 + szz, 0), a.D - 1), gxc = min(max(x0 - 1 + sxx, 0), a.W - 1);
+    if (a.relu & 0x800) gxc = min(x0 + sxx, a.W - 1);          // DIAG: line-aligned halo rows (wrong data)
+    if (a.relu & 0x1000) gzc = min(z0, a.D - 1);               // DIAG: every lane reads the same z-plane
     const int zx = gzc * HW + gxc;
     const int gy0 = y0 - 1 + ssy;
 #pragma unroll
@@ -145,7 +175,16 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   };
 
   // write the staged stage (t, chunk) into LDS, zeroing everything outside the volume / past Cin
-  auto commit = [&](int t, int chunk) {
+  auto commit = [&](const TC& t, int chunk) {
+    if (SY == 1 && interior(t, chunk)) {
+      if (sactive) {
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+#pragma unroll
+          for (int k = 0; k < KY; ++k) wr[(c * HZ * HY + k) * HX] = st[c * KY + k];
+      }
+      return;
+    }
     int b, x0, y0, z0;
     decode(t, b, x0, y0, z0);
     const bool zx_ok = sactive && (unsigned)(z0 - 1 + szz) < (unsigned)a.D && (unsigned)(x0 - 1 + sxx) < (unsigned)a.W;
@@ -181,7 +220,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     }
   };
 
-  auto epilogue = [&](int t, auto full_, auto res_) {
+  auto epilogue = [&](const TC& t, auto full_, auto res_) {
     constexpr bool FULL = decltype(full_)::value;
     constexpr bool RES = decltype(res_)::value;
     int b, x0, y0, z0;
@@ -199,10 +238,11 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
         sc[s] = *reinterpret_cast<const f32x4*>(&bnp[s][0][g * 4]);   // LDS broadcast reads
         sh[s] = *reinterpret_cast<const f32x4*>(&bnp[s][1][g * 4]);
       }
+      constexpr int NM = VCO > 0 ? VCO : 4;   // channels of this group actually computed
       float rv[4][R];
       if (RES) {   // all residual loads of this group first, then the arithmetic and the stores
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < NM; ++m) {
           const float* rc = rb + (int64_t)(rch[g] + m) * DHW;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
@@ -212,7 +252,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
         }
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < NM; ++m) {
         if (!FULL && (gbase + g) * 4 + m >= a.Cout) continue;
         float* yc = yb + (int64_t)(ych[g] + m) * DHW;   // wave-uniform base
 #pragma unroll
@@ -226,7 +266,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
             val += v1;
           }
           if (RES) val += rv[m][r];
-          yc[off0 + (unsigned)(r * a.W)] = val;
+          if (!(a.relu & 0x100) || val == 12345.678f) yc[off0 + (unsigned)(r * a.W)] = val;   // DIAG: 0x100 skips stores
         }
       }
     }
@@ -267,10 +307,53 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     });
   };
 
-  int t = blockIdx.x, chunk = 0;
-  if (t >= ntiles) return;
-  prefetch(t, 0);
-  if (a.w_in_lds) {
+  // VALU form of the same block: weights are wave-uniform scalar loads from the raw [Cout][Cin][27] tensor
+  auto valu_block = [&](int chunk) {
+    const float* wc = wlds + chunk * NPAIR;      // raw weights cached in LDS: + co * Cin * 27 + (c * 27 + tap)
+    float vbuf[2][R + 2][3];
+    load_v(vbuf[0], std::integral_constant<int, 0>{});
+    static_for<CK * 3>([&](auto blk_) {
+      constexpr int blk = decltype(blk_)::value;
+      constexpr int c = blk / 3, dz = blk % 3;
+      if constexpr (blk + 1 < CK * 3) load_v(vbuf[(blk + 1) & 1], std::integral_constant<int, blk + 1>{});
+      static_for<9>([&](auto tap_) {
+        constexpr int dy = decltype(tap_)::value / 3, dx = decltype(tap_)::value % 3;
+        constexpr int q = c * 27 + (dz * 3 + dy) * 3 + dx;
+#pragma unroll
+        for (int co = 0; co < (VCO > 0 ? VCO : 1); ++co) {
+          const float w = wc[co * a.Cin * 27 + q];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[0][r][0][co] = fmaf(w, vbuf[blk & 1][r + dy][dx], acc[0][r][0][co]);
+        }
+      });
+    });
+  };
+
+  // XCD-aware persistent schedule: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with
+  // its own L2.  Every XCD gets one CONTIGUOUS slab of the tile index space (x fastest, then y, z) and its
+  // workgroups stride through it together, so halos shared by neighbouring tiles are L2 hits.  Speed only:
+  // any placement gives the same results.
+  int t, tend, tstep;
+  if (gridDim.x % 8 == 0) {
+    const int xcd = blockIdx.x & 7, per = (ntiles + 7) / 8;
+    t = xcd * per + (blockIdx.x >> 3);
+    tend = min((xcd + 1) * per, ntiles);
+    tstep = gridDim.x >> 3;
+  } else {
+    t = blockIdx.x; tend = ntiles; tstep = gridDim.x;
+  }
+  int chunk = 0;
+  if (t >= tend) return;
+
+  const bool diag_nomfma = (a.relu & 0x200) != 0, diag_nostage = (a.relu & 0x400) != 0;   // DIAG switches
+  TC cur = decode_tc(t), nxt = cur;
+  if (!diag_nostage) prefetch(cur, 0);
+  if constexpr (VCO > 0) {
+    // VALU form: the whole raw weight tensor [Cout][Cin][27] (<= a few KB) lives in LDS for the kernel's lifetime;
+    // global loads of it inside the loop could not be scalar (stores may alias) and would stall every 16 weights
+    const int n = a.Cout * a.Cin * 27;
+    for (int i = tid; i < n; i += 256) wlds[i] = a.wp[0][i];
+  } else if (a.w_in_lds) {
     // the G groups of this workgroup are one contiguous block per set in the packed array
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
@@ -280,31 +363,36 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
       for (int i = tid * 4; i < n; i += 1024) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
     }
   }
-  if (nch == 1 && !a.w_in_lds) load_weights(0);
+  if (VCO == 0 && nch == 1 && !a.w_in_lds) load_weights(0);
 
   while (true) {
     __syncthreads();  // every wave is done reading the previous stage's tile
-    commit(t, chunk);
+    if (!diag_nostage) commit(cur, chunk);
     __syncthreads();
 
-    // next stage: same tile / next chunk, or this workgroup's next tile (grid-stride)
+    // next stage: same tile / next chunk, or this workgroup's next tile
     int nt = t, nchunk = chunk + 1;
-    if (nchunk == nch) { nchunk = 0; nt += gridDim.x; }
-    const bool has_next = nt < ntiles;
-    if (has_next) prefetch(nt, nchunk);   // global loads stay in flight under the MFMA phase below
-    if (nch > 1 || a.w_in_lds) load_weights(chunk);   // from LDS: visible after the barrier above
+    if (nchunk == nch) { nchunk = 0; nt += tstep; }
+    const bool has_next = nt < tend;
+    if (has_next && nt != t) nxt = decode_tc(nt);
+    if (has_next && !diag_nostage) prefetch(nxt, nchunk);   // global loads stay in flight under the MFMA phase below
 
-    if (NSET == 2 && chunk >= nch0) mfma_block(std::integral_constant<int, NSET - 1>{});
-    else mfma_block(std::integral_constant<int, 0>{});
+    if (diag_nomfma) {
+    } else if constexpr (VCO > 0) {
+      valu_block(chunk);
+    } else {
+      if (nch > 1 || a.w_in_lds) load_weights(chunk);   // from LDS: visible after the barrier above
+      if (NSET == 2 && chunk >= nch0) mfma_block(std::integral_constant<int, NSET - 1>{});
+      else mfma_block(std::integral_constant<int, 0>{});
+    }
 
     if (chunk == nch - 1) {
-      int b, x0, y0, z0;
-      decode(t, b, x0, y0, z0);
-      const bool full = x0 + TX <= a.W && y0 + TY <= a.H && z0 + TZ <= a.D && (gbase + G) * 4 <= a.Cout;
+      const bool full = cur.x0 + TX <= a.W && cur.y0 + TY <= a.H && cur.z0 + TZ <= a.D &&
+                        (VCO > 0 ? VCO == a.Cout : (gbase + G) * 4 <= a.Cout);
       if (full) {
-        if (has_res) epilogue(t, std::true_type{}, std::true_type{}); else epilogue(t, std::true_type{}, std::false_type{});
+        if (has_res) epilogue(cur, std::true_type{}, std::true_type{}); else epilogue(cur, std::true_type{}, std::false_type{});
       } else {
-        if (has_res) epilogue(t, std::false_type{}, std::true_type{}); else epilogue(t, std::false_type{}, std::false_type{});
+        if (has_res) epilogue(cur, std::false_type{}, std::true_type{}); else epilogue(cur, std::false_type{}, std::false_type{});
       }
 #pragma unroll
       for (int s = 0; s < NSET; ++s)
@@ -315,6 +403,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     }
     if (!has_next) break;
     t = nt;
+    cur = nxt;
     chunk = nchunk;
   }
 }
@@ -342,20 +431,22 @@ inline int split_groups(int ngroups) {
   return 1;
 }
 
-template <int G, int LOG_TX, int R, int NSET, int WPS>
+template <int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
 static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
   constexpr size_t tile_bytes = (size_t)CK * 6 * (TY + 2) * (TX + 2) * sizeof(float);
   const size_t wbytes = (size_t)G * (a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0)) * PACK_PER_GC * sizeof(float);
   // cache the weights in LDS when they fit the budget (policy switch for experiments: RAGMI_K3_WLDS=0 never,
   // 1 whenever they fit, 2 (default) only for multi-stage tiles)
+  static const int diag_nostore = [] { const char* e = getenv("RAGMI_K3_DIAG_NOSTORE"); return e ? atoi(e) : 0; }();
+  if (diag_nostore) a.relu |= (diag_nostore << 8);   // DIAG: 1 no stores, 2 no MFMA block, 4 no staging
   static const int policy = [] { const char* e = getenv("RAGMI_K3_WLDS"); return e ? atoi(e) : 2; }();
   const int nstages = a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0);
-  a.w_in_lds = (policy != 0 && wbytes <= (size_t)K3_MAX_WLDS_BYTES && (policy == 1 || nstages > 1)) ? 1 : 0;
-  const size_t lds = tile_bytes + (a.w_in_lds ? wbytes : 0);
+  a.w_in_lds = (VCO == 0 && policy != 0 && wbytes <= (size_t)K3_MAX_WLDS_BYTES && (policy == 1 || nstages > 1)) ? 1 : 0;
+  const size_t lds = tile_bytes + (VCO > 0 ? (size_t)a.Cout * a.Cin * 27 * sizeof(float) : (a.w_in_lds ? wbytes : 0));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(tile_bytes + K3_MAX_WLDS_BYTES));
     attr_set = true;
   }
@@ -367,11 +458,12 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   for (int i = 0; i < ncached; ++i)
     if (cached_lds[i] == lds) slots = cached_slots[i];
   if (slots == 0) {
-    slots = persistent_slots(conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS>, lds);
+    slots = persistent_slots(conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>, lds);
     if (ncached < 8) { cached_lds[ncached] = lds; cached_slots[ncached] = slots; ++ncached; }
   }
-  const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
-  hipLaunchKernelGGL((conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
+  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
+  if (gx >= 8) gx -= gx % 8;   // the XCD-aware schedule wants a multiple of 8 workgroups per split
+  hipLaunchKernelGGL((conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
 }
 
 // one tile configuration: sets the tile counts and launches with G = split_groups(ngroups)
@@ -397,9 +489,21 @@ static int launch_cfg(K3Args a, int ngroups, hipStream_t s) {
 int launch_k3_s1_cfg0(const K3Args& a, int ngroups, hipStream_t s);   // TX=32 R=4
 int launch_k3_s1_cfg1(const K3Args& a, int ngroups, hipStream_t s);   // TX=16 R=2
 int launch_k3_s1_cfg2(const K3Args& a, int ngroups, hipStream_t s);   // TX=8  R=1
-int launch_k3_s2_cfg0(const K3Args& a, int ngroups, hipStream_t s);   // dual, TX=32 R=2, 2 waves/SIMD
-int launch_k3_s2_cfg0b(const K3Args& a, int ngroups, hipStream_t s);  // dual, TX=32 R=4, 1 wave/SIMD
+int launch_k3_s2_cfg0(const K3Args& a, int ngroups, hipStream_t s);   // dual, TX=32 R=4
 int launch_k3_s2_cfg1(const K3Args& a, int ngroups, hipStream_t s);
 int launch_k3_s2_cfg2(const K3Args& a, int ngroups, hipStream_t s);
+int launch_k3_valu(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights
+
+template <int LOG_TX, int R, int VCO>
+static int launch_cfg_valu(K3Args a, hipStream_t s) {
+  constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
+  a.tiles_x = (int)ceil_div(a.W, TX);
+  a.tiles_y = (int)ceil_div(a.H, TY);
+  a.tiles_z = (int)ceil_div(a.D, 4);
+  const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
+  launch_one<1, LOG_TX, R, 1, 2, VCO>(a, ntiles, 1, s);
+  return check_launch("conv3d_k3_small");
+}
 
 }  // namespace ragmi

@@ -25,41 +25,41 @@ __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
   const int ox = (int)(o % a.Wo), oy = (int)(o / a.Wo);
   const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
   const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
-  const int64_t hw = (int64_t)a.h * a.w;
+  const int hw = a.h * a.w;
   const float* base = a.cost + (int64_t)b * a.d * hw;
   const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1;
   const int o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
+  const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
+  (void)w00; (void)w01; (void)w10; (void)w11;
 
-  auto plane = [&](int z) -> float {  // bilinear sample of coarse plane z at (oy, ox)
-    const float* p = base + z * hw;
+  auto plane = [&](int z) -> float {  // bilinear sample of coarse plane z at (oy, ox); x innermost like ATen
+    const float* p = base + (int64_t)z * hw;
     return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
   };
 
-  // two cached coarse-plane samples; with upsampling the fine index walks them in order
-  int cz0 = -1, cz1 = -1;
-  float cv0 = 0.f, cv1 = 0.f;
+  // Walk the fine disparities in order; the coarse pair (cz, cz+1) only ever moves forward, so each
+  // plane is sampled once.  Online softmax of -cost in base 2, branch-free:
+  //   m' = max(m, t); s = s*2^((m-m')k) + 2^((t-m')k); differences are formed BEFORE scaling by k=log2(e)
+  //   so large |cost| does not lose the bits that matter near the maximum.
+  constexpr float K = 1.4426950408889634f;
+  int cz = 0;
+  float b0 = plane(0), b1 = plane(a.d > 1 ? 1 : 0);
   float m = -INFINITY, s = 0.f, ws = 0.f;
   for (int dd = 0; dd < a.maxdisp; ++dd) {
     const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
-    float v0, v1;
-    if (lz.i0 == cz0) v0 = cv0;
-    else if (lz.i0 == cz1) v0 = cv1;
-    else v0 = plane(lz.i0);
-    if (lz.i1 == lz.i0) v1 = v0;
-    else if (lz.i1 == cz1) v1 = cv1;
-    else if (lz.i1 == cz0) v1 = cv0;
-    else v1 = plane(lz.i1);
-    cz0 = lz.i0; cv0 = v0; cz1 = lz.i1; cv1 = v1;
-    const float t = -(lz.w0 * v0 + lz.w1 * v1);  // Softmin = softmax of the negated cost
-    if (t > m) {
-      const float r = expf(m - t);  // exp(-inf) = 0 on the first sample
-      s *= r;
-      ws *= r;
-      m = t;
+    while (lz.i0 > cz) {   // rarely more than one step (only when down-sampling the disparity axis)
+      ++cz;
+      b0 = b1;
+      b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1);
     }
-    const float e = expf(t - m);
-    s += e;
-    ws = fmaf(e, (float)dd, ws);
+    const float v1 = lz.i1 == lz.i0 ? b0 : b1;
+    const float t = -(lz.w0 * b0 + lz.w1 * v1);
+    const float mn = fmaxf(m, t);
+    const float r = __builtin_amdgcn_exp2f((m - mn) * K);   // 2^(-inf) = 0 on the first sample
+    const float e = __builtin_amdgcn_exp2f((t - mn) * K);
+    s = fmaf(s, r, e);
+    ws = fmaf(ws, r, e * (float)dd);
+    m = mn;
   }
   a.out[(int64_t)b * npix + o] = ws / s;
 }

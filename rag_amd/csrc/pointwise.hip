@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
   const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= a.dhw) return;
   const int b = blockIdx.y;
+  a.co0 = blockIdx.z * NCO;   // output-channel slab of this block
   const float* xp = a.x + b * a.x_bstride + p;
   float acc[NCO][V];
 #pragma unroll
@@ -92,20 +93,38 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, i
   }
 }
 
-template <bool VEC>
-static void launch_k1(const K1Args& base, int B, hipStream_t s) {
+template <int NCO, bool VEC>
+static void launch_k1_nco(const K1Args& a, int B, hipStream_t s) {
   constexpr int V = VEC ? 4 : 1;
-  dim3 grid((unsigned)ceil_div(ceil_div(base.dhw, V), 256), B);
-  K1Args a = base;
-  int co = 0;
-  while (co < a.Cout) {
-    const int left = a.Cout - co;
-    a.co0 = co;
-    if (left >= 24) { hipLaunchKernelGGL((conv_k1_kernel<24, VEC>), grid, dim3(256), 0, s, a); co += 24; }
-    else if (left >= 16) { hipLaunchKernelGGL((conv_k1_kernel<16, VEC>), grid, dim3(256), 0, s, a); co += 16; }
-    else if (left >= 12) { hipLaunchKernelGGL((conv_k1_kernel<12, VEC>), grid, dim3(256), 0, s, a); co += 12; }
-    else if (left >= 8) { hipLaunchKernelGGL((conv_k1_kernel<8, VEC>), grid, dim3(256), 0, s, a); co += 8; }
-    else { hipLaunchKernelGGL((conv_k1_kernel<4, VEC>), grid, dim3(256), 0, s, a); co += 4; }
+  dim3 grid((unsigned)ceil_div(ceil_div(a.dhw, V), 256), B, (unsigned)ceil_div(a.Cout, NCO));
+  hipLaunchKernelGGL((conv_k1_kernel<NCO, VEC>), grid, dim3(256), 0, s, a);
+}
+
+// Pick the widest output slab per thread that still leaves enough threads to fill the chip:
+// large volumes read the input once (NCO = Cout); tiny ones (level-12: 53k voxels) are latency-
+// bound, so they trade L2 re-reads of the input for parallelism (slabs of 4 on blockIdx.z).
+template <bool VEC>
+static void launch_k1(const K1Args& a, int B, hipStream_t s) {
+  constexpr int V = VEC ? 4 : 1;
+  const int64_t threads = (int64_t)B * ceil_div(a.dhw, V);
+  const int64_t want = 256 * 256 * 2;   // ~2 workgroups per CU
+  static const int widths[5] = {24, 16, 12, 8, 4};
+  int cover = 24;   // smallest slab covering Cout (Cout > 24 runs in slabs of 24)
+  for (int w : widths)
+    if (w >= a.Cout) cover = w;
+  int nco = 4;
+  if (threads >= want) {
+    nco = cover;    // plenty of threads: read the input once
+  } else {
+    for (int w : widths)   // widest slab that still yields enough blocks
+      if (w <= cover && threads * ceil_div(a.Cout, w) >= want) { nco = w; break; }
+  }
+  switch (nco) {
+    case 24: launch_k1_nco<24, VEC>(a, B, s); break;
+    case 16: launch_k1_nco<16, VEC>(a, B, s); break;
+    case 12: launch_k1_nco<12, VEC>(a, B, s); break;
+    case 8: launch_k1_nco<8, VEC>(a, B, s); break;
+    default: launch_k1_nco<4, VEC>(a, B, s); break;
   }
 }
 
@@ -119,11 +138,13 @@ extern "C" int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride, const void*
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1: scale/shift must both be given or both NULL");
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && DHW > 0 && y_ch0 >= 0, RAGMI_EINVAL, "conv3d_k1: bad size");
   RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k1: dtype %d not built", dtype);
-  RAGMI_REQUIRE(B <= 65535, RAGMI_EUNSUPPORTED, "conv3d_k1: B too large");
+  RAGMI_REQUIRE(B <= 65535 && Cout <= 4 * 65535, RAGMI_EUNSUPPORTED, "conv3d_k1: B or Cout too large");
   K1Args a{(const float*)x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
            (float*)y, y_bstride, y_ch0, Cin, Cout, 0, DHW, relu};
+  // 16-B columns need alignment; small volumes use one voxel per thread for 4x the parallelism
   const bool vec = (DHW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) &&
-                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                   (int64_t)B * DHW >= (1 << 19);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (vec) launch_k1<true>(a, B, s); else launch_k1<false>(a, B, s);
   return check_launch("conv3d_k1");

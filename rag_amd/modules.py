@@ -82,6 +82,10 @@ class ConvBR_3d(nn.Module):
                                       "(everything the reference's Matching Net instantiates)")
         return k[0]
 
+    def _small(self) -> bool:
+        """Cout <= 2 (last_3_3d): VALU form of the 3x3x3 kernel instead of the 4-row MFMA."""
+        return self.conv.out_channels <= 2 and self.conv.in_channels % 4 == 0 and self.conv.in_channels <= 128
+
     def stamp(self) -> tuple:
         w, bn = self.conv.weight, self.bn
         return (w.data_ptr(), w._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
@@ -97,7 +101,12 @@ class ConvBR_3d(nn.Module):
             k = self._geometry()
             w = self.conv.weight.detach()
             with torch.no_grad():
-                wk = ops.conv3d_k3_pack(w) if k == 3 else w.reshape(w.shape[0], w.shape[1]).contiguous()
+                if k == 3 and self._small():
+                    wk = w.contiguous()                      # VALU form reads the raw weight
+                elif k == 3:
+                    wk = ops.conv3d_k3_pack(w)
+                else:
+                    wk = w.reshape(w.shape[0], w.shape[1]).contiguous()
                 if self.use_bn:
                     bn = self.bn
                     # same folding ATen's eval batch_norm uses: alpha = gamma * rsqrt(var + eps); beta = b - mean * alpha
@@ -115,7 +124,9 @@ class ConvBR_3d(nn.Module):
         cout = self.conv.out_channels
         if out is None:
             out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
-        if k == 3:
+        if k == 3 and self._small():
+            ops.conv3d_k3_small(x, wk, scale, shift, self.relu, out, out_ch0)
+        elif k == 3:
             groups = [out_ch0 + 4 * g for g in range(ops.packed_groups(cout))]
             ops.conv3d_k3(x, wk, cout, scale, shift, self.relu, out, groups)
         else:

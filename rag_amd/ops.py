@@ -121,6 +121,22 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
     return out
 
 
+def conv3d_k3_small(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu: bool, out: torch.Tensor, out_ch0: int = 0,
+                    res: Optional[torch.Tensor] = None, res_ch0: int = 0) -> torch.Tensor:
+    """3x3x3 ConvBR_3d with Cout <= 2 on the VALU (raw weight [Cout, Cin, 3, 3, 3]): ragmi_conv3d_k3_small_fwd."""
+    _need_gpu(x, weight, scale, shift, out, res)
+    B, Cin, D, H, W = x.shape
+    cout = weight.shape[0]
+    w = weight.detach().contiguous()
+    if out_ch0 + cout > out.shape[1] or tuple(out.shape[2:]) != (D, H, W):
+        raise ValueError("conv3d_k3_small: output buffer too small / wrong spatial size")
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(load_library().ragmi_conv3d_k3_small_fwd(
+        x.data_ptr(), _planes(x), w.data_ptr(), ptr(scale), ptr(shift), int(relu), out.data_ptr(), _planes(out), out_ch0,
+        ptr(res), _planes(res) if res is not None else 0, res_ch0, B, Cin, cout, D, H, W, F32, _stream()), "conv3d_k3_small")
+    return out
+
+
 def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a, shift_a,
                    packed_b: torch.Tensor, scale_b, shift_b, cout: int, relu: bool, out: torch.Tensor,
                    out_group_ch: Optional[Sequence[int]] = None, res: Optional[torch.Tensor] = None,

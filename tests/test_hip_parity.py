@@ -164,6 +164,23 @@ def test_conv3d_k3_dual_vs_oracle(ra, ca, cb, cout, shape):
     np.testing.assert_allclose(out.cpu().numpy(), (ref + res).numpy(), **TOL)
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(12, 1, (1, 5, 12, 40)), (12, 1, (2, 3, 7, 9)), (4, 2, (1, 6, 10, 20)), (12, 1, (1, 64, 16, 96))])
+def test_conv3d_k3_small_vs_oracle(ra, cin, cout, shape):
+    """VALU form for Cout <= 2 (last_3_3d)."""
+    B, D, H, W = shape
+    x = torch.randn((B, cin, D, H, W), generator=gen(30))
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen(31)) * (2.0 / (27 * cin)) ** 0.5
+    res = torch.randn((B, cout + 1, D, H, W), generator=gen(32))
+    ref = F.conv3d(x, w, padding=1)
+    out = torch.full((B, cout, D, H, W), float("nan"), device=DEV)
+    ra.ops.conv3d_k3_small(gpu(x), gpu(w), None, None, False, out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), **TOL)
+    scale, shift = torch.rand(cout, generator=gen(33)) + 0.5, torch.randn(cout, generator=gen(34)) * 0.1
+    ra.ops.conv3d_k3_small(gpu(x), gpu(w), gpu(scale), gpu(shift), True, out, 0, gpu(res), 1)
+    exp = F.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)) + res[:, 1:1 + cout]
+    np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), **TOL)
+
+
 def test_conv3d_linearity_full_size(ra):
     """Size-independent property at the headline level-3 shape: conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
     D, H, W = 64, 128, 416
