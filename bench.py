@@ -105,6 +105,37 @@ class K3Profiler:
         return by
 
 
+def shard_range(n_items: int, world: int, rank: int):
+    """Contiguous [lo, hi) slice of `n_items` independent stereo pairs owned by `rank` (GPU g gets pairs
+    [g*B/N, (g+1)*B/N)); sizes differ by at most one."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def timed_region(step, steps: int, warmup: int, dist=None, sync=lambda: None, device="cpu"):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides;
+    returns the MAX elapsed seconds over ranks (the only collective: one scalar all-reduce for timing)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def cpu_baseline(net, lf, rf):
     """Oracle leg (checker code, allowed here only): one pair of the same workload on host cores."""
     from oracle import matching_oracle as O
@@ -161,11 +192,6 @@ def main():
         with torch.no_grad():
             return net(lf, rf)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
@@ -178,21 +204,18 @@ def main():
         graph.replay()
         torch.cuda.synchronize()
 
-    prof.enabled = graph is None and rank == 0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    holder = {}
+
+    def timed_step():
         if graph is not None:
             graph.replay()
         else:
-            out = step()
-    barrier()
-    dt = time.perf_counter() - t0
+            holder["out"] = step()
+
+    prof.enabled = graph is None and rank == 0
+    dt = timed_region(timed_step, args.steps, 0, dist, torch.cuda.synchronize, device)   # warm-up was done above
     prof.enabled = False
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    out = holder.get("out", out)
 
     if graph is not None and rank == 0:   # per-kernel events need eager launches: same kernels, extra pass
         prof.enabled = True

@@ -14,7 +14,10 @@ from .modules import (  # noqa: F401
     Identity_3d, MatchingNet, OPS_3d, PRIMITIVES_3D,
 )
 
+from .network import Cell_2d, ConvBR_2d, Network  # noqa: E402,F401
+
 __all__ = [
+    "Network", "Cell_2d", "ConvBR_2d",
     "ops", "load_library", "lib_path", "MatchingNet", "Cell_3d", "ConvBR_3d", "Identity_3d", "Disp",
     "DisparityRegression", "OPS_3d", "PRIMITIVES_3D", "Genotype", "ALL_CONV_GENOTYPE", "ALL_SKIP_GENOTYPE",
 ]

@@ -48,7 +48,12 @@ def sd_np(module, prefix="sd::"):
     return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]   # e.g. `make_golden.py g8` regenerates one fixture family
+
+
 def save(name, **arrays):
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
@@ -223,6 +228,34 @@ def main():
     arrays.update({k_: v for k_, v in sd_np(net).items()
                    if any(s in k_ for s in ("stem3d", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d"))})
     save("g7_plumbing_264x516_d48", **arrays)
+
+
+    # ---- G8: growth-API bookkeeping of Network.expand / get_new_model / select (rag_model.py:391-551, 709-845)
+    import json
+    torch.manual_seed(81)
+    net = rm.Network(genotype(ALL_CONV), "cpu")
+    keys0 = sorted(net.state_dict().keys())
+    net.expand(1, genotype(MIXED_UNSORTED), "cpu")
+    keys1 = sorted(net.state_dict().keys())
+    p_expand = [p_.numpy().tolist() for p_ in net.p]
+    new_models = {k_: [int(v) for v in vs] for k_, vs in net.new_models.items()}
+    winners = (1, 5, 9, 12)                 # p-indices where the candidate unit wins
+    for k_, p_ in enumerate(net.p):
+        if k_ in winners:
+            p_[-1] = 0.9
+    best = net.select(1)
+    to_int = lambda d: {k_: [int(v) for v in vs] for k_, vs in d.items()}  # noqa: E731
+    blob = {"keys_initial": keys0, "keys_expanded": keys1, "keys_selected": sorted(net.state_dict().keys()),
+            "p_after_expand": p_expand, "new_models": new_models, "winners": list(winners),
+            "best_archi": to_int(best), "model_to_train": to_int(net.model_to_train),
+            "length": {k_: int(v) for k_, v in net.length.items()}, "arch_init": to_int(net.arch_init)}
+    # second growth round on top, everything reused
+    net.expand(2, genotype(ALL_SKIP), "cpu")
+    best2 = net.select(2)
+    blob["best_archi_round2"] = to_int(best2)
+    blob["length_round2"] = {k_: int(v) for k_, v in net.length.items()}
+    blob["keys_round2"] = sorted(net.state_dict().keys())
+    save("g8_growth_api", blob=np.frombuffer(json.dumps(blob).encode(), dtype=np.uint8))
 
 
 if __name__ == "__main__":

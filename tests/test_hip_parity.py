@@ -283,6 +283,27 @@ def test_matchingnet_plumbing_config_golden(ra):
     np.testing.assert_allclose(disp.double().mean(dim=2).numpy()[0], g["disp_row_means"], rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("name", ["conv_48x96_d48", "unsorted_36x60_d24"])
+def test_network_forward_from_images_golden(ra, name):
+    """Full reference-layout Network (PyTorch Feature Net -> HIP Matching Net) from images vs the reference output.
+    The 2-D Feature Net runs in PyTorch-ROCm (not part of the hot path), so features differ from the CPU ones in
+    the last bits; near-tie pixels may flip -> EPE gate with a looser per-pixel quantile."""
+    g = load_golden("g5_forward_" + name)
+    rows = g["rows"]
+    net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=int(g["maxdisp"]))
+    net.load_state_dict(split_sd(g), strict=True)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        disp = net(gpu(g["left"]), gpu(g["right"]), 0, net.arch_init)
+        fea = net.feature(gpu(g["left"]), net.arch_init, None)
+        sel = [0] * 18
+        disp_search = net.search_forward(gpu(g["left"]), gpu(g["right"]), 0, sel)
+    np.testing.assert_allclose(fea.cpu().numpy(), g["left_fea"], rtol=1e-3, atol=1e-3)
+    ref = torch.from_numpy(g["disp"])
+    assert O.epe(disp.cpu(), ref) <= 5e-3, O.epe(disp.cpu(), ref)
+    assert torch.equal(disp, disp_search)      # search_forward with all-zero unit choices == forward(arch_init)
+
+
 def test_matchingnet_batch_shard_equivalence(ra):
     """Multi-GPU sharding is a batch split with no collective: a B=3 forward equals three B=1 forwards bitwise."""
     rows = O.ALL_CONV

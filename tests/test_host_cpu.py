@@ -119,3 +119,57 @@ def test_training_mode_is_refused_not_emulated():
         m.prepared()
     with pytest.raises(NotImplementedError):   # autograd through the HIP path is not silently dropped
         m.eval()(torch.zeros(1, 4, 2, 2, 2, requires_grad=True))
+
+
+# ------------------------------------------------------------------ Network (growth loop surface)
+def _blob():
+    import json
+    return json.loads(bytes(load_golden("g8_growth_api")["blob"]).decode())
+
+
+def test_network_state_dict_matches_reference_network():
+    """Full-Network keys and shapes (Feature Net + Matching Net) == the reference Network's; strict load."""
+    import rag_amd
+    g = load_golden("g5_forward_unsorted_36x60_d24")
+    rows = g["rows"]
+    ref = split_sd(g)
+    net = rag_amd.Network(rag_amd.Genotype(rows, None, rows, None), "cpu", maxdisp=int(g["maxdisp"]))
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.items()}
+    net.load_state_dict(ref, strict=True)
+    assert sorted(net.state_dict().keys()) == sorted(ref.keys())
+
+
+def test_network_growth_api_matches_reference_bookkeeping():
+    """expand / get_new_model / select replayed against the reference's own run (tests/golden/make_golden.py G8)."""
+    import rag_amd
+    blob = _blob()
+    mixed = np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]])
+    geno = lambda r: rag_amd.Genotype(r, None, r, None)  # noqa: E731
+    net = rag_amd.Network(geno(O.ALL_CONV), "cpu")
+    assert sorted(net.state_dict().keys()) == blob["keys_initial"]
+    assert {k: list(v) for k, v in net.arch_init.items()} == blob["arch_init"]
+    net.expand(1, geno(mixed), "cpu")
+    assert sorted(net.state_dict().keys()) == blob["keys_expanded"]
+    assert [[round(float(x), 6) for x in p] for p in net.p] == [[round(x, 6) for x in p] for p in blob["p_after_expand"]]
+    assert {k: [int(i) for i in v] for k, v in net.new_models.items()} == blob["new_models"]
+    for k, p in enumerate(net.p):
+        if k in blob["winners"]:
+            p[-1] = 0.9
+    best = net.select(1)
+    as_int = lambda d: {k: [int(i) for i in v] for k, v in d.items()}  # noqa: E731
+    assert as_int(best) == blob["best_archi"]
+    assert as_int(net.model_to_train) == blob["model_to_train"]
+    assert {k: int(v) for k, v in net.length.items()} == blob["length"]
+    assert sorted(net.state_dict().keys()) == blob["keys_selected"]
+    # get_param / modify_param address exactly the units to train
+    net.modify_param({k: list(range(net.length[k])) for k in net.length if k in net.new_models}, False)
+    net.modify_param(net.model_to_train, True)
+    trainable = {n for n, p in net.named_parameters() if p.requires_grad}
+    n_params = sum(len(list(g["params"])) for g in net.get_param(net.model_to_train))
+    assert n_params == len(trainable) and any(n.startswith("stem2d1.1.") for n in trainable)
+    assert all(not n.startswith("stem2d0.") for n in trainable) and any(n.startswith("last_3_3d.1.") for n in trainable)
+    net.expand(2, geno(O.ALL_SKIP), "cpu")
+    best2 = net.select(2)
+    assert as_int(best2) == blob["best_archi_round2"]
+    assert {k: int(v) for k, v in net.length.items()} == blob["length_round2"]
+    assert sorted(net.state_dict().keys()) == blob["keys_round2"]
