@@ -131,6 +131,18 @@ int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride,
                         int dtype, void* stream);
 
 /*
+ * Trilinear resample fused into the 1x1x1 ConvBR_3d that consumes it:
+ *   y[b, y_ch0 + co] = act(bn(W . interpolate(x, [Do,Ho,Wo], 'trilinear', align_corners)))
+ * (Cell_3d down/up-sampling + preprocess, rag_model.py:146-155; head last_6_3d(upsample_12(.)), :358-365).
+ * x: [B, Cin, Di, Hi, Wi]; the interpolated tensor is never materialised.
+ */
+int ragmi_conv3d_k1_resample_fwd(const void* x, int64_t x_bstride, int Di, int Hi, int Wi,
+                                 const void* weight, const void* scale, const void* shift, int relu,
+                                 void* y, int64_t y_bstride, int y_ch0,
+                                 int B, int Cin, int Cout, int Do, int Ho, int Wo, int align_corners,
+                                 int dtype, void* stream);
+
+/*
  * Trilinear resample, F.interpolate(mode='trilinear') with ATen's source-index
  * rule for align_corners = 1 (rag_model.py:150-153, 357-358) or 0.
  * x: [B, C, Di, Hi, Wi] -> y: [B, C, Do, Ho, Wo] (contiguous).

@@ -28,6 +28,8 @@ SIGNATURES = {
     "ragmi_conv3d_k3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int32_p, c_int32_p, c_int32_p, c_int]),
     "ragmi_conv3d_k1_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "ragmi_conv3d_k1_resample_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                             c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_trilinear3d_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     "ragmi_add_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,

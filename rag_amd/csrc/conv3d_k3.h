@@ -461,6 +461,8 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
     slots = persistent_slots(conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>, lds);
     if (ncached < 8) { cached_lds[ncached] = lds; cached_slots[ncached] = slots; ++ncached; }
   }
+  static const int occ_cap = [] { const char* e = getenv("RAGMI_K3_MAX_WG_PER_CU"); return e ? atoi(e) : 0; }();   // experiment
+  if (occ_cap > 0) slots = std::min(slots, occ_cap * 256);
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
   if (gx >= 8) gx -= gx % 8;   // the XCD-aware schedule wants a multiple of 8 workgroups per split
   hipLaunchKernelGGL((conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);

@@ -77,6 +77,71 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
   }
 }
 
+// Trilinear resample fused into the 1x1x1 ConvBR_3d that consumes it (Cell_3d: s1 = interpolate(prev) ->
+// preprocess, rag_model.py:146-155; head: last_6_3d(upsample_12(.)), :358-365).  A thread owns one OUTPUT voxel:
+// it computes its 3 (index, weight) pairs once, gathers the 8 taps of every input channel (for the x0.5 case each
+// input voxel is read exactly once overall), interpolates in ATen's nesting order and feeds the channel mix.
+// The interpolated tensor is never written to HBM.
+struct K1RArgs {
+  K1Args k;
+  int Di, Hi, Wi, Do, Ho, Wo;
+  float sd, sh, sw;
+  int align;
+};
+
+template <int NCO>
+__global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RArgs r) {
+  K1Args& a = r.k;
+  const int64_t ovol = (int64_t)r.Do * r.Ho * r.Wo;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= ovol) return;
+  const int b = blockIdx.y;
+  a.co0 = blockIdx.z * NCO;
+  const int ox = (int)(o % r.Wo);
+  const int64_t t = o / r.Wo;
+  const int oy = (int)(t % r.Ho), oz = (int)(t / r.Ho);
+  const LinIdx lz = lin_index(oz, r.Di, r.Do, r.sd, r.align);
+  const LinIdx ly = lin_index(oy, r.Hi, r.Ho, r.sh, r.align);
+  const LinIdx lx = lin_index(ox, r.Wi, r.Wo, r.sw, r.align);
+  const int64_t ivol = (int64_t)r.Di * r.Hi * r.Wi;
+  const int r00 = (lz.i0 * r.Hi + ly.i0) * r.Wi, r01 = (lz.i0 * r.Hi + ly.i1) * r.Wi;
+  const int r10 = (lz.i1 * r.Hi + ly.i0) * r.Wi, r11 = (lz.i1 * r.Hi + ly.i1) * r.Wi;
+  const float* xp = a.x + b * a.x_bstride;
+  float acc[NCO];
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) acc[j] = 0.f;
+#pragma unroll 2
+  for (int ci = 0; ci < a.Cin; ++ci) {
+    const float* pc = xp + ci * ivol;
+    const float v000 = pc[r00 + lx.i0], v001 = pc[r00 + lx.i1], v010 = pc[r01 + lx.i0], v011 = pc[r01 + lx.i1];
+    const float v100 = pc[r10 + lx.i0], v101 = pc[r10 + lx.i1], v110 = pc[r11 + lx.i0], v111 = pc[r11 + lx.i1];
+    const float a0 = ly.w0 * (lx.w0 * v000 + lx.w1 * v001) + ly.w1 * (lx.w0 * v010 + lx.w1 * v011);
+    const float a1 = ly.w0 * (lx.w0 * v100 + lx.w1 * v101) + ly.w1 * (lx.w0 * v110 + lx.w1 * v111);
+    const float xv = lz.w0 * a0 + lz.w1 * a1;
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) {
+      const int co = a.co0 + j;
+      const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
+      acc[j] = fmaf(wv, xv, acc[j]);
+    }
+  }
+  float* yp = a.y + b * a.y_bstride + o;
+#pragma unroll
+  for (int j = 0; j < NCO; ++j) {
+    const int co = a.co0 + j;
+    if (co >= a.Cout) break;
+    float v = a.scale ? fmaf(acc[j], a.scale[co], a.shift[co]) : acc[j];
+    yp[(int64_t)(a.y_ch0 + co) * ovol] = a.relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+template <int NCO>
+static void launch_k1r_nco(const K1RArgs& r, int B, hipStream_t s) {
+  const int64_t ovol = (int64_t)r.Do * r.Ho * r.Wo;
+  dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)ceil_div(r.k.Cout, NCO));
+  hipLaunchKernelGGL((conv_k1_resample_kernel<NCO>), grid, dim3(256), 0, s, r);
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, int64_t a_bs, const float* __restrict__ b,
                                                   int64_t b_bs, float* __restrict__ y, int64_t y_bs, int64_t n) {
@@ -144,10 +209,51 @@ extern "C" int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride, const void*
   // 16-B columns need alignment; small volumes use one voxel per thread for 4x the parallelism
   const bool vec = (DHW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) &&
                    ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
-                   (int64_t)B * DHW >= (1 << 19);
+                   (int64_t)B * DHW >= (1 << 18);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (vec) launch_k1<true>(a, B, s); else launch_k1<false>(a, B, s);
   return check_launch("conv3d_k1");
+}
+
+extern "C" int ragmi_conv3d_k1_resample_fwd(const void* x, int64_t x_bstride, int Di, int Hi, int Wi, const void* weight,
+                                            const void* scale, const void* shift, int relu, void* y, int64_t y_bstride,
+                                            int y_ch0, int B, int Cin, int Cout, int Do, int Ho, int Wo, int align_corners,
+                                            int dtype, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k1_resample: null pointer");
+  RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1_resample: scale/shift must both be given or both NULL");
+  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && y_ch0 >= 0, RAGMI_EINVAL,
+                "conv3d_k1_resample: bad size");
+  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k1_resample: dtype %d not built", dtype);
+  RAGMI_REQUIRE(B <= 65535 && (int64_t)Di * Hi * Wi < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: size too large");
+  K1RArgs r{};
+  r.k = K1Args{(const float*)x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
+               (float*)y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu};
+  r.Di = Di; r.Hi = Hi; r.Wi = Wi; r.Do = Do; r.Ho = Ho; r.Wo = Wo;
+  r.sd = lin_scale(Di, Do, align_corners); r.sh = lin_scale(Hi, Ho, align_corners); r.sw = lin_scale(Wi, Wo, align_corners);
+  r.align = align_corners ? 1 : 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // slab width: same policy as the plain kernel (one voxel per thread here)
+  const int64_t threads = (int64_t)B * Do * Ho * Wo, want = 256 * 256 * 2;
+  static const int widths[5] = {24, 16, 12, 8, 4};
+  int cover = 24;
+  for (int w : widths)
+    if (w >= Cout) cover = w;
+  int nco = 4;
+  if (threads >= want) {
+    nco = cover;
+  } else {
+    for (int w : widths)
+      if (w <= cover && threads * ceil_div(Cout, w) >= want) { nco = w; break; }
+  }
+  switch (nco) {
+    case 24: launch_k1r_nco<24>(r, B, s); break;
+    case 16: launch_k1r_nco<16>(r, B, s); break;
+    case 12: launch_k1r_nco<12>(r, B, s); break;
+    case 8: launch_k1r_nco<8>(r, B, s); break;
+    default: launch_k1r_nco<4>(r, B, s); break;
+  }
+  return check_launch("conv3d_k1_resample");
 }
 
 extern "C" int ragmi_add_fwd(const void* a, int64_t a_bstride, int a_ch0, const void* b, int64_t b_bstride, int b_ch0,

@@ -117,11 +117,23 @@ class ConvBR_3d(nn.Module):
             self._cache = (stamp, wk, scale, shift)
         return self._cache[1], self._cache[2], self._cache[3]
 
-    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_ch0: int = 0) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_ch0: int = 0,
+                resample_to: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """`out`/`out_ch0` write into a channel slice of a wider buffer.  `resample_to` (1x1x1 only) first resamples x
+        trilinearly (align_corners=True) to that size inside the same kernel — the reference's
+        `conv(F.interpolate(x, size, mode='trilinear', align_corners=True))`."""
         _require_inference(x, self.conv.weight)
         k = self._geometry()
         wk, scale, shift = self.prepared()
         cout = self.conv.out_channels
+        if resample_to is not None and tuple(resample_to) == tuple(x.shape[2:]):
+            resample_to = None
+        if resample_to is not None:
+            if k != 1:
+                raise NotImplementedError("ConvBR_3d: fused resample is built for the 1x1x1 form only")
+            if out is None:
+                out = torch.empty((x.shape[0], cout) + tuple(int(v) for v in resample_to), device=x.device, dtype=torch.float32)
+            return ops.conv3d_k1_resample(x, resample_to, True, wk, scale, shift, self.relu, out, out_ch0)
         if out is None:
             out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
         if k == 3 and self._small():
@@ -249,13 +261,15 @@ class Cell_3d(nn.Module):
             raise NotImplementedError("rag_amd.Cell_3d: filter_multiplier must be a multiple of 4 and "
                                       "block_multiplier <= steps (true for every cell the reference builds)")
         s0, s1 = prev_prev_input, prev_input
+        # the trilinear resamples (rag_model.py:146-153) are fused into the 1x1x1 preprocess convs that consume them
+        size = tuple(s1.shape[2:])
         if self.downup_sample != 0:
-            size = [self.scale_dimension(s1.shape[2], self.scale), self.scale_dimension(s1.shape[3], self.scale),
-                    self.scale_dimension(s1.shape[4], self.scale)]
-            s1 = ops.trilinear3d(s1, size, True)
-        if tuple(s0.shape[2:]) != tuple(s1.shape[2:]):
-            s0 = ops.trilinear3d(s0, s1.shape[2:], True)
-        B, _, D, H, W = s1.shape
+            size = (self.scale_dimension(s1.shape[2], self.scale), self.scale_dimension(s1.shape[3], self.scale),
+                    self.scale_dimension(s1.shape[4], self.scale))
+        if s0.shape[1] == C and tuple(s0.shape[2:]) != size:
+            s0 = ops.trilinear3d(s0, size, True)     # no pre_preprocess to fuse into (never the case in Network)
+        B = s1.shape[0]
+        D, H, W = size
         dev = s1.device
 
         pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=torch.float32)
@@ -268,11 +282,11 @@ class Cell_3d(nn.Module):
         # (buffer, first channel) of every state
         where: List[Tuple[torch.Tensor, int]] = []
         if s0.shape[1] != C:
-            self.pre_preprocess(s0, out=pre, out_ch0=0)
+            self.pre_preprocess(s0, out=pre, out_ch0=0, resample_to=size)
             where.append((pre, 0))
         else:
             where.append((s0.contiguous(), 0))
-        self.preprocess(s1, out=pre, out_ch0=C)
+        self.preprocess(s1, out=pre, out_ch0=C, resample_to=size)
         where.append((pre, C))
         for k in range(2, n_states):
             where.append((cat, (k - first_cat) * C) if k >= first_cat else (scratch, (k - 2) * C))
@@ -456,8 +470,9 @@ class MatchingNet(nn.Module):
             y = ops.trilinear3d(self.last_6_3d[i6](last_output), (d, h, w), True)
             return self.last_3_3d[i3](y)
         if last_output.size()[3] == h // 4:
-            y = ops.trilinear3d(self.last_12_3d[i12](last_output), (d // 2, h // 2, w // 2), True)
-            y = ops.trilinear3d(self.last_6_3d[i6](y), (d, h, w), True)
+            # upsample_12 is fused into last_6_3d's 1x1x1 kernel; upsample_6 feeds a 3x3x3 conv and stays a kernel
+            y = self.last_6_3d[i6](self.last_12_3d[i12](last_output), resample_to=(d // 2, h // 2, w // 2))
+            y = ops.trilinear3d(y, (d, h, w), True)
             return self.last_3_3d[i3](y)
         # the reference reaches `return mat` with mat unbound here (UnboundLocalError)
         raise ValueError("MatchingNet: feature height must be a multiple of 4 (input H a multiple of 12)")

@@ -180,6 +180,24 @@ def conv3d_k1(x: torch.Tensor, weight2d: torch.Tensor, scale: Optional[torch.Ten
     return out
 
 
+def conv3d_k1_resample(x: torch.Tensor, size: Sequence[int], align_corners: bool, weight2d: torch.Tensor,
+                       scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool, out: torch.Tensor,
+                       out_ch0: int = 0) -> torch.Tensor:
+    """act(bn(conv1x1x1(F.interpolate(x, size, 'trilinear', align_corners)))) without materialising the resampled tensor."""
+    _need_gpu(x, weight2d, scale, shift, out)
+    B, Cin, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = [int(v) for v in size]
+    Cout = weight2d.shape[0]
+    if out_ch0 + Cout > out.shape[1] or tuple(out.shape[2:]) != (Do, Ho, Wo):
+        raise ValueError("conv3d_k1_resample: output buffer too small / wrong spatial size")
+    check(load_library().ragmi_conv3d_k1_resample_fwd(
+        x.data_ptr(), _planes(x), Di, Hi, Wi, weight2d.data_ptr(),
+        scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
+        out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, Do, Ho, Wo, int(bool(align_corners)), F32, _stream()),
+        "conv3d_k1_resample")
+    return out
+
+
 def trilinear3d(x: torch.Tensor, size: Sequence[int], align_corners: bool) -> torch.Tensor:
     """F.interpolate(x, size, mode='trilinear', align_corners=...) for x[B,C,D,H,W]."""
     _need_gpu(x)

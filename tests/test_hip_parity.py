@@ -221,6 +221,22 @@ def test_trilinear_vs_aten(ra, align, shape, size):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout,shape,size", [(12, 8, (2, 8, 12, 20), (4, 6, 10)), (24, 16, (1, 7, 9, 13), (4, 5, 7)),
+                                                 (48, 8, (1, 3, 4, 5), (6, 8, 10)), (48, 24, (1, 4, 8, 26), (8, 16, 52)),
+                                                 (12, 4, (1, 64, 32, 104), (32, 16, 52))])
+def test_conv3d_k1_resample_vs_aten(ra, cin, cout, shape, size):
+    """Fused trilinear(align_corners=True) + 1x1x1 ConvBR vs F.interpolate -> conv -> affine -> relu."""
+    x = torch.randn((shape[0], cin) + shape[1:], generator=gen(40))
+    w = torch.randn((cout, cin, 1, 1, 1), generator=gen(41)) * (2.0 / cin) ** 0.5
+    scale, shift = torch.rand(cout, generator=gen(42)) + 0.5, torch.randn(cout, generator=gen(43)) * 0.1
+    ref = F.relu(F.conv3d(F.interpolate(x, size, mode="trilinear", align_corners=True), w) * scale.view(1, -1, 1, 1, 1)
+                 + shift.view(1, -1, 1, 1, 1))
+    out = torch.zeros((shape[0], cout + 2) + tuple(size), device=DEV)
+    ra.ops.conv3d_k1_resample(gpu(x), size, True, gpu(w.reshape(cout, cin)), gpu(scale), gpu(shift), True, out, 1)
+    np.testing.assert_allclose(out[:, 1:1 + cout].cpu().numpy(), ref.numpy(), **TOL)
+    assert float(out[:, :1].abs().max()) == 0.0 and float(out[:, 1 + cout:].abs().max()) == 0.0
+
+
 def test_add(ra):
     a, b = torch.randn((2, 6, 3, 5, 7), generator=gen(18)), torch.randn((2, 9, 3, 5, 7), generator=gen(19))
     out = torch.zeros((2, 8, 3, 5, 7), device=DEV)
@@ -263,7 +279,8 @@ def test_matchingnet_golden(ra, name):
         cost = net.cost_volume(lf, rf)
         mat = net.matching(cost, net.arch_init)
         disp = net(lf, rf)
-    np.testing.assert_allclose(mat.cpu().numpy(), g["mat"], rtol=1e-3, atol=1e-3)
+    # |mat| reaches 1e4-1e5 with seeded random weights: absolute tolerance scales with the tensor (fp32 cancellation)
+    np.testing.assert_allclose(mat.cpu().numpy(), g["mat"], rtol=1e-3, atol=2e-6 * float(np.abs(g["mat"]).max()))
     epe = O.epe(disp.cpu(), torch.from_numpy(g["disp"]))
     assert epe <= EPE_GATE, epe
     # random weights drive |cost| to 1e4-1e5, so softmin is almost an argmin: a few near-tie pixels may move
