@@ -84,6 +84,42 @@ int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride,
                         int dtype, void* stream);
 
 /*
+ * Consumer 1x1x1 ConvBR_3d fused into the producing 3x3x3 kernel's epilogue (a "tail"):
+ *   y_t[b, y_ch0 + j] = act(bn_t(sum_c W_t[j][c] * out[b, c]))       j < cout <= 4
+ * where out is the (activated, summed) result of the 3x3x3 call it is attached to.  This is how the level-3
+ * Cell_3d.pre_preprocess / preprocess convs (rag_model.py:125-126, 154-155) of the NEXT cells are computed by the
+ * stem / cell that produces their input, instead of as separate HBM-bound passes.  weight: raw [cout][Cout_main].
+ */
+typedef struct {
+  const void* weight;
+  const void* scale;   /* folded BN of the tail, or NULL/NULL */
+  const void* shift;
+  int32_t relu;
+  void* y;
+  int64_t y_bstride;
+  int32_t y_ch0;
+  int32_t cout;
+} ragmi_tail_t;
+
+/*
+ * ragmi_conv3d_k3_fwd / ragmi_conv3d_k3_dual_fwd with up to two tails.  store_main = 0 skips writing the 3x3x3
+ * result itself (only the tails consume it).  Tails need Cout in {4, 8, 12, 16} (all channels in one workgroup).
+ */
+int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride,
+                           const void* packed_weight, const void* scale, const void* shift, int relu,
+                           void* y, int64_t y_bstride, const int32_t* y_group_ch,
+                           const void* res, int64_t res_bstride, const int32_t* res_group_ch,
+                           int B, int Cin, int Cout, int D, int H, int W,
+                           int store_main, int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
+int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride,
+                                int CinA, const void* packedA, const void* scaleA, const void* shiftA,
+                                int CinB, const void* packedB, const void* scaleB, const void* shiftB,
+                                int relu, void* y, int64_t y_bstride, const int32_t* y_group_ch,
+                                const void* res, int64_t res_bstride, const int32_t* res_group_ch,
+                                int B, int Cout, int D, int H, int W,
+                                int store_main, int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
+
+/*
  * Same operation as ragmi_conv3d_k3_fwd for Cout <= 2 (last_3_3d: 12 -> 1, rag_model.py:269), computed with
  * v_fma and wave-uniform weights instead of MFMA (a 4-row MFMA tile would idle 3 rows at Cout = 1).
  * `weight` is the RAW nn.Conv3d weight [Cout, Cin, 3, 3, 3]; Cin must be a multiple of 4.

@@ -10,6 +10,14 @@ _LOCK = threading.Lock()
 c_void_p, c_int, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
+class TailSpec(ctypes.Structure):
+    """ragmi_tail_t of include/rag_amd.h: a consumer 1x1x1 ConvBR_3d fused into a 3x3x3 kernel's epilogue."""
+    _fields_ = [("weight", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("relu", ctypes.c_int32),
+                ("y", c_void_p), ("y_bstride", c_int64), ("y_ch0", ctypes.c_int32), ("cout", ctypes.c_int32)]
+
+
+c_tail_p = ctypes.POINTER(TailSpec)
+
 # name -> (restype, argtypes); mirrors include/rag_amd.h one-to-one
 SIGNATURES = {
     "ragmi_version": (c_int, []),
@@ -25,6 +33,13 @@ SIGNATURES = {
     "ragmi_conv3d_k3_dual_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int32_p,
                                          c_void_p, c_int64, c_int32_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k3_fwd_ex": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_int64, c_int32_p, c_void_p, c_int64, c_int32_p,
+                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_tail_p, c_int, c_void_p]),
+    "ragmi_conv3d_k3_dual_fwd_ex": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int32_p,
+                                            c_void_p, c_int64, c_int32_p, c_int, c_int, c_int, c_int, c_int,
+                                            c_int, c_int, c_tail_p, c_int, c_void_p]),
     "ragmi_conv3d_k3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int32_p, c_int32_p, c_int32_p, c_int]),
     "ragmi_conv3d_k1_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),

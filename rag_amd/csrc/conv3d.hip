@@ -71,6 +71,29 @@ static int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int
   return RAGMI_OK;
 }
 
+static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* tails, int Cout) {
+  a.store_main = 1;
+  a.ntail = 0;
+  if (ntail == 0 && store_main) return RAGMI_OK;
+  RAGMI_REQUIRE(ntail >= 0 && ntail <= 2 && (ntail == 0 || tails != nullptr), RAGMI_EINVAL, "conv3d_k3: 0..2 tails");
+  RAGMI_REQUIRE(ntail > 0 || store_main, RAGMI_EINVAL, "conv3d_k3: store_main = 0 needs at least one tail");
+  const int ngroups = (Cout + 3) / 4;
+  RAGMI_REQUIRE(ntail == 0 || (Cout % 4 == 0 && Cout <= 16 && split_groups(ngroups) == ngroups), RAGMI_EUNSUPPORTED,
+                "conv3d_k3: fused tails need Cout in {4, 8, 12, 16} handled by one workgroup (got %d)", Cout);
+  for (int t = 0; t < ntail; ++t) {
+    RAGMI_REQUIRE(tails[t].weight && tails[t].y && tails[t].cout >= 1 && tails[t].cout <= 4 && tails[t].y_ch0 >= 0 &&
+                      ((tails[t].scale == nullptr) == (tails[t].shift == nullptr)),
+                  RAGMI_EINVAL, "conv3d_k3: bad tail %d (1..4 output channels)", t);
+    a.tail_w[t] = (const float*)tails[t].weight; a.tail_scale[t] = (const float*)tails[t].scale;
+    a.tail_shift[t] = (const float*)tails[t].shift; a.tail_y[t] = (float*)tails[t].y;
+    a.tail_bstride[t] = tails[t].y_bstride; a.tail_ch0[t] = tails[t].y_ch0; a.tail_cout[t] = tails[t].cout;
+    a.tail_relu[t] = tails[t].relu;
+  }
+  a.ntail = ntail;
+  a.store_main = store_main ? 1 : 0;
+  return RAGMI_OK;
+}
+
 }  // namespace ragmi
 
 extern "C" int64_t ragmi_conv3d_k3_packed_elems(int Cout, int Cin) {
@@ -94,6 +117,15 @@ extern "C" int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride, const void*
                                    const void* shift, int relu, void* y, int64_t y_bstride, const int32_t* y_group_ch,
                                    const void* res, int64_t res_bstride, const int32_t* res_group_ch, int B, int Cin,
                                    int Cout, int D, int H, int W, int dtype, void* stream) {
+  return ragmi_conv3d_k3_fwd_ex(x, x_bstride, packed_weight, scale, shift, relu, y, y_bstride, y_group_ch, res, res_bstride,
+                                res_group_ch, B, Cin, Cout, D, H, W, 1, 0, nullptr, dtype, stream);
+}
+
+extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const void* packed_weight, const void* scale,
+                                      const void* shift, int relu, void* y, int64_t y_bstride, const int32_t* y_group_ch,
+                                      const void* res, int64_t res_bstride, const int32_t* res_group_ch, int B, int Cin,
+                                      int Cout, int D, int H, int W, int store_main, int ntail, const ragmi_tail_t* tails,
+                                      int dtype, void* stream) {
   using namespace ragmi;
   RAGMI_REQUIRE(x && packed_weight && y, RAGMI_EINVAL, "conv3d_k3: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k3: scale/shift must both be given or both NULL");
@@ -103,6 +135,8 @@ extern "C" int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride, const void*
   if (rc != RAGMI_OK) return rc;
   a.wp[0] = (const float*)packed_weight; a.scale[0] = (const float*)scale; a.shift[0] = (const float*)shift;
   a.nchunks[0] = (Cin + CK - 1) / CK;
+  const int rt = fill_tails(a, store_main, ntail, tails, Cout);
+  if (rt != RAGMI_OK) return rt;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return launch_k3_s1_cfg0(a, (Cout + 3) / 4, s);
@@ -128,6 +162,7 @@ extern "C" int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const
   if (rc != RAGMI_OK) return rc;
   a.wp[0] = (const float*)weight; a.scale[0] = (const float*)scale; a.shift[0] = (const float*)shift;
   a.nchunks[0] = Cin / CK;
+  a.store_main = 1;
   return launch_k3_valu(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));
 }
 
@@ -137,6 +172,16 @@ extern "C" int ragmi_conv3d_k3_dual_fwd(const void* x, int64_t x_bstride, int Ci
                                         const int32_t* y_group_ch, const void* res, int64_t res_bstride,
                                         const int32_t* res_group_ch, int B, int Cout, int D, int H, int W, int dtype,
                                         void* stream) {
+  return ragmi_conv3d_k3_dual_fwd_ex(x, x_bstride, CinA, packedA, scaleA, shiftA, CinB, packedB, scaleB, shiftB, relu, y, y_bstride,
+                                     y_group_ch, res, res_bstride, res_group_ch, B, Cout, D, H, W, 1, 0, nullptr, dtype, stream);
+}
+
+extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int CinA, const void* packedA,
+                                           const void* scaleA, const void* shiftA, int CinB, const void* packedB,
+                                           const void* scaleB, const void* shiftB, int relu, void* y, int64_t y_bstride,
+                                           const int32_t* y_group_ch, const void* res, int64_t res_bstride,
+                                           const int32_t* res_group_ch, int B, int Cout, int D, int H, int W,
+                                           int store_main, int ntail, const ragmi_tail_t* tails, int dtype, void* stream) {
   using namespace ragmi;
   RAGMI_REQUIRE(x && packedA && packedB && y, RAGMI_EINVAL, "conv3d_k3_dual: null pointer");
   RAGMI_REQUIRE((scaleA == nullptr) == (shiftA == nullptr) && (scaleB == nullptr) == (shiftB == nullptr), RAGMI_EINVAL,
@@ -151,6 +196,8 @@ extern "C" int ragmi_conv3d_k3_dual_fwd(const void* x, int64_t x_bstride, int Ci
   a.wp[1] = (const float*)packedB; a.scale[1] = (const float*)scaleB; a.shift[1] = (const float*)shiftB;
   a.nchunks[0] = CinA / CK;
   a.nchunks[1] = (CinB + CK - 1) / CK;
+  const int rt = fill_tails(a, store_main, ntail, tails, Cout);
+  if (rt != RAGMI_OK) return rt;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return launch_k3_s2_cfg0(a, (Cout + 3) / 4, s);

@@ -44,6 +44,16 @@ struct K3Args {
   int nchunks[2];  // input-channel chunks feeding set 0, then set 1 (consecutive channels of x)
   int relu;
   int tiles_x, tiles_y, tiles_z;
+  // up to two consumer 1x1x1 ConvBR_3d fused into the epilogue ("tails"): y_t[j] = act(bn_t(sum_c W_t[j][c] * out[c])).
+  // Needs every output channel of a voxel in one lane: one split (gridDim.y == 1), Cout == 4*G <= 16, tail Cout <= 4.
+  int ntail;
+  int store_main;              // 0: the conv's own output is consumed only by the tails and is not written
+  const float* tail_w[2];      // [tail_cout][Cout] row-major
+  const float* tail_scale[2];
+  const float* tail_shift[2];
+  float* tail_y[2];
+  int64_t tail_bstride[2];
+  int tail_ch0[2], tail_cout[2], tail_relu[2];
   int w_in_lds;    // 1: the workgroup's weights (all chunks, both sets) are cached in LDS behind the tile
   int y_ch[RAGMI_MAX_GROUPS];    // destination channel base of each output group
   int res_ch[RAGMI_MAX_GROUPS];
@@ -102,6 +112,18 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     const bool ok = a.scale[s] != nullptr && co < a.Cout;
     bnp[s][0][j] = ok ? a.scale[s][co] : 1.f;   // identity affine when there is no BN: fma(x, 1, 0) == x exactly
     bnp[s][1][j] = ok ? a.shift[s][co] : 0.f;
+  }
+  // tail weights + folded BN, staged like bnp (alias-free reads in the epilogue)
+  __shared__ __attribute__((aligned(16))) float tailw[2][4][16];
+  __shared__ __attribute__((aligned(16))) float tailbn[2][2][4];
+  if (a.ntail > 0 && tid < 2 * 4 * 16) {
+    const int t = tid / 64, j = (tid / 16) % 4, c = tid % 16;
+    const bool ok = t < a.ntail && j < a.tail_cout[t] && c < a.Cout;
+    tailw[t][j][c] = ok ? a.tail_w[t][j * a.Cout + c] : 0.f;
+    if (c < 2) {
+      const bool okb = t < a.ntail && j < a.tail_cout[t] && a.tail_scale[t] != nullptr;
+      tailbn[t][c][j] = okb ? (c == 0 ? a.tail_scale[t][j] : a.tail_shift[t][j]) : (c == 0 ? 1.f : 0.f);
+    }
   }
   int ych[G], rch[G];
 #pragma unroll
@@ -223,6 +245,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   auto epilogue = [&](const TC& t, auto full_, auto res_) {
     constexpr bool FULL = decltype(full_)::value;
     constexpr bool RES = decltype(res_)::value;
+    constexpr int NM = VCO > 0 ? VCO : 4;   // channels of a group actually computed
     int b, x0, y0, z0;
     decode(t, b, x0, y0, z0);
     const int gz = z0 + wave, gx = x0 + xl, gy0 = y0 + ysub * R;
@@ -230,34 +253,35 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     const unsigned off0 = (unsigned)(gz * HW + gy0 * a.W + gx);
     float* yb = a.y + (int64_t)b * a.y_bstride;
     const float* rb = RES ? a.res + (int64_t)b * a.res_bstride : nullptr;
+    const bool tails = VCO == 0 && a.ntail > 0;
+    const bool store_main = a.store_main != 0;
+    // row-outer: only one output row's G*4 activated values are live at a time (they feed the tails)
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      f32x4 sc[NSET], sh[NSET];
+    for (int r = 0; r < R; ++r) {
+      if (!FULL && gy0 + r >= a.H) continue;
+      const unsigned off = off0 + (unsigned)(r * a.W);
+      float fin[G * 4];
+      float rv[G * 4];
+      if (RES) {   // residual loads of this row first, then the arithmetic and the stores
 #pragma unroll
-      for (int s = 0; s < NSET; ++s) {
-        sc[s] = *reinterpret_cast<const f32x4*>(&bnp[s][0][g * 4]);   // LDS broadcast reads
-        sh[s] = *reinterpret_cast<const f32x4*>(&bnp[s][1][g * 4]);
-      }
-      constexpr int NM = VCO > 0 ? VCO : 4;   // channels of this group actually computed
-      float rv[4][R];
-      if (RES) {   // all residual loads of this group first, then the arithmetic and the stores
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
-          const float* rc = rb + (int64_t)(rch[g] + m) * DHW;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const bool ok = FULL || ((gbase + g) * 4 + m < a.Cout && gy0 + r < a.H);
-            rv[m][r] = ok ? rc[off0 + (unsigned)(r * a.W)] : 0.f;
+          for (int m = 0; m < NM; ++m) {
+            const bool ok = FULL || (gbase + g) * 4 + m < a.Cout;
+            rv[g * 4 + m] = ok ? (rb + (int64_t)(rch[g] + m) * DHW)[off] : 0.f;
           }
-        }
       }
 #pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        if (!FULL && (gbase + g) * 4 + m >= a.Cout) continue;
-        float* yc = yb + (int64_t)(ych[g] + m) * DHW;   // wave-uniform base
+      for (int g = 0; g < G; ++g) {
+        f32x4 sc[NSET], sh[NSET];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if (!FULL && gy0 + r >= a.H) continue;
+        for (int s = 0; s < NSET; ++s) {
+          sc[s] = *reinterpret_cast<const f32x4*>(&bnp[s][0][g * 4]);   // LDS broadcast reads
+          sh[s] = *reinterpret_cast<const f32x4*>(&bnp[s][1][g * 4]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (m >= NM) { fin[g * 4 + m] = 0.f; continue; }
           float val = fmaf(acc[0][r][g][m], sc[0][m], sh[0][m]);
           if (do_relu) val = fmaxf(val, 0.f);
           if (NSET == 2) {
@@ -265,8 +289,35 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
             if (do_relu) v1 = fmaxf(v1, 0.f);
             val += v1;
           }
-          if (RES) val += rv[m][r];
-          if (!(a.relu & 0x100) || val == 12345.678f) yc[off0 + (unsigned)(r * a.W)] = val;   // DIAG: 0x100 skips stores
+          if (RES) val += rv[g * 4 + m];
+          fin[g * 4 + m] = val;
+          const bool ch_ok = FULL || (gbase + g) * 4 + m < a.Cout;
+          if (ch_ok && store_main && (!(a.relu & 0x100) || val == 12345.678f))   // (0x100: DIAG, skip stores)
+            (yb + (int64_t)(ych[g] + m) * DHW)[off] = val;
+        }
+      }
+      if (tails) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          if (tt >= a.ntail) break;
+          float* tb = a.tail_y[tt] + (int64_t)b * a.tail_bstride[tt] + (int64_t)a.tail_ch0[tt] * DHW;
+          const f32x4 tsc = *reinterpret_cast<const f32x4*>(&tailbn[tt][0][0]);
+          const f32x4 tsh = *reinterpret_cast<const f32x4*>(&tailbn[tt][1][0]);
+          const bool trelu = a.tail_relu[tt] != 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j >= a.tail_cout[tt]) break;
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const f32x4 w = *reinterpret_cast<const f32x4*>(&tailw[tt][j][g * 4]);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) sacc = fmaf(w[m], fin[g * 4 + m], sacc);
+            }
+            sacc = fmaf(sacc, tsc[j], tsh[j]);
+            if (trelu) sacc = fmaxf(sacc, 0.f);
+            (tb + (int64_t)j * DHW)[off] = sacc;
+          }
         }
       }
     }

@@ -117,8 +117,16 @@ class ConvBR_3d(nn.Module):
             self._cache = (stamp, wk, scale, shift)
         return self._cache[1], self._cache[2], self._cache[3]
 
+    def as_tail(self, out: torch.Tensor, out_ch0: int) -> "ops.Tail":
+        """This 1x1x1 ConvBR (<= 4 output channels) as a tail of the kernel that produces its input."""
+        if self._geometry() != 1 or self.conv.out_channels > 4:
+            raise ValueError("only 1x1x1 ConvBR_3d with <= 4 output channels can be fused as a tail")
+        wk, scale, shift = self.prepared()
+        return ops.Tail(wk, scale, shift, self.relu, out, out_ch0)
+
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_ch0: int = 0,
-                resample_to: Optional[Sequence[int]] = None) -> torch.Tensor:
+                resample_to: Optional[Sequence[int]] = None, tails: Optional[Sequence["ops.Tail"]] = None,
+                store_main: bool = True) -> torch.Tensor:
         """`out`/`out_ch0` write into a channel slice of a wider buffer.  `resample_to` (1x1x1 only) first resamples x
         trilinearly (align_corners=True) to that size inside the same kernel — the reference's
         `conv(F.interpolate(x, size, mode='trilinear', align_corners=True))`."""
@@ -140,7 +148,7 @@ class ConvBR_3d(nn.Module):
             ops.conv3d_k3_small(x, wk, scale, shift, self.relu, out, out_ch0)
         elif k == 3:
             groups = [out_ch0 + 4 * g for g in range(ops.packed_groups(cout))]
-            ops.conv3d_k3(x, wk, cout, scale, shift, self.relu, out, groups)
+            ops.conv3d_k3(x, wk, cout, scale, shift, self.relu, out, groups, tails=tails, store_main=store_main)
         else:
             ops.conv3d_k1(x, wk, scale, shift, self.relu, out, out_ch0)
         return out
@@ -255,6 +263,21 @@ class Cell_3d(nn.Module):
         return hit[1]
 
     def forward(self, prev_prev_input, prev_input):
+        concat_feature, _applied = self._run(prev_prev_input, prev_input)
+        return prev_input, concat_feature
+
+    def out_size(self, prev_size: Sequence[int]) -> Tuple[int, int, int]:
+        """Spatial size this cell works at (and outputs) given the size of prev_input."""
+        if self.downup_sample == 0:
+            return tuple(int(v) for v in prev_size)
+        return tuple(self.scale_dimension(int(v), self.scale) for v in prev_size)
+
+    def _run(self, prev_prev_input, prev_input, pre: Optional[torch.Tensor] = None, pre_has=(False, False),
+             tails: Optional[Sequence["ops.Tail"]] = None, store_main: bool = True, size: Optional[Sequence[int]] = None):
+        """forward() plus the cross-cell fusion hooks used by MatchingNet.matching:
+        `pre`/`pre_has`: the [B, 2C, ...] buffer in which the producers of the inputs have already written s0 (ch 0..C)
+        and/or s1 (ch C..2C) as fused tails; `tails`/`store_main`: consumer 1x1x1 convs to compute in THIS cell's final
+        conv launch (possible when one dual launch produces all new states).  Returns (concat or None, tails_applied)."""
         _require_inference(prev_prev_input, prev_input)
         C = self.C_out
         if C % 4 != 0 or self.block_multiplier > self._steps:
@@ -262,36 +285,48 @@ class Cell_3d(nn.Module):
                                       "block_multiplier <= steps (true for every cell the reference builds)")
         s0, s1 = prev_prev_input, prev_input
         # the trilinear resamples (rag_model.py:146-153) are fused into the 1x1x1 preprocess convs that consume them
-        size = tuple(s1.shape[2:])
-        if self.downup_sample != 0:
-            size = (self.scale_dimension(s1.shape[2], self.scale), self.scale_dimension(s1.shape[3], self.scale),
-                    self.scale_dimension(s1.shape[4], self.scale))
-        if s0.shape[1] == C and tuple(s0.shape[2:]) != size:
+        if size is None:
+            size = self.out_size(s1.shape[2:])
+        size = tuple(int(v) for v in size)
+        if not pre_has[0] and s0.shape[1] == C and tuple(s0.shape[2:]) != size:
             s0 = ops.trilinear3d(s0, size, True)     # no pre_preprocess to fuse into (never the case in Network)
-        B = s1.shape[0]
         D, H, W = size
-        dev = s1.device
-
-        pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=torch.float32)
+        if pre is None:
+            B, dev = s1.shape[0], s1.device
+            pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=torch.float32)
+        B, dev = pre.shape[0], pre.device
         n_states = 2 + self._steps
         first_cat = n_states - self.block_multiplier             # first state that lands in the concat buffer
-        cat = torch.empty((B, self.block_multiplier * C, D, H, W), device=dev, dtype=torch.float32)
+        tails_applied = False
+        contribs = self._contributions()
+        conv_from = {j: [(k, op) for k, lst in contribs.items() for (src, op) in lst
+                         if src == j and isinstance(op, ConvBR_3d)] for j in (0, 1)}
+        # one dual launch produces every new state <=> both inputs feed conv branches into all of them and nothing else does
+        single_dual = (bool(conv_from[0]) and (pre_has[0] or s0.shape[1] != C) and [k for k, _ in conv_from[0]] == [k for k, _ in conv_from[1]]
+                       and all(len(contribs[k]) == 2 for k, _ in conv_from[0]) and len(conv_from[0]) == self._steps
+                       and self.block_multiplier == self._steps)
+        use_tails = bool(tails) and single_dual and C * self._steps <= 16
+        drop_main = use_tails and not store_main
+        cat = (pre if drop_main else   # placeholder pointer: nothing is stored when the output is only consumed by tails
+               torch.empty((B, self.block_multiplier * C, D, H, W), device=dev, dtype=torch.float32))
         scratch = (torch.empty((B, (first_cat - 2) * C, D, H, W), device=dev, dtype=torch.float32)
                    if first_cat > 2 else None)
 
         # (buffer, first channel) of every state
         where: List[Tuple[torch.Tensor, int]] = []
-        if s0.shape[1] != C:
+        if pre_has[0]:
+            where.append((pre, 0))                 # already written by the producer of prev_prev_input (fused tail)
+        elif s0.shape[1] != C:
             self.pre_preprocess(s0, out=pre, out_ch0=0, resample_to=size)
             where.append((pre, 0))
         else:
             where.append((s0.contiguous(), 0))
-        self.preprocess(s1, out=pre, out_ch0=C, resample_to=size)
+        if not pre_has[1]:
+            self.preprocess(s1, out=pre, out_ch0=C, resample_to=size)
         where.append((pre, C))
         for k in range(2, n_states):
             where.append((cat, (k - first_cat) * C) if k >= first_cat else (scratch, (k - 2) * C))
 
-        contribs = self._contributions()
         written = {k: False for k in contribs}
         pending_id = {k: [j for (j, op) in lst if not isinstance(op, ConvBR_3d)] for k, lst in contribs.items()}
         for k, lst in contribs.items():
@@ -319,8 +354,6 @@ class Cell_3d(nn.Module):
         # (e.g. the all-conv genotype): ONE dual-input launch computes relu(bn(conv(s0))) + relu(bn(conv(s1)))
         # for all of them, so the running sum never goes through HBM.
         done = set()
-        conv_from = {j: [(k, op) for k, lst in contribs.items() for (src, op) in lst
-                         if src == j and isinstance(op, ConvBR_3d)] for j in (0, 1)}
         if (conv_from[0] and where[0][0] is pre and [k for k, _ in conv_from[0]] == [k for k, _ in conv_from[1]]
                 and all(len(contribs[k]) == 2 and not pending_id[k] for k, _ in conv_from[0])
                 and len({id(where[k][0]) for k, _ in conv_from[0]}) == 1):
@@ -328,7 +361,9 @@ class Cell_3d(nn.Module):
             pb, sb, hb = self._fused([op for _k, op in conv_from[1]])
             groups = [where[k][1] + 4 * g for k, _op in conv_from[0] for g in range(C // 4)]
             ops.conv3d_k3_dual(pre, C, pa, sa, ha, pb, sb, hb, C * len(conv_from[0]), True,
-                               where[conv_from[0][0][0]][0], groups)
+                               where[conv_from[0][0][0]][0], groups,
+                               tails=tails if use_tails else None, store_main=not drop_main)
+            tails_applied = use_tails
             for j in (0, 1):
                 for k, op in conv_from[j]:
                     written[k] = True
@@ -383,8 +418,9 @@ class Cell_3d(nn.Module):
                                       res_buf, rg if res_buf is not None else None)
         for k in contribs:
             finalize(k)
-        concat_feature = cat
-        return prev_input, concat_feature
+        if tails_applied and drop_main:
+            return None, True          # the concat exists only inside the kernel: its consumers were the tails
+        return cat, tails_applied
 
 
 # Matching-Net macro architecture, src/models/rag_model.py:238-261:
@@ -441,26 +477,90 @@ class MatchingNet(nn.Module):
         def unit(name):
             return task_arch[name][0] if task_arch is not None else None
 
-        stem0 = self.stem3d0[unit("stem_3d0")](x)
-        stem1 = self.stem3d1[unit("stem_3d1")](stem0)
-        out = (stem0, stem1)
+        cells = []
         for i, cell in enumerate(self.cells_3d):
             arch_cell = None
             if task_arch is not None:
                 arch_cell = task_arch["cell_3d" + str(i)][0]
             elif path is not None:
                 arch_cell = path[i + 1]
-            out = cell[arch_cell](out[0], out[1])
-        return self._head(x, out[-1], unit("last_3_3d"), unit("last_6_3d"), unit("last_12_3d"))
+            cells.append(cell[arch_cell])
+        last = self._run_chain(x, self.stem3d0[unit("stem_3d0")], self.stem3d1[unit("stem_3d1")], cells)
+        return self._head(x, last, unit("last_3_3d"), unit("last_6_3d"), unit("last_12_3d"))
 
     # -- rag_model.py:663-685
     def search_matching(self, x, selected_ops, t):
-        stem0 = self.stem3d0[selected_ops[8]](x)
-        stem1 = self.stem3d1[selected_ops[9]](stem0)
-        out = (stem0, stem1)
-        for i, cell in enumerate(self.cells_3d):
-            out = cell[selected_ops[i + 10]](out[0], out[1])
-        return self._head(x, out[-1], t, t, t)
+        cells = [cell[selected_ops[i + 10]] for i, cell in enumerate(self.cells_3d)]
+        last = self._run_chain(x, self.stem3d0[selected_ops[8]], self.stem3d1[selected_ops[9]], cells)
+        return self._head(x, last, t, t, t)
+
+    def _run_chain(self, x, stem0, stem1, cells):
+        """stem3d0 -> stem3d1 -> cells (rag_model.py:341-351) with cross-module fusion: the 1x1x1 pre_preprocess /
+        preprocess conv of a cell that needs no resampling is computed in the epilogue of the kernel that PRODUCES its
+        input (a "tail"), and a tensor consumed only by tails is never written to HBM.  Tensors: T[-2] = stem0 output,
+        T[-1] = stem1 output, T[i] = output of cell i; cell i reads T[i-2] (prev_prev) and T[i-1] (prev)."""
+        n = len(cells)
+        sizes = {-2: tuple(x.shape[2:]), -1: tuple(x.shape[2:])}
+        for i, c in enumerate(cells):
+            sizes[i] = c.out_size(sizes[i - 1])
+        B, dev = x.shape[0], x.device
+
+        def fusable(i):
+            """consumers of T[i] that can ride on its producer: [(cell index j, role 0 = pre_preprocess / 1 = preprocess)]"""
+            out = []
+            j = i + 1
+            if 0 <= j < n and cells[j].downup_sample == 0 and cells[j].C_out <= 4 and cells[j].C_out % 4 == 0:
+                out.append((j, 1))
+            j = i + 2
+            if (0 <= j < n and cells[j].downup_sample == 0 and cells[j - 1].downup_sample == 0 and cells[j].C_out <= 4
+                    and cells[j].C_out % 4 == 0 and cells[j].C_prev_prev != cells[j].C_out):
+                out.append((j, 0))
+            return out
+
+        def all_consumers(i):
+            return [(j, r) for (j, r) in ((i + 1, 1), (i + 2, 0)) if 0 <= j < n]
+
+        pre: Dict[int, torch.Tensor] = {}
+        has: Dict[int, List[bool]] = {}
+
+        def tails_for(i):
+            specs = []
+            for (j, role) in fusable(i):
+                if j not in pre:
+                    pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=torch.float32)
+                    has[j] = [False, False]
+                mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
+                specs.append((j, role, mod.as_tail(pre[j], cells[j].C_out if role == 1 else 0)))
+            return specs
+
+        def settle(i, specs, applied, tensor):
+            """mark fused consumers as done, or run them as plain 1x1x1 launches if the producer could not fuse them"""
+            for (j, role, tail) in specs:
+                if not applied:
+                    mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
+                    mod(tensor, out=pre[j], out_ch0=tail.out_ch0)
+                has[j][role] = True
+
+        T: Dict[int, Optional[torch.Tensor]] = {}
+        # stem3d0: its output also feeds stem3d1 (3x3x3), so it is always materialised
+        specs = tails_for(-2)
+        T[-2] = stem0(x, tails=[s[2] for s in specs] or None)
+        settle(-2, specs, True, T[-2])
+        # stem3d1
+        specs = tails_for(-1)
+        need_main = len(specs) < len(all_consumers(-1)) or n == 0
+        out1 = stem1(T[-2], tails=[s[2] for s in specs] or None, store_main=need_main or not specs)
+        T[-1] = out1 if (need_main or not specs) else None
+        settle(-1, specs, True, out1)
+        for i, c in enumerate(cells):
+            specs = tails_for(i)
+            need_main = i == n - 1 or len(specs) < len(all_consumers(i))   # the head reads the last cell's output
+            cat, applied = c._run(T[i - 2], T[i - 1], pre=pre.get(i), pre_has=tuple(has.get(i, (False, False))),
+                                  tails=[s[2] for s in specs] or None, store_main=need_main, size=sizes[i])
+            settle(i, specs, applied, cat)
+            T[i] = cat
+            T.pop(i - 2, None)
+        return T[n - 1]
 
     def _head(self, x, last_output, i3, i6, i12):
         d, h, w = x.size()[2], x.size()[3], x.size()[4]

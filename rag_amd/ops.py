@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from ._lib import check, load_library
+from ._lib import TailSpec, check, load_library
 
 F32 = 0
 
@@ -45,6 +45,30 @@ def _i32_array(vals: Optional[Sequence[int]]):
     if vals is None:
         return None
     return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+class Tail:
+    """A consumer 1x1x1 ConvBR_3d to be computed in the producing 3x3x3 kernel's epilogue:
+    out[:, ch0:ch0+cout] = act(bn(weight2d @ producer_output)) (weight2d [cout <= 4, C_producer])."""
+
+    def __init__(self, weight2d: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool,
+                 out: torch.Tensor, out_ch0: int):
+        _need_gpu(weight2d, scale, shift, out)
+        self.weight2d, self.scale, self.shift, self.relu, self.out, self.out_ch0 = weight2d, scale, shift, relu, out, out_ch0
+
+    def spec(self) -> TailSpec:
+        p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        return TailSpec(p(self.weight2d), p(self.scale), p(self.shift), int(self.relu), self.out.data_ptr(),
+                        _planes(self.out), int(self.out_ch0), int(self.weight2d.shape[0]))
+
+
+def _tail_array(tails: Optional[Sequence["Tail"]]):
+    if not tails:
+        return 0, None
+    if len(tails) > 2:
+        raise ValueError("at most two fused tails per conv launch")
+    arr = (TailSpec * len(tails))(*[t.spec() for t in tails])
+    return len(tails), arr
 
 
 def costvol(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -93,7 +117,8 @@ def packed_groups(cout: int) -> int:
 
 def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
               relu: bool, out: torch.Tensor, out_group_ch: Optional[Sequence[int]] = None,
-              res: Optional[torch.Tensor] = None, res_group_ch: Optional[Sequence[int]] = None) -> torch.Tensor:
+              res: Optional[torch.Tensor] = None, res_group_ch: Optional[Sequence[int]] = None,
+              tails: Optional[Sequence[Tail]] = None, store_main: bool = True) -> torch.Tensor:
     """Fused 3x3x3 ConvBR_3d (+ running sum / concat): see ragmi_conv3d_k3_fwd in include/rag_amd.h.
     `out` (and `res`) are [B, C*, D, H, W] buffers; group g of 4 output channels lands at channel
     out_group_ch[g] (default 4g)."""
@@ -112,12 +137,13 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
     max_ch = max(out_group_ch) + 4 if out_group_ch is not None else cout
     if max_ch > out.shape[1] + (3 if cout % 4 else 0):
         raise ValueError("conv3d_k3: destination channels exceed the output buffer")
-    check(load_library().ragmi_conv3d_k3_fwd(
+    ntail, tarr = _tail_array(tails)
+    check(load_library().ragmi_conv3d_k3_fwd_ex(
         x.data_ptr(), xb, packed.data_ptr(),
         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
         out.data_ptr(), yb, _i32_array(out_group_ch),
         res.data_ptr() if res is not None else None, rb, _i32_array(res_group_ch),
-        B, Cin, cout, D, H, W, F32, _stream()), "conv3d_k3")
+        B, Cin, cout, D, H, W, int(store_main), ntail, tarr, F32, _stream()), "conv3d_k3")
     return out
 
 
@@ -140,7 +166,8 @@ def conv3d_k3_small(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu: b
 def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a, shift_a,
                    packed_b: torch.Tensor, scale_b, shift_b, cout: int, relu: bool, out: torch.Tensor,
                    out_group_ch: Optional[Sequence[int]] = None, res: Optional[torch.Tensor] = None,
-                   res_group_ch: Optional[Sequence[int]] = None) -> torch.Tensor:
+                   res_group_ch: Optional[Sequence[int]] = None, tails: Optional[Sequence[Tail]] = None,
+                   store_main: bool = True) -> torch.Tensor:
     """Two sibling ConvBR_3d groups in one launch: out = act(bnA(convA(x[:, :cin_a]))) + act(bnB(convB(x[:, cin_a:])))
     (+ res): see ragmi_conv3d_k3_dual_fwd in include/rag_amd.h."""
     _need_gpu(x, packed_a, packed_b, scale_a, shift_a, scale_b, shift_b, out, res)
@@ -153,12 +180,13 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
     if tuple(out.shape[2:]) != (D, H, W) or out.shape[0] != B or not 0 < cin_a < Cx:
         raise ValueError("conv3d_k3_dual: bad shapes")
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    check(load_library().ragmi_conv3d_k3_dual_fwd(
+    ntail, tarr = _tail_array(tails)
+    check(load_library().ragmi_conv3d_k3_dual_fwd_ex(
         x.data_ptr(), _planes(x), cin_a, packed_a.data_ptr(), ptr(scale_a), ptr(shift_a),
         Cx - cin_a, packed_b.data_ptr(), ptr(scale_b), ptr(shift_b), int(relu),
         out.data_ptr(), _planes(out), _i32_array(out_group_ch),
         ptr(res), _planes(res) if res is not None else 0, _i32_array(res_group_ch),
-        B, cout, D, H, W, F32, _stream()), "conv3d_k3_dual")
+        B, cout, D, H, W, int(store_main), ntail, tarr, F32, _stream()), "conv3d_k3_dual")
     return out
 
 

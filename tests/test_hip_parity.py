@@ -181,6 +181,46 @@ def test_conv3d_k3_small_vs_oracle(ra, cin, cout, shape):
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), **TOL)
 
 
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("store_main", [True, False])
+@pytest.mark.parametrize("shape", [(1, 5, 9, 33), (2, 4, 8, 20), (1, 64, 16, 64)])
+def test_conv3d_k3_fused_tails_vs_oracle(ra, dual, store_main, shape):
+    """Consumer 1x1x1 ConvBRs computed in the producing 3x3x3 kernel's epilogue; optionally without storing the producer."""
+    B, D, H, W = shape
+    cout = 12
+    x = torch.randn((B, 8 if dual else 24, D, H, W), generator=gen(50))
+    v = lambda t_: t_.view(1, -1, 1, 1, 1)  # noqa: E731
+    sa, ha = torch.rand(cout, generator=gen(53)) + 0.5, torch.randn(cout, generator=gen(54)) * 0.1
+    if dual:
+        wa = torch.randn((cout, 4, 3, 3, 3), generator=gen(51)) * 0.1
+        wb = torch.randn((cout, 4, 3, 3, 3), generator=gen(52)) * 0.1
+        sb, hb = torch.rand(cout, generator=gen(55)) + 0.5, torch.randn(cout, generator=gen(56)) * 0.1
+        main = F.relu(F.conv3d(x[:, :4], wa, padding=1) * v(sa) + v(ha)) + F.relu(F.conv3d(x[:, 4:], wb, padding=1) * v(sb) + v(hb))
+    else:
+        wa = torch.randn((cout, 24, 3, 3, 3), generator=gen(51)) * 0.05
+        main = F.relu(F.conv3d(x, wa, padding=1) * v(sa) + v(ha))
+    tw = [torch.randn((4, cout), generator=gen(57)) * 0.3, torch.randn((3, cout), generator=gen(58)) * 0.3]
+    ts = [(torch.rand(4, generator=gen(59)) + 0.5, torch.randn(4, generator=gen(60)) * 0.1), (None, None)]
+    exp0 = F.relu(F.conv3d(main, tw[0].view(4, cout, 1, 1, 1)) * v(ts[0][0]) + v(ts[0][1]))
+    exp1 = F.conv3d(main, tw[1].view(3, cout, 1, 1, 1))
+    out = torch.full((B, cout, D, H, W), -7.0, device=DEV)
+    t0 = torch.zeros((B, 8, D, H, W), device=DEV)
+    t1 = torch.zeros((B, 5, D, H, W), device=DEV)
+    tails = [ra.ops.Tail(gpu(tw[0]), gpu(ts[0][0]), gpu(ts[0][1]), True, t0, 4), ra.ops.Tail(gpu(tw[1]), None, None, False, t1, 1)]
+    if dual:
+        ra.ops.conv3d_k3_dual(gpu(x), 4, ra.ops.conv3d_k3_pack(gpu(wa)), gpu(sa), gpu(ha), ra.ops.conv3d_k3_pack(gpu(wb)), gpu(sb),
+                              gpu(hb), cout, True, out, tails=tails, store_main=store_main)
+    else:
+        ra.ops.conv3d_k3(gpu(x), ra.ops.conv3d_k3_pack(gpu(wa)), cout, gpu(sa), gpu(ha), True, out, tails=tails, store_main=store_main)
+    if store_main:
+        np.testing.assert_allclose(out.cpu().numpy(), main.numpy(), **TOL)
+    else:
+        assert float((out + 7.0).abs().max()) == 0.0            # untouched
+    np.testing.assert_allclose(t0[:, 4:8].cpu().numpy(), exp0.numpy(), **TOL)
+    np.testing.assert_allclose(t1[:, 1:4].cpu().numpy(), exp1.numpy(), **TOL)
+    assert float(t0[:, :4].abs().max()) == 0.0 and float(t1[:, :1].abs().max()) == 0.0 and float(t1[:, 4:].abs().max()) == 0.0
+
+
 def test_conv3d_linearity_full_size(ra):
     """Size-independent property at the headline level-3 shape: conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
     D, H, W = 64, 128, 416
