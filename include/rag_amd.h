@@ -179,6 +179,24 @@ int ragmi_conv3d_k1_resample_fwd(const void* x, int64_t x_bstride, int Di, int H
                                  int dtype, void* stream);
 
 /*
+ * Two such resample + 1x1x1 ConvBR_3d calls that write into the same buffer at the same output size (a cell's
+ * pre_preprocess and preprocess, each reading its own input at its own size) as ONE launch.
+ */
+typedef struct {
+  const void* x;
+  int64_t x_bstride;
+  int32_t Di, Hi, Wi;
+  const void* weight; /* [Cout][Cin] */
+  const void* scale;
+  const void* shift;
+  int32_t relu;
+  int32_t y_ch0;
+  int32_t Cin, Cout;
+} ragmi_k1r_t;
+int ragmi_conv3d_k1_resample_pair_fwd(const ragmi_k1r_t* a, const ragmi_k1r_t* b, void* y, int64_t y_bstride,
+                                      int B, int Do, int Ho, int Wo, int align_corners, int dtype, void* stream);
+
+/*
  * Trilinear resample, F.interpolate(mode='trilinear') with ATen's source-index
  * rule for align_corners = 1 (rag_model.py:150-153, 357-358) or 0.
  * x: [B, C, Di, Hi, Wi] -> y: [B, C, Do, Ho, Wo] (contiguous).

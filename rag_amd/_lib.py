@@ -18,6 +18,16 @@ class TailSpec(ctypes.Structure):
 
 c_tail_p = ctypes.POINTER(TailSpec)
 
+
+class K1RSpec(ctypes.Structure):
+    """ragmi_k1r_t of include/rag_amd.h: one resample + 1x1x1 ConvBR_3d of a paired launch."""
+    _fields_ = [("x", c_void_p), ("x_bstride", c_int64), ("Di", ctypes.c_int32), ("Hi", ctypes.c_int32), ("Wi", ctypes.c_int32),
+                ("weight", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("relu", ctypes.c_int32),
+                ("y_ch0", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32)]
+
+
+c_k1r_p = ctypes.POINTER(K1RSpec)
+
 # name -> (restype, argtypes); mirrors include/rag_amd.h one-to-one
 SIGNATURES = {
     "ragmi_version": (c_int, []),
@@ -45,6 +55,7 @@ SIGNATURES = {
                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "ragmi_conv3d_k1_resample_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                              c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k1_resample_pair_fwd": (c_int, [c_k1r_p, c_k1r_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_trilinear3d_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     "ragmi_add_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,

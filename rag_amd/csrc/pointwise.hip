@@ -89,14 +89,23 @@ struct K1RArgs {
   int align;
 };
 
+// up to two such convs that write into the same buffer at the same output size (a cell's pre_preprocess and
+// preprocess) run as ONE launch: blockIdx.z = conv * splits + output-channel slab
+struct K1RPair {
+  K1RArgs c[2];
+  int splits[2];
+};
+
 template <int NCO>
-__global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RArgs r) {
+__global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
+  const int which = (int)blockIdx.z >= pr.splits[0] ? 1 : 0;
+  K1RArgs& r = pr.c[which];
   K1Args& a = r.k;
   const int64_t ovol = (int64_t)r.Do * r.Ho * r.Wo;
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= ovol) return;
   const int b = blockIdx.y;
-  a.co0 = blockIdx.z * NCO;
+  a.co0 = ((int)blockIdx.z - (which ? pr.splits[0] : 0)) * NCO;
   const int ox = (int)(o % r.Wo);
   const int64_t t = o / r.Wo;
   const int oy = (int)(t % r.Ho), oz = (int)(t / r.Ho);
@@ -110,19 +119,30 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RArgs r) {
   float acc[NCO];
 #pragma unroll
   for (int j = 0; j < NCO; ++j) acc[j] = 0.f;
-#pragma unroll 2
-  for (int ci = 0; ci < a.Cin; ++ci) {
-    const float* pc = xp + ci * ivol;
-    const float v000 = pc[r00 + lx.i0], v001 = pc[r00 + lx.i1], v010 = pc[r01 + lx.i0], v011 = pc[r01 + lx.i1];
-    const float v100 = pc[r10 + lx.i0], v101 = pc[r10 + lx.i1], v110 = pc[r11 + lx.i0], v111 = pc[r11 + lx.i1];
-    const float a0 = ly.w0 * (lx.w0 * v000 + lx.w1 * v001) + ly.w1 * (lx.w0 * v010 + lx.w1 * v011);
-    const float a1 = ly.w0 * (lx.w0 * v100 + lx.w1 * v101) + ly.w1 * (lx.w0 * v110 + lx.w1 * v111);
-    const float xv = lz.w0 * a0 + lz.w1 * a1;
+  // U channels per trip: 8U independent gathers in flight before the first use (the kernel is latency-bound at the
+  // small volumes it runs on, so the number of dependent round trips is what matters)
+  constexpr int U = NCO <= 8 ? 8 : 4;
+  for (int c0 = 0; c0 < a.Cin; c0 += U) {
+    float tap[U][8];
 #pragma unroll
-    for (int j = 0; j < NCO; ++j) {
-      const int co = a.co0 + j;
-      const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
-      acc[j] = fmaf(wv, xv, acc[j]);
+    for (int u = 0; u < U; ++u) {
+      const float* pc = xp + (int64_t)min(c0 + u, a.Cin - 1) * ivol;
+      tap[u][0] = pc[r00 + lx.i0]; tap[u][1] = pc[r00 + lx.i1]; tap[u][2] = pc[r01 + lx.i0]; tap[u][3] = pc[r01 + lx.i1];
+      tap[u][4] = pc[r10 + lx.i0]; tap[u][5] = pc[r10 + lx.i1]; tap[u][6] = pc[r11 + lx.i0]; tap[u][7] = pc[r11 + lx.i1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u >= a.Cin) break;
+      const int ci = c0 + u;
+      const float a0 = ly.w0 * (lx.w0 * tap[u][0] + lx.w1 * tap[u][1]) + ly.w1 * (lx.w0 * tap[u][2] + lx.w1 * tap[u][3]);
+      const float a1 = ly.w0 * (lx.w0 * tap[u][4] + lx.w1 * tap[u][5]) + ly.w1 * (lx.w0 * tap[u][6] + lx.w1 * tap[u][7]);
+      const float xv = lz.w0 * a0 + lz.w1 * a1;
+#pragma unroll
+      for (int j = 0; j < NCO; ++j) {
+        const int co = a.co0 + j;
+        const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
+        acc[j] = fmaf(wv, xv, acc[j]);
+      }
     }
   }
   float* yp = a.y + b * a.y_bstride + o;
@@ -136,10 +156,56 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RArgs r) {
 }
 
 template <int NCO>
-static void launch_k1r_nco(const K1RArgs& r, int B, hipStream_t s) {
-  const int64_t ovol = (int64_t)r.Do * r.Ho * r.Wo;
-  dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)ceil_div(r.k.Cout, NCO));
-  hipLaunchKernelGGL((conv_k1_resample_kernel<NCO>), grid, dim3(256), 0, s, r);
+static void launch_k1r_nco(const K1RArgs* r, int n, int B, hipStream_t s) {
+  const int64_t ovol = (int64_t)r[0].Do * r[0].Ho * r[0].Wo;
+  K1RPair pr{};
+  pr.c[0] = r[0];
+  pr.c[1] = r[n - 1];
+  pr.splits[0] = (int)ceil_div(r[0].k.Cout, NCO);
+  pr.splits[1] = n == 2 ? (int)ceil_div(r[1].k.Cout, NCO) : 0;
+  dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)(pr.splits[0] + pr.splits[1]));
+  hipLaunchKernelGGL((conv_k1_resample_kernel<NCO>), grid, dim3(256), 0, s, pr);
+}
+
+static int fill_k1r(K1RArgs& r, const void* x, int64_t x_bstride, int Di, int Hi, int Wi, const void* weight, const void* scale,
+                    const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0, int B, int Cin, int Cout, int Do, int Ho,
+                    int Wo, int align_corners) {
+  RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k1_resample: null pointer");
+  RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1_resample: scale/shift must both be given or both NULL");
+  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && y_ch0 >= 0, RAGMI_EINVAL,
+                "conv3d_k1_resample: bad size");
+  RAGMI_REQUIRE(B <= 65535 && (int64_t)Di * Hi * Wi < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: size too large");
+  r.k = K1Args{(const float*)x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
+               (float*)y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu};
+  r.Di = Di; r.Hi = Hi; r.Wi = Wi; r.Do = Do; r.Ho = Ho; r.Wo = Wo;
+  r.sd = lin_scale(Di, Do, align_corners); r.sh = lin_scale(Hi, Ho, align_corners); r.sw = lin_scale(Wi, Wo, align_corners);
+  r.align = align_corners ? 1 : 0;
+  return RAGMI_OK;
+}
+
+static int launch_k1r(const K1RArgs* r, int n, int B, hipStream_t s) {
+  // slab width: same policy as the plain kernel (one voxel per thread here)
+  const int cmax = n == 2 ? (r[0].k.Cout > r[1].k.Cout ? r[0].k.Cout : r[1].k.Cout) : r[0].k.Cout;
+  const int64_t threads = (int64_t)B * r[0].Do * r[0].Ho * r[0].Wo * n, want = 256 * 256 * 2;
+  static const int widths[5] = {24, 16, 12, 8, 4};
+  int cover = 24;
+  for (int w : widths)
+    if (w >= cmax) cover = w;
+  int nco = 4;
+  if (threads >= want) {
+    nco = cover;
+  } else {
+    for (int w : widths)
+      if (w <= cover && threads * ceil_div(cmax, w) >= want) { nco = w; break; }
+  }
+  switch (nco) {
+    case 24: launch_k1r_nco<24>(r, n, B, s); break;
+    case 16: launch_k1r_nco<16>(r, n, B, s); break;
+    case 12: launch_k1r_nco<12>(r, n, B, s); break;
+    case 8: launch_k1r_nco<8>(r, n, B, s); break;
+    default: launch_k1r_nco<4>(r, n, B, s); break;
+  }
+  return check_launch("conv3d_k1_resample");
 }
 
 template <bool VEC>
@@ -220,40 +286,26 @@ extern "C" int ragmi_conv3d_k1_resample_fwd(const void* x, int64_t x_bstride, in
                                             int y_ch0, int B, int Cin, int Cout, int Do, int Ho, int Wo, int align_corners,
                                             int dtype, void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k1_resample: null pointer");
-  RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1_resample: scale/shift must both be given or both NULL");
-  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && y_ch0 >= 0, RAGMI_EINVAL,
-                "conv3d_k1_resample: bad size");
   RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k1_resample: dtype %d not built", dtype);
-  RAGMI_REQUIRE(B <= 65535 && (int64_t)Di * Hi * Wi < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: size too large");
   K1RArgs r{};
-  r.k = K1Args{(const float*)x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
-               (float*)y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu};
-  r.Di = Di; r.Hi = Hi; r.Wi = Wi; r.Do = Do; r.Ho = Ho; r.Wo = Wo;
-  r.sd = lin_scale(Di, Do, align_corners); r.sh = lin_scale(Hi, Ho, align_corners); r.sw = lin_scale(Wi, Wo, align_corners);
-  r.align = align_corners ? 1 : 0;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  // slab width: same policy as the plain kernel (one voxel per thread here)
-  const int64_t threads = (int64_t)B * Do * Ho * Wo, want = 256 * 256 * 2;
-  static const int widths[5] = {24, 16, 12, 8, 4};
-  int cover = 24;
-  for (int w : widths)
-    if (w >= Cout) cover = w;
-  int nco = 4;
-  if (threads >= want) {
-    nco = cover;
-  } else {
-    for (int w : widths)
-      if (w <= cover && threads * ceil_div(Cout, w) >= want) { nco = w; break; }
+  const int rc = fill_k1r(r, x, x_bstride, Di, Hi, Wi, weight, scale, shift, relu, y, y_bstride, y_ch0, B, Cin, Cout, Do, Ho, Wo, align_corners);
+  if (rc != RAGMI_OK) return rc;
+  return launch_k1r(&r, 1, B, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ragmi_conv3d_k1_resample_pair_fwd(const ragmi_k1r_t* a, const ragmi_k1r_t* b, void* y, int64_t y_bstride, int B,
+                                                 int Do, int Ho, int Wo, int align_corners, int dtype, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(a && b, RAGMI_EINVAL, "conv3d_k1_resample_pair: null descriptor");
+  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k1_resample_pair: dtype %d not built", dtype);
+  K1RArgs r[2]{};
+  const ragmi_k1r_t* d[2] = {a, b};
+  for (int i = 0; i < 2; ++i) {
+    const int rc = fill_k1r(r[i], d[i]->x, d[i]->x_bstride, d[i]->Di, d[i]->Hi, d[i]->Wi, d[i]->weight, d[i]->scale, d[i]->shift,
+                            d[i]->relu, y, y_bstride, d[i]->y_ch0, B, d[i]->Cin, d[i]->Cout, Do, Ho, Wo, align_corners);
+    if (rc != RAGMI_OK) return rc;
   }
-  switch (nco) {
-    case 24: launch_k1r_nco<24>(r, B, s); break;
-    case 16: launch_k1r_nco<16>(r, B, s); break;
-    case 12: launch_k1r_nco<12>(r, B, s); break;
-    case 8: launch_k1r_nco<8>(r, B, s); break;
-    default: launch_k1r_nco<4>(r, B, s); break;
-  }
-  return check_launch("conv3d_k1_resample");
+  return launch_k1r(r, 2, B, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ragmi_add_fwd(const void* a, int64_t a_bstride, int a_ch0, const void* b, int64_t b_bstride, int b_ch0,

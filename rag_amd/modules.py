@@ -314,15 +314,23 @@ class Cell_3d(nn.Module):
 
         # (buffer, first channel) of every state
         where: List[Tuple[torch.Tensor, int]] = []
-        if pre_has[0]:
-            where.append((pre, 0))                 # already written by the producer of prev_prev_input (fused tail)
-        elif s0.shape[1] != C:
-            self.pre_preprocess(s0, out=pre, out_ch0=0, resample_to=size)
+        if not pre_has[0] and not pre_has[1] and s0.shape[1] != C:
+            # both 1x1x1 convs (each with its own fused resample) as ONE launch
+            w0, sc0, sh0 = self.pre_preprocess.prepared()
+            w1, sc1, sh1 = self.preprocess.prepared()
+            ops.conv3d_k1_resample_pair([(s0, w0, sc0, sh0, self.pre_preprocess.relu, 0),
+                                         (s1, w1, sc1, sh1, self.preprocess.relu, C)], size, pre)
             where.append((pre, 0))
         else:
-            where.append((s0.contiguous(), 0))
-        if not pre_has[1]:
-            self.preprocess(s1, out=pre, out_ch0=C, resample_to=size)
+            if pre_has[0]:
+                where.append((pre, 0))             # already written by the producer of prev_prev_input (fused tail)
+            elif s0.shape[1] != C:
+                self.pre_preprocess(s0, out=pre, out_ch0=0, resample_to=size)
+                where.append((pre, 0))
+            else:
+                where.append((s0.contiguous(), 0))
+            if not pre_has[1]:
+                self.preprocess(s1, out=pre, out_ch0=C, resample_to=size)
         where.append((pre, C))
         for k in range(2, n_states):
             where.append((cat, (k - first_cat) * C) if k >= first_cat else (scratch, (k - 2) * C))

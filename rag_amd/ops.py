@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from ._lib import TailSpec, check, load_library
+from ._lib import K1RSpec, TailSpec, check, load_library
 
 F32 = 0
 
@@ -223,6 +223,26 @@ def conv3d_k1_resample(x: torch.Tensor, size: Sequence[int], align_corners: bool
         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
         out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, Do, Ho, Wo, int(bool(align_corners)), F32, _stream()),
         "conv3d_k1_resample")
+    return out
+
+
+def conv3d_k1_resample_pair(specs, size: Sequence[int], out: torch.Tensor) -> torch.Tensor:
+    """Two resample(align_corners=True) + 1x1x1 ConvBR_3d writing into `out` at the same output `size`, as one launch.
+    specs: two tuples (x, weight2d, scale, shift, relu, out_ch0)."""
+    arr = []
+    for (x, w2d, scale, shift, relu, ch0) in specs:
+        _need_gpu(x, w2d, scale, shift)
+        p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        arr.append(K1RSpec(x.data_ptr(), _planes(x), x.shape[2], x.shape[3], x.shape[4], w2d.data_ptr(), p(scale), p(shift),
+                           int(relu), int(ch0), x.shape[1], w2d.shape[0]))
+        if ch0 + w2d.shape[0] > out.shape[1]:
+            raise ValueError("conv3d_k1_resample_pair: output buffer too small")
+    _need_gpu(out)
+    Do, Ho, Wo = [int(v) for v in size]
+    if tuple(out.shape[2:]) != (Do, Ho, Wo):
+        raise ValueError("conv3d_k1_resample_pair: wrong output spatial size")
+    check(load_library().ragmi_conv3d_k1_resample_pair_fwd(ctypes.byref(arr[0]), ctypes.byref(arr[1]), out.data_ptr(), _planes(out),
+                                                           out.shape[0], Do, Ho, Wo, 1, F32, _stream()), "conv3d_k1_resample_pair")
     return out
 
 
