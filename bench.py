@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (configs[1]: 1)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a captured hipGraph")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="activation storage: f32 (configs[1], default) or bf16 storage / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -196,8 +198,9 @@ def main():
     net = build_net(device)
     B, h, w = args.batch, H // 3, W // 3
     g = torch.Generator().manual_seed(1234 + rank)
-    lf = torch.randn((B, FEA_C, h, w), generator=g).to(device)
-    rf = torch.randn((B, FEA_C, h, w), generator=g).to(device)
+    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    lf = torch.randn((B, FEA_C, h, w), generator=g).to(device).to(act)
+    rf = torch.randn((B, FEA_C, h, w), generator=g).to(device).to(act)
 
     prof = K3Profiler(rag_amd.ops)
 
@@ -259,7 +262,7 @@ def main():
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
         cpu = None
         if n_gpus == 1 and not args.no_cpu_baseline:
-            cpu, ref = cpu_baseline(net, lf, rf)
+            cpu, ref = cpu_baseline(net, lf.float(), rf.float())
             from oracle import matching_oracle as O
             epe = O.epe(out[:1].float().cpu(), ref)
             log(f"  EPE of the timed GPU path vs the CPU oracle on the same pair: {epe:.3e} px")
@@ -269,8 +272,9 @@ def main():
             "metric": "disparity maps/sec at 384x1248 D=192 (Matching-Net forward)",
             "value": round(n_gpus * B * args.steps / dt, 3), "unit": "disparity maps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, fp32, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
                        "global_batch": n_gpus * B, "sharding": "batch split, no collective",
                        "launch": "hipGraph" if graph is not None else "eager"},

@@ -19,7 +19,8 @@
  *    thread-local message for the last failure on this thread;
  *  - stateless and re-entrant; kernels are enqueued on the hipStream_t passed
  *    as `stream` (void*), never synchronise, never allocate device memory;
- *  - dtype: RAGMI_F32 = fp32 storage+math (fp32 MFMA, exact fmaf chains).
+ *  - dtype: RAGMI_F32 = fp32 storage+math (fp32 MFMA, exact fmaf chains); RAGMI_BF16 = bf16 activation storage
+ *    with the same fp32 on-chip math (BASELINE config 3); weights, scale/shift and the final disparity are fp32.
  */
 #ifndef RAG_AMD_H
 #define RAG_AMD_H
@@ -36,6 +37,7 @@ extern "C" {
 #define RAGMI_ELAUNCH (-3)      /* hipLaunch / runtime error */
 
 #define RAGMI_F32 0
+#define RAGMI_BF16 1 /* activations stored as bf16; fp32 on chip (LDS, MFMA, accumulate, BN); weights/BN stay fp32 */
 
 #define RAGMI_MAX_GROUPS 16 /* output-channel groups of 4 per conv call */
 

@@ -14,6 +14,47 @@ namespace ragmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Activation storage types.  RAGMI_F32: float.  RAGMI_BF16: bf16 in HBM (raw 16-bit), fp32 everywhere on chip
+// (LDS tiles, MFMA operands, accumulators, BN/ReLU) and rounded to nearest-even once, at the store.
+typedef unsigned short bf16_t;
+template <class T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return __uint_as_float((unsigned)(*p) << 16); }
+__device__ __forceinline__ bf16_t to_bf16(float v) {
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // keep a NaN a (quiet) NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+template <class T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = to_bf16(v); }
+// 4 consecutive elements (16 B of float / 8 B of bf16); pointer must be aligned to 4 elements
+template <class T> __device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <class T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  uint2 t;
+  t.x = (unsigned)to_bf16(v[0]) | ((unsigned)to_bf16(v[1]) << 16);
+  t.y = (unsigned)to_bf16(v[2]) | ((unsigned)to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+inline bool dtype_ok(int dtype) { return dtype == RAGMI_F32 || dtype == RAGMI_BF16; }
+inline size_t dtype_size(int dtype) { return dtype == RAGMI_BF16 ? 2 : 4; }
+// 4-element vector paths need the pointer aligned to 4 elements
+inline bool aligned4(const void* p, int dtype) { return (reinterpret_cast<uintptr_t>(p) & (4 * dtype_size(dtype) - 1)) == 0; }
+
 // thread-local last-error text, returned by ragmi_last_error()
 char* error_buffer();
 int fail(int code, const char* fmt, ...);

@@ -60,9 +60,9 @@ static int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int
   const int ngroups = (Cout + 3) / 4;
   RAGMI_REQUIRE(ngroups <= RAGMI_MAX_GROUPS, RAGMI_EUNSUPPORTED, "conv3d_k3: Cout %d > %d", Cout, 4 * RAGMI_MAX_GROUPS);
   RAGMI_REQUIRE((int64_t)D * H * W < (1ll << 30), RAGMI_EUNSUPPORTED, "conv3d_k3: volume too large (32-bit plane offsets)");
-  a.x = (const float*)x; a.x_bstride = x_bstride;
-  a.y = (float*)y; a.y_bstride = y_bstride;
-  a.res = (const float*)res; a.res_bstride = res_bstride;
+  a.x = x; a.x_bstride = x_bstride;
+  a.y = y; a.y_bstride = y_bstride;
+  a.res = res; a.res_bstride = res_bstride;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = relu;
   for (int g = 0; g < ngroups; ++g) {
     a.y_ch[g] = y_group_ch ? y_group_ch[g] : g * 4;
@@ -85,7 +85,7 @@ static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* 
                       ((tails[t].scale == nullptr) == (tails[t].shift == nullptr)),
                   RAGMI_EINVAL, "conv3d_k3: bad tail %d (1..4 output channels)", t);
     a.tail_w[t] = (const float*)tails[t].weight; a.tail_scale[t] = (const float*)tails[t].scale;
-    a.tail_shift[t] = (const float*)tails[t].shift; a.tail_y[t] = (float*)tails[t].y;
+    a.tail_shift[t] = (const float*)tails[t].shift; a.tail_y[t] = tails[t].y;
     a.tail_bstride[t] = tails[t].y_bstride; a.tail_ch0[t] = tails[t].y_ch0; a.tail_cout[t] = tails[t].cout;
     a.tail_relu[t] = tails[t].relu;
   }
@@ -129,7 +129,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   using namespace ragmi;
   RAGMI_REQUIRE(x && packed_weight && y, RAGMI_EINVAL, "conv3d_k3: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k3: scale/shift must both be given or both NULL");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3: dtype %d not built", dtype);
   K3Args a{};
   const int rc = fill_common(a, x, x_bstride, y, y_bstride, y_group_ch, res, res_bstride, res_group_ch, B, Cin, Cout, D, H, W, relu);
   if (rc != RAGMI_OK) return rc;
@@ -138,10 +138,12 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   const int rt = fill_tails(a, store_main, ntail, tails, Cout);
   if (rt != RAGMI_OK) return rt;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ng = (Cout + 3) / 4;
+  const bool bf = dtype == RAGMI_BF16;
   switch (choose_cfg(B, D, H, W)) {
-    case 0: return launch_k3_s1_cfg0(a, (Cout + 3) / 4, s);
-    case 1: return launch_k3_s1_cfg1(a, (Cout + 3) / 4, s);
-    default: return launch_k3_s1_cfg2(a, (Cout + 3) / 4, s);
+    case 0: return bf ? launch_k3_s1_cfg0_bf16(a, ng, s) : launch_k3_s1_cfg0_f32(a, ng, s);
+    case 1: return bf ? launch_k3_s1_cfg1_bf16(a, ng, s) : launch_k3_s1_cfg1_f32(a, ng, s);
+    default: return bf ? launch_k3_s1_cfg2_bf16(a, ng, s) : launch_k3_s1_cfg2_f32(a, ng, s);
   }
 }
 
@@ -152,7 +154,7 @@ extern "C" int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const
   using namespace ragmi;
   RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k3_small: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k3_small: scale/shift must both be given or both NULL");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3_small: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3_small: dtype %d not built", dtype);
   RAGMI_REQUIRE(Cout >= 1 && Cout <= 2 && Cin % CK == 0 && (size_t)Cout * Cin * 27 * sizeof(float) <= (size_t)K3_MAX_WLDS_BYTES,
                 RAGMI_EUNSUPPORTED, "conv3d_k3_small: needs Cout <= 2 and Cin a multiple of %d, <= %d (use ragmi_conv3d_k3_fwd otherwise)",
                 CK, K3_MAX_WLDS_BYTES / (2 * 27 * 4));
@@ -163,7 +165,8 @@ extern "C" int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const
   a.wp[0] = (const float*)weight; a.scale[0] = (const float*)scale; a.shift[0] = (const float*)shift;
   a.nchunks[0] = Cin / CK;
   a.store_main = 1;
-  return launch_k3_valu(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));
+  return dtype == RAGMI_BF16 ? launch_k3_valu_bf16(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream))
+                             : launch_k3_valu_f32(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ragmi_conv3d_k3_dual_fwd(const void* x, int64_t x_bstride, int CinA, const void* packedA,
@@ -186,7 +189,7 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   RAGMI_REQUIRE(x && packedA && packedB && y, RAGMI_EINVAL, "conv3d_k3_dual: null pointer");
   RAGMI_REQUIRE((scaleA == nullptr) == (shiftA == nullptr) && (scaleB == nullptr) == (shiftB == nullptr), RAGMI_EINVAL,
                 "conv3d_k3_dual: scale/shift must both be given or both NULL");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3_dual: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3_dual: dtype %d not built", dtype);
   RAGMI_REQUIRE(CinA > 0 && CinB > 0 && CinA % CK == 0, RAGMI_EINVAL,
                 "conv3d_k3_dual: CinA must be a positive multiple of %d (B's channels start on a chunk boundary)", CK);
   K3Args a{};
@@ -199,10 +202,12 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   const int rt = fill_tails(a, store_main, ntail, tails, Cout);
   if (rt != RAGMI_OK) return rt;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ng = (Cout + 3) / 4;
+  const bool bf = dtype == RAGMI_BF16;
   switch (choose_cfg(B, D, H, W)) {
-    case 0: return launch_k3_s2_cfg0(a, (Cout + 3) / 4, s);
-    case 1: return launch_k3_s2_cfg1(a, (Cout + 3) / 4, s);
-    default: return launch_k3_s2_cfg2(a, (Cout + 3) / 4, s);
+    case 0: return bf ? launch_k3_s2_cfg0_bf16(a, ng, s) : launch_k3_s2_cfg0_f32(a, ng, s);
+    case 1: return bf ? launch_k3_s2_cfg1_bf16(a, ng, s) : launch_k3_s2_cfg1_f32(a, ng, s);
+    default: return bf ? launch_k3_s2_cfg2_bf16(a, ng, s) : launch_k3_s2_cfg2_f32(a, ng, s);
   }
 }
 

@@ -31,14 +31,14 @@ constexpr int NVG = (NPAIR + 15) / 16;       // VGPRs per output group per chunk
 constexpr int PACK_PER_GC = NVG * 64;        // packed floats per (group, chunk) = 448
 
 struct K3Args {
-  const float* x;
+  const void* x;          // activations: float or bf16_t per the kernel's storage type T
   int64_t x_bstride;
   const float* wp[2];     // per accumulator set: packed [groups][nchunks[s]][NVG][64]
   const float* scale[2];  // per set, indexed by output channel
   const float* shift[2];
-  float* y;
+  void* y;
   int64_t y_bstride;
-  const float* res;
+  const void* res;
   int64_t res_bstride;
   int B, Cin, Cout, D, H, W;
   int nchunks[2];  // input-channel chunks feeding set 0, then set 1 (consecutive channels of x)
@@ -51,7 +51,7 @@ struct K3Args {
   const float* tail_w[2];      // [tail_cout][Cout] row-major
   const float* tail_scale[2];
   const float* tail_shift[2];
-  float* tail_y[2];
+  void* tail_y[2];
   int64_t tail_bstride[2];
   int tail_ch0[2], tail_cout[2], tail_relu[2];
   int w_in_lds;    // 1: the workgroup's weights (all chunks, both sets) are cached in LDS behind the tile
@@ -69,7 +69,10 @@ constexpr int K3_MAX_WLDS_BYTES = 36 * 1024;   // weight cache budget per workgr
 // VCO > 0 selects the VALU form for Cout = VCO <= 2 (last_3_3d has Cout = 1): a 4x4x1 MFMA would idle 3 of its
 // 4 rows there, while v_fma with wave-uniform (SGPR) weights does the same per-lane work at 2.5x the issue
 // rate.  Same tiles, staging pipeline and epilogue; a.wp[0] is then the RAW weight [Cout][Cin][27].
-template <int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
+//
+// T = activation storage type (float, or bf16_t for RAGMI_BF16): halo loads convert to fp32 on their way into LDS and
+// the epilogue rounds once at the store; LDS tile, MFMA operands, accumulators, BN and the tails are fp32 either way.
+template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
 __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   static_assert(VCO == 0 || (G == 1 && NSET == 1 && VCO <= 4), "VALU form: one output group, one set");
   constexpr int TX = 1 << LOG_TX;
@@ -170,14 +173,14 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   auto prefetch = [&](const TC& t, int chunk) {
     int b, x0, y0, z0;
     decode(t, b, x0, y0, z0);
-    const float* xb = a.x + (int64_t)b * a.x_bstride;
+    const T* xb = static_cast<const T*>(a.x) + (int64_t)b * a.x_bstride;
     if (SY == 1 && interior(t, chunk)) {
       const unsigned zx = (unsigned)((z0 - 1 + szz) * HW + x0 - 1 + sxx);   // the only per-lane quantity
-      const float* xr = xb + (int64_t)(chunk * CK) * DHW + (int64_t)(y0 - 1) * a.W;   // wave-uniform
+      const T* xr = xb + (int64_t)(chunk * CK) * DHW + (int64_t)(y0 - 1) * a.W;   // wave-uniform
 #pragma unroll
       for (int c = 0; c < CK; ++c)
 #pragma unroll
-        for (int k = 0; k < KY; ++k) st[c * KY + k] = (xr + (int64_t)c * DHW + (int64_t)k * a.W)[sactive ? zx : 0u];
+        for (int k = 0; k < KY; ++k) st[c * KY + k] = ld(xr + (int64_t)c * DHW + (int64_t)k * a.W + (sactive ? zx : 0u));
       return;
     }
     int gzc = min(max(z0 - 1 + szz, 0), a.D - 1), gxc = min(max(x0 - 1 + sxx, 0), a.W - 1);
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     const int gy0 = y0 - 1 + ssy;
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
-      const float* xc = xb + (int64_t)min(chunk * CK + c, a.Cin - 1) * DHW;   // wave-uniform base
+      const T* xc = xb + (int64_t)min(chunk * CK + c, a.Cin - 1) * DHW;   // wave-uniform base
 #pragma unroll
       for (int k = 0; k < KY; ++k) {
         const int gyc = min(max(gy0 + k * SY, 0), a.H - 1);
-        st[c * KY + k] = xc[(unsigned)(zx + gyc * a.W)];
+        st[c * KY + k] = ld(xc + (unsigned)(zx + gyc * a.W));
       }
     }
   };
@@ -251,8 +254,8 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     const int gz = z0 + wave, gx = x0 + xl, gy0 = y0 + ysub * R;
     if (!FULL && (gz >= a.D || gx >= a.W)) return;
     const unsigned off0 = (unsigned)(gz * HW + gy0 * a.W + gx);
-    float* yb = a.y + (int64_t)b * a.y_bstride;
-    const float* rb = RES ? a.res + (int64_t)b * a.res_bstride : nullptr;
+    T* yb = static_cast<T*>(a.y) + (int64_t)b * a.y_bstride;
+    const T* rb = RES ? static_cast<const T*>(a.res) + (int64_t)b * a.res_bstride : nullptr;
     const bool tails = VCO == 0 && a.ntail > 0;
     const bool store_main = a.store_main != 0;
     // row-outer: only one output row's G*4 activated values are live at a time (they feed the tails)
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
 #pragma unroll
           for (int m = 0; m < NM; ++m) {
             const bool ok = FULL || (gbase + g) * 4 + m < a.Cout;
-            rv[g * 4 + m] = ok ? (rb + (int64_t)(rch[g] + m) * DHW)[off] : 0.f;
+            rv[g * 4 + m] = ok ? ld(rb + (int64_t)(rch[g] + m) * DHW + off) : 0.f;
           }
       }
 #pragma unroll
@@ -293,14 +296,14 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
           fin[g * 4 + m] = val;
           const bool ch_ok = FULL || (gbase + g) * 4 + m < a.Cout;
           if (ch_ok && store_main && (!(a.relu & 0x100) || val == 12345.678f))   // (0x100: DIAG, skip stores)
-            (yb + (int64_t)(ych[g] + m) * DHW)[off] = val;
+            ragmi::st(yb + (int64_t)(ych[g] + m) * DHW + off, val);
         }
       }
       if (tails) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           if (tt >= a.ntail) break;
-          float* tb = a.tail_y[tt] + (int64_t)b * a.tail_bstride[tt] + (int64_t)a.tail_ch0[tt] * DHW;
+          T* tb = static_cast<T*>(a.tail_y[tt]) + (int64_t)b * a.tail_bstride[tt] + (int64_t)a.tail_ch0[tt] * DHW;
           const f32x4 tsc = *reinterpret_cast<const f32x4*>(&tailbn[tt][0][0]);
           const f32x4 tsh = *reinterpret_cast<const f32x4*>(&tailbn[tt][1][0]);
           const bool trelu = a.tail_relu[tt] != 0;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
             }
             sacc = fmaf(sacc, tsc[j], tsh[j]);
             if (trelu) sacc = fmaxf(sacc, 0.f);
-            (tb + (int64_t)j * DHW)[off] = sacc;
+            ragmi::st(tb + (int64_t)j * DHW + off, sacc);
           }
         }
       }
@@ -482,7 +485,7 @@ inline int split_groups(int ngroups) {
   return 1;
 }
 
-template <int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
+template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
 static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
   constexpr size_t tile_bytes = (size_t)CK * 6 * (TY + 2) * (TX + 2) * sizeof(float);
@@ -497,7 +500,7 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   const size_t lds = tile_bytes + (VCO > 0 ? (size_t)a.Cout * a.Cin * 27 * sizeof(float) : (a.w_in_lds ? wbytes : 0));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(tile_bytes + K3_MAX_WLDS_BYTES));
     attr_set = true;
   }
@@ -509,18 +512,18 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   for (int i = 0; i < ncached; ++i)
     if (cached_lds[i] == lds) slots = cached_slots[i];
   if (slots == 0) {
-    slots = persistent_slots(conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>, lds);
+    slots = persistent_slots(conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO>, lds);
     if (ncached < 8) { cached_lds[ncached] = lds; cached_slots[ncached] = slots; ++ncached; }
   }
   static const int occ_cap = [] { const char* e = getenv("RAGMI_K3_MAX_WG_PER_CU"); return e ? atoi(e) : 0; }();   // experiment
   if (occ_cap > 0) slots = std::min(slots, occ_cap * 256);
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
   if (gx >= 8) gx -= gx % 8;   // the XCD-aware schedule wants a multiple of 8 workgroups per split
-  hipLaunchKernelGGL((conv3d_k3_kernel<G, LOG_TX, R, NSET, WPS, VCO>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
 }
 
 // one tile configuration: sets the tile counts and launches with G = split_groups(ngroups)
-template <int LOG_TX, int R, int NSET, int WPS>
+template <class T, int LOG_TX, int R, int NSET, int WPS>
 static int launch_cfg(K3Args a, int ngroups, hipStream_t s) {
   constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
   a.tiles_x = (int)ceil_div(a.W, TX);
@@ -530,24 +533,29 @@ static int launch_cfg(K3Args a, int ngroups, hipStream_t s) {
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
   const int G = split_groups(ngroups), nsplits = ngroups / G;
   switch (G) {
-    case 1: launch_one<1, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
-    case 2: launch_one<2, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
-    case 3: launch_one<3, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
-    default: launch_one<4, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    case 1: launch_one<T, 1, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    case 2: launch_one<T, 2, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    case 3: launch_one<T, 3, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    default: launch_one<T, 4, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
   }
   return check_launch("conv3d_k3");
 }
 
-// instantiated one per translation unit (conv3d_k3_inst_*.hip) so the build parallelises
-int launch_k3_s1_cfg0(const K3Args& a, int ngroups, hipStream_t s);   // TX=32 R=4
-int launch_k3_s1_cfg1(const K3Args& a, int ngroups, hipStream_t s);   // TX=16 R=2
-int launch_k3_s1_cfg2(const K3Args& a, int ngroups, hipStream_t s);   // TX=8  R=1
-int launch_k3_s2_cfg0(const K3Args& a, int ngroups, hipStream_t s);   // dual, TX=32 R=4
-int launch_k3_s2_cfg1(const K3Args& a, int ngroups, hipStream_t s);
-int launch_k3_s2_cfg2(const K3Args& a, int ngroups, hipStream_t s);
-int launch_k3_valu(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights
+// instantiated one per translation unit (conv3d_k3_inst_*.hip, fp32 and bf16 storage) so the build parallelises
+#define RAGMI_K3_DECL(name) \
+  int launch_k3_##name##_f32(const K3Args& a, int ngroups, hipStream_t s); \
+  int launch_k3_##name##_bf16(const K3Args& a, int ngroups, hipStream_t s)
+RAGMI_K3_DECL(s1_cfg0);   // TX=32 R=4
+RAGMI_K3_DECL(s1_cfg1);   // TX=16 R=2
+RAGMI_K3_DECL(s1_cfg2);   // TX=8  R=1
+RAGMI_K3_DECL(s2_cfg0);   // dual, TX=32 R=2
+RAGMI_K3_DECL(s2_cfg1);
+RAGMI_K3_DECL(s2_cfg2);
+#undef RAGMI_K3_DECL
+int launch_k3_valu_f32(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights
+int launch_k3_valu_bf16(const K3Args& a, int cfg, hipStream_t s);
 
-template <int LOG_TX, int R, int VCO>
+template <class T, int LOG_TX, int R, int VCO>
 static int launch_cfg_valu(K3Args a, hipStream_t s) {
   constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
   a.tiles_x = (int)ceil_div(a.W, TX);
@@ -555,7 +563,7 @@ static int launch_cfg_valu(K3Args a, hipStream_t s) {
   a.tiles_z = (int)ceil_div(a.D, 4);
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
-  launch_one<1, LOG_TX, R, 1, 2, VCO>(a, ntiles, 1, s);
+  launch_one<T, 1, LOG_TX, R, 1, 2, VCO>(a, ntiles, 1, s);
   return check_launch("conv3d_k3_small");
 }
 

@@ -1,0 +1,6 @@
+// conv3d_k3 instantiation: f32 storage, x-tile 2^5, 2 rows/lane, 2 accumulator set(s)
+#include "conv3d_k3.h"
+
+namespace ragmi {
+int launch_k3_s2_cfg0_f32(const K3Args& a, int ngroups, hipStream_t s) { return launch_cfg<float, 5, 2, 2, 2>(a, ngroups, s); }
+}  // namespace ragmi

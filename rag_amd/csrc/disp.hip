@@ -11,12 +11,13 @@
 namespace ragmi {
 
 struct DispArgs {
-  const float* cost;  // [B, d, h, w]
+  const void* cost;   // [B, d, h, w], float or bf16_t
   float* out;         // [B, Ho, Wo]
   int d, h, w, maxdisp, Ho, Wo;
   float sd, sh, sw;
 };
 
+template <class T>
 __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
   const int64_t npix = (int64_t)a.Ho * a.Wo;
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -26,15 +27,15 @@ __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
   const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
   const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
   const int hw = a.h * a.w;
-  const float* base = a.cost + (int64_t)b * a.d * hw;
+  const T* base = static_cast<const T*>(a.cost) + (int64_t)b * a.d * hw;
   const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1;
   const int o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
   const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
   (void)w00; (void)w01; (void)w10; (void)w11;
 
   auto plane = [&](int z) -> float {  // bilinear sample of coarse plane z at (oy, ox); x innermost like ATen
-    const float* p = base + (int64_t)z * hw;
-    return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
+    const T* p = base + (int64_t)z * hw;
+    return ly.w0 * (lx.w0 * ld(p + o00) + lx.w1 * ld(p + o01)) + ly.w1 * (lx.w0 * ld(p + o10) + lx.w1 * ld(p + o11));
   };
 
   // Walk the fine disparities in order; the coarse pair (cz, cz+1) only ever moves forward, so each
@@ -65,15 +66,16 @@ __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
 }
 
 // standalone DisparityRegression: out = sum_d prob[:, d] * d
-__global__ __launch_bounds__(256) void disparity_regression_kernel(const float* __restrict__ prob, float* __restrict__ out,
+template <class T>
+__global__ __launch_bounds__(256) void disparity_regression_kernel(const T* __restrict__ prob, float* __restrict__ out,
                                                                   int D, int64_t hw) {
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= hw) return;
   const int b = blockIdx.y;
-  const float* p = prob + (int64_t)b * D * hw + o;
+  const T* p = prob + (int64_t)b * D * hw + o;
   float acc = 0.f;
 #pragma unroll 8
-  for (int dd = 0; dd < D; ++dd) acc = fmaf(p[(int64_t)dd * hw], (float)dd, acc);
+  for (int dd = 0; dd < D; ++dd) acc = fmaf(ld(p + (int64_t)dd * hw), (float)dd, acc);
   out[(int64_t)b * hw + o] = acc;
 }
 
@@ -85,12 +87,13 @@ extern "C" int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int
   RAGMI_REQUIRE(cost && out, RAGMI_EINVAL, "disp_softargmin: null pointer");
   RAGMI_REQUIRE(B > 0 && d > 0 && h > 0 && w > 0 && maxdisp > 0 && Ho > 0 && Wo > 0, RAGMI_EINVAL,
                 "disp_softargmin: non-positive size");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "disp_softargmin: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "disp_softargmin: dtype %d not built", dtype);
   RAGMI_REQUIRE(B <= 65535 && (int64_t)h * w < (1ll << 30), RAGMI_EUNSUPPORTED, "disp_softargmin: size too large");
-  DispArgs a{(const float*)cost, (float*)out, d, h, w, maxdisp, Ho, Wo,
+  DispArgs a{cost, (float*)out, d, h, w, maxdisp, Ho, Wo,
              lin_scale(d, maxdisp, 0), lin_scale(h, Ho, 0), lin_scale(w, Wo, 0)};
   dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), B);
-  hipLaunchKernelGGL(disp_softargmin_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_kernel<bf16_t>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(disp_softargmin_kernel<float>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("disp_softargmin");
 }
 
@@ -99,11 +102,13 @@ extern "C" int ragmi_disparity_regression_fwd(const void* prob, void* out, int B
   using namespace ragmi;
   RAGMI_REQUIRE(prob && out, RAGMI_EINVAL, "disparity_regression: null pointer");
   RAGMI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, RAGMI_EINVAL, "disparity_regression: non-positive size");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "disparity_regression: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "disparity_regression: dtype %d not built", dtype);
   RAGMI_REQUIRE(B <= 65535, RAGMI_EUNSUPPORTED, "disparity_regression: B too large");
   const int64_t hw = (int64_t)H * W;
   dim3 grid((unsigned)ceil_div(hw, 256), B);
-  hipLaunchKernelGGL(disparity_regression_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
-                     (const float*)prob, (float*)out, D, hw);
+  if (dtype == RAGMI_BF16)
+    hipLaunchKernelGGL(disparity_regression_kernel<bf16_t>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t*)prob, (float*)out, D, hw);
+  else
+    hipLaunchKernelGGL(disparity_regression_kernel<float>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)prob, (float*)out, D, hw);
   return check_launch("disparity_regression");
 }

@@ -11,12 +11,12 @@
 namespace ragmi {
 
 struct K1Args {
-  const float* x;
+  const void* x;   // activations: float or bf16_t, per the kernel's storage type
   int64_t x_bstride;
   const float* w;  // [Cout][Cin]
   const float* scale;
   const float* shift;
-  float* y;
+  void* y;
   int64_t y_bstride;
   int y_ch0;
   int Cin, Cout, co0;
@@ -24,14 +24,14 @@ struct K1Args {
   int relu;
 };
 
-template <int NCO, bool VEC>
+template <class T, int NCO, bool VEC>
 __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
   constexpr int V = VEC ? 4 : 1;
   const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= a.dhw) return;
   const int b = blockIdx.y;
   a.co0 = blockIdx.z * NCO;   // output-channel slab of this block
-  const float* xp = a.x + b * a.x_bstride + p;
+  const T* xp = static_cast<const T*>(a.x) + b * a.x_bstride + p;
   float acc[NCO][V];
 #pragma unroll
   for (int j = 0; j < NCO; ++j)
@@ -41,12 +41,10 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
 #pragma unroll 4
   for (int ci = 0; ci < a.Cin; ++ci) {
     float xv[V];
-    if (VEC) {
-      const float4 t = *reinterpret_cast<const float4*>(xp + (int64_t)ci * a.dhw);
-      xv[0] = t.x;
-      if (V > 1) { xv[1 % V] = t.y; xv[2 % V] = t.z; xv[3 % V] = t.w; }
+    if constexpr (VEC) {
+      ld4(xp + (int64_t)ci * a.dhw, xv);
     } else {
-      xv[0] = xp[(int64_t)ci * a.dhw];
+      xv[0] = ld(xp + (int64_t)ci * a.dhw);
     }
 #pragma unroll
     for (int j = 0; j < NCO; ++j) {
@@ -56,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
       for (int k = 0; k < V; ++k) acc[j][k] = fmaf(wv, xv[k], acc[j][k]);
     }
   }
-  float* yp = a.y + b * a.y_bstride + p;
+  T* yp = static_cast<T*>(a.y) + b * a.y_bstride + p;
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
     const int co = a.co0 + j;
@@ -69,11 +67,8 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
       float v = a.scale ? fmaf(acc[j][k], sc, sh) : acc[j][k];
       o[k] = a.relu ? fmaxf(v, 0.f) : v;
     }
-    float* dst = yp + (int64_t)(a.y_ch0 + co) * a.dhw;
-    if (VEC)
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1 % V], o[2 % V], o[3 % V]);
-    else
-      dst[0] = o[0];
+    T* dst = yp + (int64_t)(a.y_ch0 + co) * a.dhw;
+    if constexpr (VEC) st4(dst, o); else st(dst, o[0]);
   }
 }
 
@@ -96,7 +91,7 @@ struct K1RPair {
   int splits[2];
 };
 
-template <int NCO>
+template <class T, int NCO>
 __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
   const int which = (int)blockIdx.z >= pr.splits[0] ? 1 : 0;
   K1RArgs& r = pr.c[which];
@@ -115,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
   const int64_t ivol = (int64_t)r.Di * r.Hi * r.Wi;
   const int r00 = (lz.i0 * r.Hi + ly.i0) * r.Wi, r01 = (lz.i0 * r.Hi + ly.i1) * r.Wi;
   const int r10 = (lz.i1 * r.Hi + ly.i0) * r.Wi, r11 = (lz.i1 * r.Hi + ly.i1) * r.Wi;
-  const float* xp = a.x + b * a.x_bstride;
+  const T* xp = static_cast<const T*>(a.x) + b * a.x_bstride;
   float acc[NCO];
 #pragma unroll
   for (int j = 0; j < NCO; ++j) acc[j] = 0.f;
@@ -126,9 +121,9 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
     float tap[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* pc = xp + (int64_t)min(c0 + u, a.Cin - 1) * ivol;
-      tap[u][0] = pc[r00 + lx.i0]; tap[u][1] = pc[r00 + lx.i1]; tap[u][2] = pc[r01 + lx.i0]; tap[u][3] = pc[r01 + lx.i1];
-      tap[u][4] = pc[r10 + lx.i0]; tap[u][5] = pc[r10 + lx.i1]; tap[u][6] = pc[r11 + lx.i0]; tap[u][7] = pc[r11 + lx.i1];
+      const T* pc = xp + (int64_t)min(c0 + u, a.Cin - 1) * ivol;
+      tap[u][0] = ld(pc + r00 + lx.i0); tap[u][1] = ld(pc + r00 + lx.i1); tap[u][2] = ld(pc + r01 + lx.i0); tap[u][3] = ld(pc + r01 + lx.i1);
+      tap[u][4] = ld(pc + r10 + lx.i0); tap[u][5] = ld(pc + r10 + lx.i1); tap[u][6] = ld(pc + r11 + lx.i0); tap[u][7] = ld(pc + r11 + lx.i1);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -145,17 +140,17 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
       }
     }
   }
-  float* yp = a.y + b * a.y_bstride + o;
+  T* yp = static_cast<T*>(a.y) + b * a.y_bstride + o;
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
     const int co = a.co0 + j;
     if (co >= a.Cout) break;
     float v = a.scale ? fmaf(acc[j], a.scale[co], a.shift[co]) : acc[j];
-    yp[(int64_t)(a.y_ch0 + co) * ovol] = a.relu ? fmaxf(v, 0.f) : v;
+    st(yp + (int64_t)(a.y_ch0 + co) * ovol, a.relu ? fmaxf(v, 0.f) : v);
   }
 }
 
-template <int NCO>
+template <class T, int NCO>
 static void launch_k1r_nco(const K1RArgs* r, int n, int B, hipStream_t s) {
   const int64_t ovol = (int64_t)r[0].Do * r[0].Ho * r[0].Wo;
   K1RPair pr{};
@@ -164,7 +159,7 @@ static void launch_k1r_nco(const K1RArgs* r, int n, int B, hipStream_t s) {
   pr.splits[0] = (int)ceil_div(r[0].k.Cout, NCO);
   pr.splits[1] = n == 2 ? (int)ceil_div(r[1].k.Cout, NCO) : 0;
   dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)(pr.splits[0] + pr.splits[1]));
-  hipLaunchKernelGGL((conv_k1_resample_kernel<NCO>), grid, dim3(256), 0, s, pr);
+  hipLaunchKernelGGL((conv_k1_resample_kernel<T, NCO>), grid, dim3(256), 0, s, pr);
 }
 
 static int fill_k1r(K1RArgs& r, const void* x, int64_t x_bstride, int Di, int Hi, int Wi, const void* weight, const void* scale,
@@ -175,14 +170,15 @@ static int fill_k1r(K1RArgs& r, const void* x, int64_t x_bstride, int Di, int Hi
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && y_ch0 >= 0, RAGMI_EINVAL,
                 "conv3d_k1_resample: bad size");
   RAGMI_REQUIRE(B <= 65535 && (int64_t)Di * Hi * Wi < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: size too large");
-  r.k = K1Args{(const float*)x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
-               (float*)y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu};
+  r.k = K1Args{x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
+               y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu};
   r.Di = Di; r.Hi = Hi; r.Wi = Wi; r.Do = Do; r.Ho = Ho; r.Wo = Wo;
   r.sd = lin_scale(Di, Do, align_corners); r.sh = lin_scale(Hi, Ho, align_corners); r.sw = lin_scale(Wi, Wo, align_corners);
   r.align = align_corners ? 1 : 0;
   return RAGMI_OK;
 }
 
+template <class T>
 static int launch_k1r(const K1RArgs* r, int n, int B, hipStream_t s) {
   // slab width: same policy as the plain kernel (one voxel per thread here)
   const int cmax = n == 2 ? (r[0].k.Cout > r[1].k.Cout ? r[0].k.Cout : r[1].k.Cout) : r[0].k.Cout;
@@ -199,42 +195,45 @@ static int launch_k1r(const K1RArgs* r, int n, int B, hipStream_t s) {
       if (w <= cover && threads * ceil_div(cmax, w) >= want) { nco = w; break; }
   }
   switch (nco) {
-    case 24: launch_k1r_nco<24>(r, n, B, s); break;
-    case 16: launch_k1r_nco<16>(r, n, B, s); break;
-    case 12: launch_k1r_nco<12>(r, n, B, s); break;
-    case 8: launch_k1r_nco<8>(r, n, B, s); break;
-    default: launch_k1r_nco<4>(r, n, B, s); break;
+    case 24: launch_k1r_nco<T, 24>(r, n, B, s); break;
+    case 16: launch_k1r_nco<T, 16>(r, n, B, s); break;
+    case 12: launch_k1r_nco<T, 12>(r, n, B, s); break;
+    case 8: launch_k1r_nco<T, 8>(r, n, B, s); break;
+    default: launch_k1r_nco<T, 4>(r, n, B, s); break;
   }
   return check_launch("conv3d_k1_resample");
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, int64_t a_bs, const float* __restrict__ b,
-                                                  int64_t b_bs, float* __restrict__ y, int64_t y_bs, int64_t n) {
+template <class T, bool VEC>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, int64_t a_bs, const T* __restrict__ b,
+                                                  int64_t b_bs, T* __restrict__ y, int64_t y_bs, int64_t n) {
   constexpr int V = VEC ? 4 : 1;
   const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= n) return;
   const int bi = blockIdx.y;
-  if (VEC) {
-    const float4 u = *reinterpret_cast<const float4*>(a + bi * a_bs + p);
-    const float4 v = *reinterpret_cast<const float4*>(b + bi * b_bs + p);
-    *reinterpret_cast<float4*>(y + bi * y_bs + p) = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  if constexpr (VEC) {
+    float u[4], v[4], o[4];
+    ld4(a + bi * a_bs + p, u);
+    ld4(b + bi * b_bs + p, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = u[k] + v[k];
+    st4(y + bi * y_bs + p, o);
   } else {
-    y[bi * y_bs + p] = a[bi * a_bs + p] + b[bi * b_bs + p];
+    st(y + bi * y_bs + p, ld(a + bi * a_bs + p) + ld(b + bi * b_bs + p));
   }
 }
 
-template <int NCO, bool VEC>
+template <class T, int NCO, bool VEC>
 static void launch_k1_nco(const K1Args& a, int B, hipStream_t s) {
   constexpr int V = VEC ? 4 : 1;
   dim3 grid((unsigned)ceil_div(ceil_div(a.dhw, V), 256), B, (unsigned)ceil_div(a.Cout, NCO));
-  hipLaunchKernelGGL((conv_k1_kernel<NCO, VEC>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_k1_kernel<T, NCO, VEC>), grid, dim3(256), 0, s, a);
 }
 
 // Pick the widest output slab per thread that still leaves enough threads to fill the chip:
 // large volumes read the input once (NCO = Cout); tiny ones (level-12: 53k voxels) are latency-
 // bound, so they trade L2 re-reads of the input for parallelism (slabs of 4 on blockIdx.z).
-template <bool VEC>
+template <class T, bool VEC>
 static void launch_k1(const K1Args& a, int B, hipStream_t s) {
   constexpr int V = VEC ? 4 : 1;
   const int64_t threads = (int64_t)B * ceil_div(a.dhw, V);
@@ -251,11 +250,11 @@ static void launch_k1(const K1Args& a, int B, hipStream_t s) {
       if (w <= cover && threads * ceil_div(a.Cout, w) >= want) { nco = w; break; }
   }
   switch (nco) {
-    case 24: launch_k1_nco<24, VEC>(a, B, s); break;
-    case 16: launch_k1_nco<16, VEC>(a, B, s); break;
-    case 12: launch_k1_nco<12, VEC>(a, B, s); break;
-    case 8: launch_k1_nco<8, VEC>(a, B, s); break;
-    default: launch_k1_nco<4, VEC>(a, B, s); break;
+    case 24: launch_k1_nco<T, 24, VEC>(a, B, s); break;
+    case 16: launch_k1_nco<T, 16, VEC>(a, B, s); break;
+    case 12: launch_k1_nco<T, 12, VEC>(a, B, s); break;
+    case 8: launch_k1_nco<T, 8, VEC>(a, B, s); break;
+    default: launch_k1_nco<T, 4, VEC>(a, B, s); break;
   }
 }
 
@@ -268,16 +267,19 @@ extern "C" int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride, const void*
   RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k1: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1: scale/shift must both be given or both NULL");
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && DHW > 0 && y_ch0 >= 0, RAGMI_EINVAL, "conv3d_k1: bad size");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k1: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1: dtype %d not built", dtype);
   RAGMI_REQUIRE(B <= 65535 && Cout <= 4 * 65535, RAGMI_EUNSUPPORTED, "conv3d_k1: B or Cout too large");
-  K1Args a{(const float*)x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
-           (float*)y, y_bstride, y_ch0, Cin, Cout, 0, DHW, relu};
+  K1Args a{x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
+           y, y_bstride, y_ch0, Cin, Cout, 0, DHW, relu};
   // 16-B columns need alignment; small volumes use one voxel per thread for 4x the parallelism
-  const bool vec = (DHW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) &&
-                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+  const bool vec = (DHW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) && aligned4(x, dtype) && aligned4(y, dtype) &&
                    (int64_t)B * DHW >= (1 << 18);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (vec) launch_k1<true>(a, B, s); else launch_k1<false>(a, B, s);
+  if (dtype == RAGMI_BF16) {
+    if (vec) launch_k1<bf16_t, true>(a, B, s); else launch_k1<bf16_t, false>(a, B, s);
+  } else {
+    if (vec) launch_k1<float, true>(a, B, s); else launch_k1<float, false>(a, B, s);
+  }
   return check_launch("conv3d_k1");
 }
 
@@ -286,18 +288,19 @@ extern "C" int ragmi_conv3d_k1_resample_fwd(const void* x, int64_t x_bstride, in
                                             int y_ch0, int B, int Cin, int Cout, int Do, int Ho, int Wo, int align_corners,
                                             int dtype, void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k1_resample: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: dtype %d not built", dtype);
   K1RArgs r{};
   const int rc = fill_k1r(r, x, x_bstride, Di, Hi, Wi, weight, scale, shift, relu, y, y_bstride, y_ch0, B, Cin, Cout, Do, Ho, Wo, align_corners);
   if (rc != RAGMI_OK) return rc;
-  return launch_k1r(&r, 1, B, static_cast<hipStream_t>(stream));
+  return dtype == RAGMI_BF16 ? launch_k1r<bf16_t>(&r, 1, B, static_cast<hipStream_t>(stream))
+                             : launch_k1r<float>(&r, 1, B, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ragmi_conv3d_k1_resample_pair_fwd(const ragmi_k1r_t* a, const ragmi_k1r_t* b, void* y, int64_t y_bstride, int B,
                                                  int Do, int Ho, int Wo, int align_corners, int dtype, void* stream) {
   using namespace ragmi;
   RAGMI_REQUIRE(a && b, RAGMI_EINVAL, "conv3d_k1_resample_pair: null descriptor");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k1_resample_pair: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1_resample_pair: dtype %d not built", dtype);
   K1RArgs r[2]{};
   const ragmi_k1r_t* d[2] = {a, b};
   for (int i = 0; i < 2; ++i) {
@@ -305,7 +308,8 @@ extern "C" int ragmi_conv3d_k1_resample_pair_fwd(const ragmi_k1r_t* a, const rag
                             d[i]->relu, y, y_bstride, d[i]->y_ch0, B, d[i]->Cin, d[i]->Cout, Do, Ho, Wo, align_corners);
     if (rc != RAGMI_OK) return rc;
   }
-  return launch_k1r(r, 2, B, static_cast<hipStream_t>(stream));
+  return dtype == RAGMI_BF16 ? launch_k1r<bf16_t>(r, 2, B, static_cast<hipStream_t>(stream))
+                             : launch_k1r<float>(r, 2, B, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ragmi_add_fwd(const void* a, int64_t a_bstride, int a_ch0, const void* b, int64_t b_bstride, int b_ch0,
@@ -313,21 +317,25 @@ extern "C" int ragmi_add_fwd(const void* a, int64_t a_bstride, int a_ch0, const 
   using namespace ragmi;
   RAGMI_REQUIRE(a && b && y, RAGMI_EINVAL, "add: null pointer");
   RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && a_ch0 >= 0 && b_ch0 >= 0 && y_ch0 >= 0, RAGMI_EINVAL, "add: bad size");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "add: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "add: dtype %d not built", dtype);
   RAGMI_REQUIRE(B <= 65535, RAGMI_EUNSUPPORTED, "add: B too large");
-  const float* ap = (const float*)a + (int64_t)a_ch0 * DHW;
-  const float* bp = (const float*)b + (int64_t)b_ch0 * DHW;
-  float* yp = (float*)y + (int64_t)y_ch0 * DHW;
+  const size_t es = dtype_size(dtype);
+  const char* ap = (const char*)a + (int64_t)a_ch0 * DHW * es;
+  const char* bp = (const char*)b + (int64_t)b_ch0 * DHW * es;
+  char* yp = (char*)y + (int64_t)y_ch0 * DHW * es;
   const int64_t n = (int64_t)C * DHW;
   const bool vec = (n % 4 == 0) && (DHW % 4 == 0) && (a_bstride % 4 == 0) && (b_bstride % 4 == 0) && (y_bstride % 4 == 0) &&
-                   (((reinterpret_cast<uintptr_t>(ap) | reinterpret_cast<uintptr_t>(bp) | reinterpret_cast<uintptr_t>(yp)) & 15) == 0);
+                   aligned4(ap, dtype) && aligned4(bp, dtype) && aligned4(yp, dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (vec) {
-    dim3 grid((unsigned)ceil_div(n / 4, 256), B);
-    hipLaunchKernelGGL(add_kernel<true>, grid, dim3(256), 0, s, ap, a_bstride, bp, b_bstride, yp, y_bstride, n);
-  } else {
-    dim3 grid((unsigned)ceil_div(n, 256), B);
-    hipLaunchKernelGGL(add_kernel<false>, grid, dim3(256), 0, s, ap, a_bstride, bp, b_bstride, yp, y_bstride, n);
-  }
+  auto go = [&](auto tag) {
+    using T = decltype(tag);
+    if (vec)
+      hipLaunchKernelGGL((add_kernel<T, true>), dim3((unsigned)ceil_div(n / 4, 256), B), dim3(256), 0, s, (const T*)ap, a_bstride,
+                         (const T*)bp, b_bstride, (T*)yp, y_bstride, n);
+    else
+      hipLaunchKernelGGL((add_kernel<T, false>), dim3((unsigned)ceil_div(n, 256), B), dim3(256), 0, s, (const T*)ap, a_bstride,
+                         (const T*)bp, b_bstride, (T*)yp, y_bstride, n);
+  };
+  if (dtype == RAGMI_BF16) go(bf16_t{}); else go(float{});
   return check_launch("add");
 }

@@ -9,13 +9,14 @@
 namespace ragmi {
 
 struct ResampleArgs {
-  const float* x;
-  float* y;
+  const void* x;
+  void* y;
   int C, Di, Hi, Wi, Do, Ho, Wo;
   float sd, sh, sw;
   int align;
 };
 
+template <class T>
 __global__ __launch_bounds__(256) void trilinear_kernel(ResampleArgs a) {
   const int64_t ovol = (int64_t)a.Do * a.Ho * a.Wo;
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -31,19 +32,19 @@ __global__ __launch_bounds__(256) void trilinear_kernel(ResampleArgs a) {
   const int64_t ivol = (int64_t)a.Di * a.Hi * a.Wi;
   const int64_t r00 = ((int64_t)lz.i0 * a.Hi + ly.i0) * a.Wi, r01 = ((int64_t)lz.i0 * a.Hi + ly.i1) * a.Wi;
   const int64_t r10 = ((int64_t)lz.i1 * a.Hi + ly.i0) * a.Wi, r11 = ((int64_t)lz.i1 * a.Hi + ly.i1) * a.Wi;
-  const float* xp = a.x + (int64_t)b * a.C * ivol;
-  float* yp = a.y + (int64_t)b * a.C * ovol + o;
+  const T* xp = static_cast<const T*>(a.x) + (int64_t)b * a.C * ivol;
+  T* yp = static_cast<T*>(a.y) + (int64_t)b * a.C * ovol + o;
 #pragma unroll 2
   for (int c = 0; c < a.C; ++c) {
-    const float* pc = xp + c * ivol;
-    const float v000 = pc[r00 + lx.i0], v001 = pc[r00 + lx.i1];
-    const float v010 = pc[r01 + lx.i0], v011 = pc[r01 + lx.i1];
-    const float v100 = pc[r10 + lx.i0], v101 = pc[r10 + lx.i1];
-    const float v110 = pc[r11 + lx.i0], v111 = pc[r11 + lx.i1];
+    const T* pc = xp + c * ivol;
+    const float v000 = ld(pc + r00 + lx.i0), v001 = ld(pc + r00 + lx.i1);
+    const float v010 = ld(pc + r01 + lx.i0), v011 = ld(pc + r01 + lx.i1);
+    const float v100 = ld(pc + r10 + lx.i0), v101 = ld(pc + r10 + lx.i1);
+    const float v110 = ld(pc + r11 + lx.i0), v111 = ld(pc + r11 + lx.i1);
     // x innermost, then y, then z (ATen's cpu_upsample_linear nesting)
     const float a0 = ly.w0 * (lx.w0 * v000 + lx.w1 * v001) + ly.w1 * (lx.w0 * v010 + lx.w1 * v011);
     const float a1 = ly.w0 * (lx.w0 * v100 + lx.w1 * v101) + ly.w1 * (lx.w0 * v110 + lx.w1 * v111);
-    yp[c * ovol] = lz.w0 * a0 + lz.w1 * a1;
+    st(yp + c * ovol, lz.w0 * a0 + lz.w1 * a1);
   }
 }
 
@@ -55,13 +56,14 @@ extern "C" int ragmi_trilinear3d_fwd(const void* x, void* y, int B, int C, int D
   RAGMI_REQUIRE(x && y, RAGMI_EINVAL, "trilinear3d: null pointer");
   RAGMI_REQUIRE(B > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, RAGMI_EINVAL,
                 "trilinear3d: non-positive size");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "trilinear3d: dtype %d not built", dtype);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "trilinear3d: dtype %d not built", dtype);
   RAGMI_REQUIRE(B <= 65535, RAGMI_EUNSUPPORTED, "trilinear3d: B too large");
-  ResampleArgs a{(const float*)x, (float*)y, C, Di, Hi, Wi, Do, Ho, Wo,
+  ResampleArgs a{x, y, C, Di, Hi, Wi, Do, Ho, Wo,
                  lin_scale(Di, Do, align_corners), lin_scale(Hi, Ho, align_corners), lin_scale(Wi, Wo, align_corners),
                  align_corners ? 1 : 0};
   const int64_t ovol = (int64_t)Do * Ho * Wo;
   dim3 grid((unsigned)ceil_div(ovol, 256), B);
-  hipLaunchKernelGGL(trilinear_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  if (dtype == RAGMI_BF16) hipLaunchKernelGGL(trilinear_kernel<bf16_t>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(trilinear_kernel<float>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("trilinear3d");
 }

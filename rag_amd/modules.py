@@ -140,10 +140,10 @@ class ConvBR_3d(nn.Module):
             if k != 1:
                 raise NotImplementedError("ConvBR_3d: fused resample is built for the 1x1x1 form only")
             if out is None:
-                out = torch.empty((x.shape[0], cout) + tuple(int(v) for v in resample_to), device=x.device, dtype=torch.float32)
+                out = torch.empty((x.shape[0], cout) + tuple(int(v) for v in resample_to), device=x.device, dtype=x.dtype)
             return ops.conv3d_k1_resample(x, resample_to, True, wk, scale, shift, self.relu, out, out_ch0)
         if out is None:
-            out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+            out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
         if k == 3 and self._small():
             ops.conv3d_k3_small(x, wk, scale, shift, self.relu, out, out_ch0)
         elif k == 3:
@@ -293,8 +293,8 @@ class Cell_3d(nn.Module):
         D, H, W = size
         if pre is None:
             B, dev = s1.shape[0], s1.device
-            pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=torch.float32)
-        B, dev = pre.shape[0], pre.device
+            pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=s1.dtype)
+        B, dev, adt = pre.shape[0], pre.device, pre.dtype
         n_states = 2 + self._steps
         first_cat = n_states - self.block_multiplier             # first state that lands in the concat buffer
         tails_applied = False
@@ -308,8 +308,8 @@ class Cell_3d(nn.Module):
         use_tails = bool(tails) and single_dual and C * self._steps <= 16
         drop_main = use_tails and not store_main
         cat = (pre if drop_main else   # placeholder pointer: nothing is stored when the output is only consumed by tails
-               torch.empty((B, self.block_multiplier * C, D, H, W), device=dev, dtype=torch.float32))
-        scratch = (torch.empty((B, (first_cat - 2) * C, D, H, W), device=dev, dtype=torch.float32)
+               torch.empty((B, self.block_multiplier * C, D, H, W), device=dev, dtype=adt))
+        scratch = (torch.empty((B, (first_cat - 2) * C, D, H, W), device=dev, dtype=adt)
                    if first_cat > 2 else None)
 
         # (buffer, first channel) of every state
@@ -535,7 +535,7 @@ class MatchingNet(nn.Module):
             specs = []
             for (j, role) in fusable(i):
                 if j not in pre:
-                    pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=torch.float32)
+                    pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=x.dtype)
                     has[j] = [False, False]
                 mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
                 specs.append((j, role, mod.as_tail(pre[j], cells[j].C_out if role == 1 else 0)))

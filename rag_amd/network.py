@@ -139,6 +139,7 @@ class Network(MatchingNet):
         self.last_3_2d = nn.ModuleList([self._new_unit("last_3_2d", genotype)])
         # matching net (HIP)
         self._init_matching(genotype, maxdisp)
+        self.act_dtype = torch.float32   # torch.bfloat16: Matching-Net activations stored as bf16 (BASELINE config 3)
         self.p = None               # per-layer unit probabilities during search_t
         self.new_models = None
         self.model_to_train = None
@@ -215,7 +216,7 @@ class Network(MatchingNet):
         _require_inference(left, right)
         x = self.feature(left, task_arch, path)
         y = self.feature(right, task_arch, path)
-        cost = self.cost_volume(x.float().contiguous(), y.float().contiguous())
+        cost = self.cost_volume(x.to(self.act_dtype).contiguous(), y.to(self.act_dtype).contiguous())
         cost = self.matching(cost, task_arch, path)
         return self.disp(cost)
 
@@ -223,7 +224,7 @@ class Network(MatchingNet):
         _require_inference(left, right)
         x = self.search_feature(left, selected_ops)
         y = self.search_feature(right, selected_ops)
-        cost = self.cost_volume(x.float().contiguous(), y.float().contiguous())
+        cost = self.cost_volume(x.to(self.act_dtype).contiguous(), y.to(self.act_dtype).contiguous())
         cost = self.search_matching(cost, selected_ops, t)
         return self.disp(cost)
 

@@ -13,7 +13,8 @@ import torch
 
 from ._lib import K1RSpec, TailSpec, check, load_library
 
-F32 = 0
+F32, BF16 = 0, 1   # RAGMI_F32 / RAGMI_BF16 of include/rag_amd.h
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
 def _stream() -> int:
@@ -21,13 +22,30 @@ def _stream() -> int:
 
 
 def _need_gpu(*ts: torch.Tensor) -> None:
+    """Parameters (weights, folded BN) and fp32-only tensors: CUDA + float32."""
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise RuntimeError("rag_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback")
         if t.dtype != torch.float32:
-            raise RuntimeError(f"rag_amd ops: dtype {t.dtype} not built (fp32 only)")
+            raise RuntimeError(f"rag_amd ops: dtype {t.dtype} not built for this argument (fp32 only)")
+
+
+def _act(*ts: torch.Tensor) -> int:
+    """Activations: CUDA, all float32 or all bfloat16 (bf16 storage / fp32 on-chip math). Returns the ABI dtype code."""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("rag_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype not in _DT:
+            raise RuntimeError(f"rag_amd ops: activation dtype {t.dtype} not built (float32 or bfloat16)")
+        if dt is not None and t.dtype != dt:
+            raise RuntimeError("rag_amd ops: activation tensors of one call must share a dtype")
+        dt = t.dtype
+    return _DT[dt]
 
 
 def _planes(t: torch.Tensor) -> int:
@@ -53,7 +71,8 @@ class Tail:
 
     def __init__(self, weight2d: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool,
                  out: torch.Tensor, out_ch0: int):
-        _need_gpu(weight2d, scale, shift, out)
+        _need_gpu(weight2d, scale, shift)
+        _act(out)
         self.weight2d, self.scale, self.shift, self.relu, self.out, self.out_ch0 = weight2d, scale, shift, relu, out, out_ch0
 
     def spec(self) -> TailSpec:
@@ -73,16 +92,16 @@ def _tail_array(tails: Optional[Sequence["Tail"]]):
 
 def costvol(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cost[B,2C,maxdisp/3,h,w] of src/models/rag_model.py:375-383."""
-    _need_gpu(left_fea, right_fea)
+    dt = _act(left_fea, right_fea, out)
     if left_fea.shape != right_fea.shape or left_fea.dim() != 4:
         raise ValueError("costvol: left/right features must both be [B, C, h, w]")
     left_fea, right_fea = left_fea.contiguous(), right_fea.contiguous()
     B, C, h, w = left_fea.shape
     d = int(maxdisp / 3)
     if out is None:
-        out = torch.empty((B, 2 * C, d, h, w), device=left_fea.device, dtype=torch.float32)
+        out = torch.empty((B, 2 * C, d, h, w), device=left_fea.device, dtype=left_fea.dtype)
     check(load_library().ragmi_costvol_fwd(left_fea.data_ptr(), right_fea.data_ptr(), out.data_ptr(),
-                                           B, C, d, h, w, F32, _stream()), "costvol")
+                                           B, C, d, h, w, dt, _stream()), "costvol")
     return out
 
 
@@ -122,7 +141,8 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
     """Fused 3x3x3 ConvBR_3d (+ running sum / concat): see ragmi_conv3d_k3_fwd in include/rag_amd.h.
     `out` (and `res`) are [B, C*, D, H, W] buffers; group g of 4 output channels lands at channel
     out_group_ch[g] (default 4g)."""
-    _need_gpu(x, packed, scale, shift, out, res)
+    _need_gpu(packed, scale, shift)
+    dt = _act(x, out, res, *[t.out for t in (tails or [])])
     B, Cin, D, H, W = x.shape
     xb = _planes(x)
     yb = _planes(out)
@@ -143,14 +163,15 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
         out.data_ptr(), yb, _i32_array(out_group_ch),
         res.data_ptr() if res is not None else None, rb, _i32_array(res_group_ch),
-        B, Cin, cout, D, H, W, int(store_main), ntail, tarr, F32, _stream()), "conv3d_k3")
+        B, Cin, cout, D, H, W, int(store_main), ntail, tarr, dt, _stream()), "conv3d_k3")
     return out
 
 
 def conv3d_k3_small(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu: bool, out: torch.Tensor, out_ch0: int = 0,
                     res: Optional[torch.Tensor] = None, res_ch0: int = 0) -> torch.Tensor:
     """3x3x3 ConvBR_3d with Cout <= 2 on the VALU (raw weight [Cout, Cin, 3, 3, 3]): ragmi_conv3d_k3_small_fwd."""
-    _need_gpu(x, weight, scale, shift, out, res)
+    _need_gpu(weight, scale, shift)
+    dt = _act(x, out, res)
     B, Cin, D, H, W = x.shape
     cout = weight.shape[0]
     w = weight.detach().contiguous()
@@ -159,7 +180,7 @@ def conv3d_k3_small(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu: b
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     check(load_library().ragmi_conv3d_k3_small_fwd(
         x.data_ptr(), _planes(x), w.data_ptr(), ptr(scale), ptr(shift), int(relu), out.data_ptr(), _planes(out), out_ch0,
-        ptr(res), _planes(res) if res is not None else 0, res_ch0, B, Cin, cout, D, H, W, F32, _stream()), "conv3d_k3_small")
+        ptr(res), _planes(res) if res is not None else 0, res_ch0, B, Cin, cout, D, H, W, dt, _stream()), "conv3d_k3_small")
     return out
 
 
@@ -170,7 +191,8 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
                    store_main: bool = True) -> torch.Tensor:
     """Two sibling ConvBR_3d groups in one launch: out = act(bnA(convA(x[:, :cin_a]))) + act(bnB(convB(x[:, cin_a:])))
     (+ res): see ragmi_conv3d_k3_dual_fwd in include/rag_amd.h."""
-    _need_gpu(x, packed_a, packed_b, scale_a, shift_a, scale_b, shift_b, out, res)
+    _need_gpu(packed_a, packed_b, scale_a, shift_a, scale_b, shift_b)
+    dt = _act(x, out, res, *[t.out for t in (tails or [])])
     B, Cx, D, H, W = x.shape
     ng = packed_groups(cout)
     if out_group_ch is not None and len(out_group_ch) != ng:
@@ -186,14 +208,15 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
         Cx - cin_a, packed_b.data_ptr(), ptr(scale_b), ptr(shift_b), int(relu),
         out.data_ptr(), _planes(out), _i32_array(out_group_ch),
         ptr(res), _planes(res) if res is not None else 0, _i32_array(res_group_ch),
-        B, cout, D, H, W, int(store_main), ntail, tarr, F32, _stream()), "conv3d_k3_dual")
+        B, cout, D, H, W, int(store_main), ntail, tarr, dt, _stream()), "conv3d_k3_dual")
     return out
 
 
 def conv3d_k1(x: torch.Tensor, weight2d: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
               relu: bool, out: torch.Tensor, out_ch0: int = 0) -> torch.Tensor:
     """Fused 1x1x1 ConvBR_3d writing out[:, out_ch0:out_ch0+Cout]."""
-    _need_gpu(x, weight2d, scale, shift, out)
+    _need_gpu(weight2d, scale, shift)
+    dt = _act(x, out)
     B, Cin = x.shape[:2]
     Cout = weight2d.shape[0]
     dhw = 1
@@ -204,7 +227,7 @@ def conv3d_k1(x: torch.Tensor, weight2d: torch.Tensor, scale: Optional[torch.Ten
     check(load_library().ragmi_conv3d_k1_fwd(
         x.data_ptr(), _planes(x), weight2d.data_ptr(),
         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
-        out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, dhw, F32, _stream()), "conv3d_k1")
+        out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, dhw, dt, _stream()), "conv3d_k1")
     return out
 
 
@@ -212,7 +235,8 @@ def conv3d_k1_resample(x: torch.Tensor, size: Sequence[int], align_corners: bool
                        scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool, out: torch.Tensor,
                        out_ch0: int = 0) -> torch.Tensor:
     """act(bn(conv1x1x1(F.interpolate(x, size, 'trilinear', align_corners)))) without materialising the resampled tensor."""
-    _need_gpu(x, weight2d, scale, shift, out)
+    _need_gpu(weight2d, scale, shift)
+    dt = _act(x, out)
     B, Cin, Di, Hi, Wi = x.shape
     Do, Ho, Wo = [int(v) for v in size]
     Cout = weight2d.shape[0]
@@ -221,7 +245,7 @@ def conv3d_k1_resample(x: torch.Tensor, size: Sequence[int], align_corners: bool
     check(load_library().ragmi_conv3d_k1_resample_fwd(
         x.data_ptr(), _planes(x), Di, Hi, Wi, weight2d.data_ptr(),
         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
-        out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, Do, Ho, Wo, int(bool(align_corners)), F32, _stream()),
+        out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, Do, Ho, Wo, int(bool(align_corners)), dt, _stream()),
         "conv3d_k1_resample")
     return out
 
@@ -230,48 +254,48 @@ def conv3d_k1_resample_pair(specs, size: Sequence[int], out: torch.Tensor) -> to
     """Two resample(align_corners=True) + 1x1x1 ConvBR_3d writing into `out` at the same output `size`, as one launch.
     specs: two tuples (x, weight2d, scale, shift, relu, out_ch0)."""
     arr = []
+    dt = _act(out, *[s[0] for s in specs])
     for (x, w2d, scale, shift, relu, ch0) in specs:
-        _need_gpu(x, w2d, scale, shift)
+        _need_gpu(w2d, scale, shift)
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         arr.append(K1RSpec(x.data_ptr(), _planes(x), x.shape[2], x.shape[3], x.shape[4], w2d.data_ptr(), p(scale), p(shift),
                            int(relu), int(ch0), x.shape[1], w2d.shape[0]))
         if ch0 + w2d.shape[0] > out.shape[1]:
             raise ValueError("conv3d_k1_resample_pair: output buffer too small")
-    _need_gpu(out)
     Do, Ho, Wo = [int(v) for v in size]
     if tuple(out.shape[2:]) != (Do, Ho, Wo):
         raise ValueError("conv3d_k1_resample_pair: wrong output spatial size")
     check(load_library().ragmi_conv3d_k1_resample_pair_fwd(ctypes.byref(arr[0]), ctypes.byref(arr[1]), out.data_ptr(), _planes(out),
-                                                           out.shape[0], Do, Ho, Wo, 1, F32, _stream()), "conv3d_k1_resample_pair")
+                                                           out.shape[0], Do, Ho, Wo, 1, dt, _stream()), "conv3d_k1_resample_pair")
     return out
 
 
 def trilinear3d(x: torch.Tensor, size: Sequence[int], align_corners: bool) -> torch.Tensor:
     """F.interpolate(x, size, mode='trilinear', align_corners=...) for x[B,C,D,H,W]."""
-    _need_gpu(x)
+    dt = _act(x)
     x = x.contiguous()
     B, C, Di, Hi, Wi = x.shape
     Do, Ho, Wo = [int(s) for s in size]
-    out = torch.empty((B, C, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, C, Do, Ho, Wo), device=x.device, dtype=x.dtype)
     check(load_library().ragmi_trilinear3d_fwd(x.data_ptr(), out.data_ptr(), B, C, Di, Hi, Wi, Do, Ho, Wo,
-                                               int(bool(align_corners)), F32, _stream()), "trilinear3d")
+                                               int(bool(align_corners)), dt, _stream()), "trilinear3d")
     return out
 
 
 def add(a: torch.Tensor, a_ch0: int, b: torch.Tensor, b_ch0: int, out: torch.Tensor, out_ch0: int, channels: int) -> torch.Tensor:
     """out[:, out_ch0:+C] = a[:, a_ch0:+C] + b[:, b_ch0:+C]."""
-    _need_gpu(a, b, out)
+    dt = _act(a, b, out)
     dhw = 1
     for s in a.shape[2:]:
         dhw *= s
     check(load_library().ragmi_add_fwd(a.data_ptr(), _planes(a), a_ch0, b.data_ptr(), _planes(b), b_ch0,
-                                       out.data_ptr(), _planes(out), out_ch0, a.shape[0], channels, dhw, F32, _stream()), "add")
+                                       out.data_ptr(), _planes(out), out_ch0, a.shape[0], channels, dhw, dt, _stream()), "add")
     return out
 
 
 def disp_softargmin(cost: torch.Tensor, maxdisp: int) -> torch.Tensor:
     """Fused Disp.forward: cost[B,1,d,h,w] (or [B,d,h,w]) -> disparity [B,3h,3w]."""
-    _need_gpu(cost)
+    dt = _act(cost)
     if cost.dim() == 5:
         if cost.shape[1] != 1:
             raise ValueError("disp_softargmin: expected a single-channel cost volume")
@@ -280,18 +304,18 @@ def disp_softargmin(cost: torch.Tensor, maxdisp: int) -> torch.Tensor:
     B, d, h, w = cost.shape
     out = torch.empty((B, 3 * h, 3 * w), device=cost.device, dtype=torch.float32)
     check(load_library().ragmi_disp_softargmin_fwd(cost.data_ptr(), out.data_ptr(), B, d, h, w, int(maxdisp),
-                                                   3 * h, 3 * w, F32, _stream()), "disp_softargmin")
+                                                   3 * h, 3 * w, dt, _stream()), "disp_softargmin")
     return out
 
 
 def disparity_regression(prob: torch.Tensor, maxdisp: int) -> torch.Tensor:
     """DisparityRegression.forward: prob[B,D,H,W] -> [B,H,W]."""
-    _need_gpu(prob)
+    dt = _act(prob)
     assert prob.is_contiguous()  # the reference asserts this too (rag_model.py:24)
     B, D, H, W = prob.shape
     if D != maxdisp:
         raise ValueError("disparity_regression: prob.shape[1] must equal maxdisp")
     out = torch.empty((B, H, W), device=prob.device, dtype=torch.float32)
-    check(load_library().ragmi_disparity_regression_fwd(prob.data_ptr(), out.data_ptr(), B, D, H, W, F32, _stream()),
+    check(load_library().ragmi_disparity_regression_fwd(prob.data_ptr(), out.data_ptr(), B, D, H, W, dt, _stream()),
           "disparity_regression")
     return out
