@@ -173,3 +173,41 @@ def test_network_growth_api_matches_reference_bookkeeping():
     assert as_int(best2) == blob["best_archi_round2"]
     assert {k: int(v) for k, v in net.length.items()} == blob["length_round2"]
     assert sorted(net.state_dict().keys()) == blob["keys_round2"]
+
+
+# ------------------------------------------------------------------ edge cases / argument validation
+def test_abi_rejects_unbuilt_dtype_and_bad_sizes(built_lib):
+    """Validation runs before any launch, so it is checkable without a GPU (pointers are never dereferenced)."""
+    import ctypes
+    fake = ctypes.c_void_p(0x1000)
+    # unknown dtype code -> RAGMI_EUNSUPPORTED (-2)
+    assert built_lib.ragmi_costvol_fwd(fake, fake, fake, 1, 12, 8, 4, 4, 7, None) == -2
+    assert b"dtype" in built_lib.ragmi_last_error()
+    assert built_lib.ragmi_trilinear3d_fwd(fake, fake, 1, 1, 2, 2, 2, 4, 4, 4, 1, 9, None) == -2
+    # non-positive sizes -> RAGMI_EINVAL (-1)
+    assert built_lib.ragmi_costvol_fwd(fake, fake, fake, 0, 12, 8, 4, 4, 0, None) == -1
+    assert built_lib.ragmi_conv3d_k1_fwd(fake, 0, fake, None, None, 0, fake, 0, 0, 1, 0, 4, 8, 0, None) == -1
+    # scale without shift
+    assert built_lib.ragmi_conv3d_k1_fwd(fake, 0, fake, fake, None, 0, fake, 0, 0, 1, 4, 4, 8, 0, None) == -1
+    # too many output channels for one call / dual needs CinA % 4 == 0
+    assert built_lib.ragmi_conv3d_k3_fwd(fake, 0, fake, None, None, 0, fake, 0, None, None, 0, None, 1, 4, 68, 2, 2, 2, 0, None) == -2
+    assert built_lib.ragmi_conv3d_k3_dual_fwd(fake, 0, 3, fake, None, None, 4, fake, None, None, 0, fake, 0, None, None, 0, None,
+                                              1, 4, 2, 2, 2, 0, None) == -1
+    # small-Cout form only for Cout <= 2
+    assert built_lib.ragmi_conv3d_k3_small_fwd(fake, 0, fake, None, None, 0, fake, 0, 0, None, 0, 0, 1, 4, 3, 2, 2, 2, 0, None) == -2
+
+
+def test_cost_volume_maxdisp_semantics_match_reference():
+    """d = int(maxdisp / 3) like rag_model.py:376-377 (maxdisp need not be a multiple of 3); disparities past the width
+    stay zero (the reference's slice assignment is empty there)."""
+    L, R = torch.randn(1, 2, 3, 4), torch.randn(1, 2, 3, 4)
+    assert O.cost_volume(L, R, 25).shape == (1, 4, 8, 3, 4)
+    c = O.cost_volume(L, R, 24)
+    assert float(c[:, :, 4:].abs().max()) == 0.0 and torch.equal(c[:, :2, 0], L) and torch.equal(c[:, 2:, 1, :, 1:], R[..., :-1])
+
+
+def test_oracle_rejects_shapes_the_reference_crashes_on():
+    rows = O.ALL_SKIP
+    sd = O.random_matching_state_dict(rows)
+    with pytest.raises(ValueError):     # h = 10 is not a multiple of 4 -> reference: UnboundLocalError at rag_model.py:360-366
+        O.matching(torch.zeros(1, 24, 4, 10, 8), sd, rows)
