@@ -149,6 +149,37 @@ def timed_region(step, steps: int, warmup: int, dist=None, sync=lambda: None, de
     return dt
 
 
+def end_to_end(device, steps, seed=0):
+    """(left, right) images -> disparity through rag_amd.Network: Feature Net + Matching Net, all HIP.
+    Reported beside the headline Matching-Net metric ('separately reported, end-to-end')."""
+    import rag_amd
+    torch.manual_seed(seed)
+    net = rag_amd.Network(rag_amd.ALL_CONV_GENOTYPE, device, maxdisp=MAXDISP)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.BatchNorm2d)):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    net = net.to(device).eval()
+    g = torch.Generator().manual_seed(1234)
+    left = torch.randn((1, 3, H, W), generator=g).to(device)
+    right = torch.randn((1, 3, H, W), generator=g).to(device)
+    with torch.no_grad():
+        for _ in range(2):
+            net(left, right, 0, net.arch_init)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(left, right, 0, net.arch_init)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(1.0 / dt, 3), "unit": "disparity maps/s", "ms_per_pair": round(dt * 1e3, 4),
+            "what": f"(left,right)[1,3,{H},{W}] -> disp, Feature Net + Matching Net on HIP, B=1 fp32"}
+
+
 def cpu_baseline(net, lf, rf):
     """Oracle leg (checker code, allowed here only): one pair of the same workload on host cores."""
     from oracle import matching_oracle as O
@@ -267,6 +298,9 @@ def main():
             epe = O.epe(out[:1].float().cpu(), ref)
             log(f"  EPE of the timed GPU path vs the CPU oracle on the same pair: {epe:.3e} px")
             cpu["epe_gpu_vs_cpu_px"] = epe
+        e2e = end_to_end(device, min(args.steps, 10)) if (n_gpus == 1 and args.dtype == "f32") else None
+        if e2e:
+            log(f"  end-to-end (images -> disparity, Feature Net + Matching Net): {e2e['value']} maps/s ({e2e['ms_per_pair']} ms/pair)")
         ms = dt / args.steps * 1e3
         line = {
             "metric": "disparity maps/sec at 384x1248 D=192 (Matching-Net forward)",
@@ -278,7 +312,7 @@ def main():
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
                        "global_batch": n_gpus * B, "sharding": "batch split, no collective",
                        "launch": "hipGraph" if graph is not None else "eager"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -208,6 +208,15 @@ int ragmi_trilinear3d_fwd(const void* x, void* y, int B, int C,
                           int align_corners, int dtype, void* stream);
 
 /*
+ * Feature-Net stem: 2-D 3x3 / pad 1 / stride `stride` ConvBR (stem2d1 = ConvBR_2d(6, 12, 3,
+ * stride=3, padding=1), rag_model.py:201).  x: [B, Cin, H, W] -> y: [B, Cout, (H-1)/stride+1, (W-1)/stride+1].
+ * weight: raw nn.Conv2d weight [Cout, Cin, 3, 3].  The stride-1 2-D convs of the Feature Net run on the 3-D
+ * kernels over a depth-1 volume (weights embedded in the middle z-slice).
+ */
+int ragmi_conv2d_k3_strided_fwd(const void* x, const void* weight, const void* scale, const void* shift, int relu,
+                                void* y, int B, int Cin, int Cout, int H, int W, int stride, int dtype, void* stream);
+
+/*
  * y[b, y_ch0 + c] = a[b, a_ch0 + c] + b[b, b_ch0 + c]   (sum of two Identity_3d branches,
  * rag_model.py:172 with operations_3d.py:84-90).
  */

@@ -14,7 +14,8 @@ from .modules import (  # noqa: F401
     Identity_3d, MatchingNet, OPS_3d, PRIMITIVES_3D,
 )
 
-from .network import Cell_2d, ConvBR_2d, Network  # noqa: E402,F401
+from .modules import Cell_2d, ConvBR_2d, OPS_2d, PRIMITIVES  # noqa: E402,F401
+from .network import Network  # noqa: E402,F401
 
 __all__ = [
     "Network", "Cell_2d", "ConvBR_2d",

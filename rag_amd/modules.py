@@ -48,43 +48,47 @@ class Identity_3d(nn.Module):
         return x
 
 
-class ConvBR_3d(nn.Module):
-    """Conv3d(bias=False) -> BatchNorm3d -> ReLU as ONE fused HIP kernel.
+class _ConvBR(nn.Module):
+    """Conv(bias=False) -> BatchNorm -> ReLU as ONE fused HIP kernel; shared by the 3-D (Matching Net) and 2-D (Feature
+    Net, a depth-1 volume on the same kernels) flavours.  Sub-module names `conv` / `bn`, the always-constructed `bn`
+    and the init follow the reference (operations_3d.py:31-55, operations_2d.py:31-55)."""
 
-    Mirrors src/automl/operations_3d.py:31-47 (same ctor, same sub-module names `conv`/`bn`,
-    `bn` constructed even when bn=False, same init :49-55).  Supported on the HIP path:
-    kernel_size 3 (padding 1) and 1 (padding 0), stride 1 — all the reference instantiates.
-    """
+    NDIM = 3
 
     def __init__(self, C_in, C_out, kernel_size, stride, padding, bn=True, relu=True):
         super().__init__()
         self.relu = relu
         self.use_bn = bn
-        self.conv = nn.Conv3d(C_in, C_out, kernel_size, stride=stride, padding=padding, bias=False)
-        self.bn = nn.BatchNorm3d(C_out)
+        if self.NDIM == 3:
+            self.conv = nn.Conv3d(C_in, C_out, kernel_size, stride=stride, padding=padding, bias=False)
+            self.bn = nn.BatchNorm3d(C_out)
+        else:
+            self.conv = nn.Conv2d(C_in, C_out, kernel_size, stride=stride, padding=padding, bias=False)
+            self.bn = nn.BatchNorm2d(C_out)
         self._initialize_weights()
         self._cache = None
 
     def _initialize_weights(self):
-        for m in self.modules():
-            if isinstance(m, nn.Conv3d):
-                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-            elif isinstance(m, nn.BatchNorm3d):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
+        nn.init.kaiming_normal_(self.conv.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(self.bn.weight, 1)
+        nn.init.constant_(self.bn.bias, 0)
 
     # -- HIP-side parameters: packed weights + folded eval-mode BN, cached on tensor versions
     def _geometry(self) -> int:
-        k = self.conv.kernel_size
-        if k not in ((1, 1, 1), (3, 3, 3)) or self.conv.stride != (1, 1, 1) or \
-                self.conv.padding != tuple((ki - 1) // 2 for ki in k) or self.conv.dilation != (1, 1, 1) or self.conv.groups != 1:
-            raise NotImplementedError("rag_amd.ConvBR_3d: only 1x1x1/pad0 and 3x3x3/pad1, stride 1 are built "
-                                      "(everything the reference's Matching Net instantiates)")
-        return k[0]
+        """kernel size 1 or 3 (stride 1, 'same' padding), or -3 for the strided 2-D 3x3 stem (Feature Net)."""
+        k, n = self.conv.kernel_size, self.NDIM
+        same = self.conv.padding == tuple((ki - 1) // 2 for ki in k) and self.conv.dilation == (1,) * n and self.conv.groups == 1
+        if same and k in ((1,) * n, (3,) * n) and self.conv.stride == (1,) * n:
+            return k[0]
+        if same and n == 2 and k == (3, 3) and self.conv.stride[0] == self.conv.stride[1] > 1:
+            return -3
+        raise NotImplementedError("rag_amd ConvBR: only 1x1(x1)/pad0 and 3x3(x3)/pad1 at stride 1 (plus the strided 2-D 3x3 "
+                                  "stem) are built (everything the reference instantiates)")
 
     def _small(self) -> bool:
         """Cout <= 2 (last_3_3d): VALU form of the 3x3x3 kernel instead of the 4-row MFMA."""
-        return self.conv.out_channels <= 2 and self.conv.in_channels % 4 == 0 and self.conv.in_channels <= 128
+        return (self.NDIM == 3 and self.conv.out_channels <= 2 and self.conv.in_channels % 4 == 0
+                and self.conv.in_channels <= 128)
 
     def stamp(self) -> tuple:
         w, bn = self.conv.weight, self.bn
@@ -94,16 +98,20 @@ class ConvBR_3d(nn.Module):
     def prepared(self) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
         """(weights in kernel layout, scale, shift); scale/shift None when bn=False."""
         if self.use_bn and self.bn.training:
-            raise NotImplementedError("rag_amd.ConvBR_3d: train-mode BatchNorm (batch statistics) is not built yet; "
+            raise NotImplementedError("rag_amd ConvBR: train-mode BatchNorm (batch statistics) is not built yet; "
                                       "put the module in eval() — no PyTorch fallback by design")
         stamp = self.stamp()
         if self._cache is None or self._cache[0] != stamp:
             k = self._geometry()
             w = self.conv.weight.detach()
             with torch.no_grad():
-                if k == 3 and self._small():
-                    wk = w.contiguous()                      # VALU form reads the raw weight
+                if k == -3 or (k == 3 and self._small()):
+                    wk = w.contiguous()                      # strided 2-D stem / VALU form read the raw weight
                 elif k == 3:
+                    if self.NDIM == 2:                       # 2-D 3x3 = 3-D 3x3x3 on a depth-1 volume: only the middle z-slice is non-zero
+                        w3 = w.new_zeros((w.shape[0], w.shape[1], 3, 3, 3))
+                        w3[:, :, 1] = w
+                        w = w3
                     wk = ops.conv3d_k3_pack(w)
                 else:
                     wk = w.reshape(w.shape[0], w.shape[1]).contiguous()
@@ -118,9 +126,9 @@ class ConvBR_3d(nn.Module):
         return self._cache[1], self._cache[2], self._cache[3]
 
     def as_tail(self, out: torch.Tensor, out_ch0: int) -> "ops.Tail":
-        """This 1x1x1 ConvBR (<= 4 output channels) as a tail of the kernel that produces its input."""
+        """This 1x1(x1) ConvBR (<= 4 output channels) as a tail of the kernel that produces its input."""
         if self._geometry() != 1 or self.conv.out_channels > 4:
-            raise ValueError("only 1x1x1 ConvBR_3d with <= 4 output channels can be fused as a tail")
+            raise ValueError("only 1x1x1 ConvBR with <= 4 output channels can be fused as a tail")
         wk, scale, shift = self.prepared()
         return ops.Tail(wk, scale, shift, self.relu, out, out_ch0)
 
@@ -129,19 +137,26 @@ class ConvBR_3d(nn.Module):
                 store_main: bool = True) -> torch.Tensor:
         """`out`/`out_ch0` write into a channel slice of a wider buffer.  `resample_to` (1x1x1 only) first resamples x
         trilinearly (align_corners=True) to that size inside the same kernel — the reference's
-        `conv(F.interpolate(x, size, mode='trilinear', align_corners=True))`."""
+        `conv(F.interpolate(x, size, mode='trilinear', align_corners=True))`.  The 2-D flavour accepts [B,C,H,W] (or an
+        already depth-1 5-D view) and returns the same rank."""
         _require_inference(x, self.conv.weight)
         k = self._geometry()
         wk, scale, shift = self.prepared()
         cout = self.conv.out_channels
+        if k == -3:
+            return ops.conv2d_k3_strided(x if x.dim() == 4 else x[:, :, 0], wk, scale, shift, self.relu, self.conv.stride[0])
+        squeeze = x.dim() == 4
+        if squeeze:
+            x = x.unsqueeze(2)
         if resample_to is not None and tuple(resample_to) == tuple(x.shape[2:]):
             resample_to = None
         if resample_to is not None:
             if k != 1:
-                raise NotImplementedError("ConvBR_3d: fused resample is built for the 1x1x1 form only")
+                raise NotImplementedError("ConvBR: fused resample is built for the 1x1x1 form only")
             if out is None:
                 out = torch.empty((x.shape[0], cout) + tuple(int(v) for v in resample_to), device=x.device, dtype=x.dtype)
-            return ops.conv3d_k1_resample(x, resample_to, True, wk, scale, shift, self.relu, out, out_ch0)
+            ops.conv3d_k1_resample(x, resample_to, True, wk, scale, shift, self.relu, out, out_ch0)
+            return out[:, :, 0] if squeeze else out
         if out is None:
             out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
         if k == 3 and self._small():
@@ -151,7 +166,24 @@ class ConvBR_3d(nn.Module):
             ops.conv3d_k3(x, wk, cout, scale, shift, self.relu, out, groups, tails=tails, store_main=store_main)
         else:
             ops.conv3d_k1(x, wk, scale, shift, self.relu, out, out_ch0)
-        return out
+        return out[:, :, 0] if squeeze else out
+
+
+class ConvBR_3d(_ConvBR):
+    """src/automl/operations_3d.py:31-47 — same ctor `(C_in, C_out, kernel_size, stride, padding, bn=True, relu=True)`."""
+    NDIM = 3
+
+
+class ConvBR_2d(_ConvBR):
+    """src/automl/operations_2d.py:31-47 (Feature Net) on the same kernels over a depth-1 volume."""
+    NDIM = 2
+
+
+class Identity_2d(nn.Module):
+    """src/automl/operations_2d.py Identity_2d."""
+
+    def forward(self, x):
+        return x
 
 
 # src/automl/operations_3d.py:5-8 (stride is always 1 on the hot path)
@@ -165,6 +197,19 @@ OPS_3d = {
     "skip_connect_3d": _skip,
     "3d_conv_3x3": lambda C, stride: ConvBR_3d(C, C, 3, stride, 1),
 }
+
+
+# src/automl/genotypes_2d.py:10-12, operations_2d.py:5-8
+PRIMITIVES = ["skip_connect_2d", "conv_3x3"]
+
+
+def _skip_2d(C, stride):
+    if stride != 1:
+        raise NotImplementedError("skip_connect_2d with stride != 1 is dead code in the reference")
+    return Identity_2d()
+
+
+OPS_2d = {"skip_connect_2d": _skip_2d, "conv_3x3": lambda C, stride: ConvBR_2d(C, C, 3, stride, 1)}
 
 
 class DisparityRegression(nn.Module):
@@ -194,8 +239,9 @@ class Disp(nn.Module):
         return ops.disp_softargmin(x, self.maxdisp)
 
 
-class Cell_3d(nn.Module):
-    """src/models/rag_model.py:114-177 on HIP kernels.
+class _Cell(nn.Module):
+    """Shared executor of Cell_3d (rag_model.py:114-177) and Cell_2d (:47-111) on HIP kernels; tensors are 5-D
+    (the 2-D cell runs on depth-1 volumes: scale_dimension(1, s) == 1, and trilinear with one plane is bilinear).
 
     forward(prev_prev_input, prev_input) -> (prev_input, concat).  The 1x1x1 preprocess convs
     write s0|s1 into one buffer, every selected op writes/accumulates straight into its
@@ -214,8 +260,8 @@ class Cell_3d(nn.Module):
         self.C_prev = int(block_multiplier * prev_filter_multiplier)
         self.C_prev_prev = int(block_multiplier * prev_prev_fmultiplier)
         self.downup_sample = downup_sample
-        self.pre_preprocess = ConvBR_3d(self.C_prev_prev, self.C_out, 1, 1, 0)
-        self.preprocess = ConvBR_3d(self.C_prev, self.C_out, 1, 1, 0)
+        self.pre_preprocess = self.CONV(self.C_prev_prev, self.C_out, 1, 1, 0)
+        self.preprocess = self.CONV(self.C_prev, self.C_out, 1, 1, 0)
         self._steps = steps
         self.block_multiplier = block_multiplier
         self._ops = nn.ModuleList()
@@ -223,17 +269,19 @@ class Cell_3d(nn.Module):
             self.scale = 0.5
         elif downup_sample == 1:
             self.scale = 2
-        for x in self.genotype.reduce:
-            primitive = PRIMITIVES_3D[x[1]]
-            self._ops.append(OPS_3d[primitive](self.C_out, stride=1))
+        for x in self._rows():
+            self._ops.append(self.OPS[self.PRIMS[x[1]]](self.C_out, stride=1))
         self._fused_cache: Dict[tuple, tuple] = {}
+
+    def _rows(self):
+        raise NotImplementedError
 
     def scale_dimension(self, dim, scale):
         return int((float(dim) - 1.0) * scale + 1.0) if dim % 2 == 1 else int(float(dim) * scale)
 
     def _contributions(self) -> Dict[int, List[Tuple[int, nn.Module]]]:
         """new-state index -> [(source state j, op module)] in the reference's visit order."""
-        selected = set(int(v) for v in np.asarray(self.genotype.reduce)[:, 0])
+        selected = set(int(v) for v in np.asarray(self._rows())[:, 0])
         contribs: Dict[int, List[Tuple[int, nn.Module]]] = {}
         offset, n_states, ops_index = 0, 2, 0
         for _ in range(self._steps):
@@ -263,6 +311,9 @@ class Cell_3d(nn.Module):
         return hit[1]
 
     def forward(self, prev_prev_input, prev_input):
+        if prev_input.dim() == 4:     # 2-D cell: run on depth-1 volumes
+            concat_feature, _applied = self._run(prev_prev_input.unsqueeze(2), prev_input.unsqueeze(2))
+            return prev_input, concat_feature[:, :, 0]
         concat_feature, _applied = self._run(prev_prev_input, prev_input)
         return prev_input, concat_feature
 
@@ -300,7 +351,7 @@ class Cell_3d(nn.Module):
         tails_applied = False
         contribs = self._contributions()
         conv_from = {j: [(k, op) for k, lst in contribs.items() for (src, op) in lst
-                         if src == j and isinstance(op, ConvBR_3d)] for j in (0, 1)}
+                         if src == j and isinstance(op, _ConvBR)] for j in (0, 1)}
         # one dual launch produces every new state <=> both inputs feed conv branches into all of them and nothing else does
         single_dual = (bool(conv_from[0]) and (pre_has[0] or s0.shape[1] != C) and [k for k, _ in conv_from[0]] == [k for k, _ in conv_from[1]]
                        and all(len(contribs[k]) == 2 for k, _ in conv_from[0]) and len(conv_from[0]) == self._steps
@@ -336,7 +387,7 @@ class Cell_3d(nn.Module):
             where.append((cat, (k - first_cat) * C) if k >= first_cat else (scratch, (k - 2) * C))
 
         written = {k: False for k in contribs}
-        pending_id = {k: [j for (j, op) in lst if not isinstance(op, ConvBR_3d)] for k, lst in contribs.items()}
+        pending_id = {k: [j for (j, op) in lst if not isinstance(op, _ConvBR)] for k, lst in contribs.items()}
         for k, lst in contribs.items():
             if not lst:
                 raise ValueError("Cell_3d: a step with no selected branch (the reference fails in torch.cat here too)")
@@ -383,7 +434,7 @@ class Cell_3d(nn.Module):
             parts: Dict[object, list] = {}
             for k, lst in contribs.items():
                 for (src, op) in lst:
-                    if src != j or not isinstance(op, ConvBR_3d) or (j, id(op)) in done:
+                    if src != j or not isinstance(op, _ConvBR) or (j, id(op)) in done:
                         continue
                     if written[k]:
                         res = where[k]                                   # running sum: accumulate in place
@@ -429,6 +480,22 @@ class Cell_3d(nn.Module):
         if tails_applied and drop_main:
             return None, True          # the concat exists only inside the kernel: its consumers were the tails
         return cat, tails_applied
+
+
+class Cell_3d(_Cell):
+    """src/models/rag_model.py:114-177: forward(prev_prev_input, prev_input) -> (prev_input, concat); ops from genotype.reduce."""
+    CONV, OPS, PRIMS = ConvBR_3d, OPS_3d, PRIMITIVES_3D
+
+    def _rows(self):
+        return self.genotype.reduce
+
+
+class Cell_2d(_Cell):
+    """src/models/rag_model.py:47-111 (Feature Net cell; ops from genotype.normal) on the same executor."""
+    CONV, OPS, PRIMS = ConvBR_2d, OPS_2d, PRIMITIVES
+
+    def _rows(self):
+        return self.genotype.normal
 
 
 # Matching-Net macro architecture, src/models/rag_model.py:238-261:

@@ -7,10 +7,10 @@ What `approaches/rag.py` (Appr) drives is kept one-to-one: ``forward(left, right
 attributes ``p, length, arch_init, new_models, model_to_train`` plus every per-layer ``nn.ModuleList`` name,
 hence the checkpoint layout of ``run.py:194-196``.
 
-The 2-D Feature Net (`Cell_2d`, `ConvBR_2d`; ≈1 % of the FLOPs) is OUTSIDE the hot path of this build
-("next"): it is plain PyTorch-ROCm here, kept only so that the Matching Net can be
-driven from images and the growth loop has a complete model to poke.  Everything from the cost volume on is
-HIP (`MatchingNet`).
+The 2-D Feature Net (`Cell_2d`, `ConvBR_2d`; ≈1 % of the FLOPs) runs on the same HIP
+kernels as the Matching Net: a 2-D conv is the 3-D kernel over a depth-1 volume, the stride-3 stem has its own
+kernel (`ragmi_conv2d_k3_strided_fwd`), bilinear resampling is the trilinear kernel with one plane.  So
+`Network.forward(left, right)` is HIP end to end; PyTorch only allocates.
 """
 from __future__ import annotations
 
@@ -18,97 +18,8 @@ from typing import Dict, List
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from .modules import Cell_3d, ConvBR_3d, MatchingNet, _require_inference
-
-# src/automl/genotypes_2d.py:10-12
-PRIMITIVES = ["skip_connect_2d", "conv_3x3"]
-
-
-class Identity_2d(nn.Module):
-    def forward(self, x):
-        return x
-
-
-class ConvBR_2d(nn.Module):
-    """src/automl/operations_2d.py:31-47 (Feature Net, PyTorch)."""
-
-    def __init__(self, C_in, C_out, kernel_size, stride, padding, bn=True, relu=True):
-        super().__init__()
-        self.relu = relu
-        self.use_bn = bn
-        self.conv = nn.Conv2d(C_in, C_out, kernel_size, stride=stride, padding=padding, bias=False)
-        self.bn = nn.BatchNorm2d(C_out)
-        nn.init.kaiming_normal_(self.conv.weight, mode="fan_out", nonlinearity="relu")
-        nn.init.constant_(self.bn.weight, 1)
-        nn.init.constant_(self.bn.bias, 0)
-
-    def forward(self, x):
-        x = self.conv(x)
-        if self.use_bn:
-            x = self.bn(x)
-        return F.relu(x, inplace=True) if self.relu else x
-
-
-def _skip_2d(C, stride):
-    if stride != 1:
-        raise NotImplementedError("skip_connect_2d with stride != 1 is dead code in the reference")
-    return Identity_2d()
-
-
-OPS_2d = {"skip_connect_2d": _skip_2d, "conv_3x3": lambda C, stride: ConvBR_2d(C, C, 3, stride, 1)}
-
-
-class Cell_2d(nn.Module):
-    """src/models/rag_model.py:47-111 (Feature Net cell, PyTorch; reads genotype.normal)."""
-
-    def __init__(self, steps, block_multiplier, prev_prev_fmultiplier, prev_filter_multiplier, genotype,
-                 filter_multiplier, downup_sample):
-        super().__init__()
-        self.genotype = genotype
-        self.C_in = block_multiplier * filter_multiplier
-        self.C_out = filter_multiplier
-        self.C_prev = int(block_multiplier * prev_filter_multiplier)
-        self.C_prev_prev = int(block_multiplier * prev_prev_fmultiplier)
-        self.downup_sample = downup_sample
-        self.pre_preprocess = ConvBR_2d(self.C_prev_prev, self.C_out, 1, 1, 0)
-        self.preprocess = ConvBR_2d(self.C_prev, self.C_out, 1, 1, 0)
-        self._steps = steps
-        self.block_multiplier = block_multiplier
-        self._ops = nn.ModuleList()
-        if downup_sample == -1:
-            self.scale = 0.5
-        elif downup_sample == 1:
-            self.scale = 2
-        for x in self.genotype.normal:
-            self._ops.append(OPS_2d[PRIMITIVES[x[1]]](self.C_out, stride=1))
-
-    def scale_dimension(self, dim, scale):
-        return int((float(dim) - 1.0) * scale + 1.0) if dim % 2 == 1 else int(float(dim) * scale)
-
-    def forward(self, prev_prev_input, prev_input):
-        s0, s1 = prev_prev_input, prev_input
-        if self.downup_sample != 0:
-            size = [self.scale_dimension(s1.shape[2], self.scale), self.scale_dimension(s1.shape[3], self.scale)]
-            s1 = F.interpolate(s1, size, mode="bilinear", align_corners=True)
-        if tuple(s0.shape[2:]) != tuple(s1.shape[2:]):
-            s0 = F.interpolate(s0, tuple(s1.shape[2:]), mode="bilinear", align_corners=True)
-        s0 = self.pre_preprocess(s0) if s0.shape[1] != self.C_out else s0
-        s1 = self.preprocess(s1)
-        states = [s0, s1]
-        selected = set(int(v) for v in self.genotype.normal[:, 0])
-        offset, ops_index = 0, 0
-        for _ in range(self._steps):
-            new_states = []
-            for j, h in enumerate(states):
-                if offset + j in selected:            # positional op pairing, like Cell_3d (SURVEY §8 A6)
-                    new_states.append(self._ops[ops_index](h))
-                    ops_index += 1
-            offset += len(states)
-            states.append(sum(new_states))
-        return prev_input, torch.cat(states[-self.block_multiplier:], dim=1)
-
+from .modules import Cell_2d, Cell_3d, ConvBR_2d, ConvBR_3d, MatchingNet, _require_inference  # noqa: F401
 
 # Feature-Net macro architecture, rag_model.py:207-219: (prev_prev_fm, prev_fm, filter_multiplier, downup)
 _CELL2D_ARCH = ((4, 4, 8, -1), (4, 8, 4, 1), (8, 4, 8, -1), (4, 8, 4, 1))
@@ -126,7 +37,7 @@ class Network(MatchingNet):
         self._genotype0 = genotype
         self.length: Dict[str, int] = {}
         self.arch_init: Dict[str, List[int]] = {}
-        # feature net (PyTorch)
+        # feature net (HIP, depth-1 volumes)
         self.cells_2d = nn.ModuleList()
         self.stem2d0 = nn.ModuleList([self._new_unit("stem_2d0", genotype)])
         self.stem2d1 = nn.ModuleList([self._new_unit("stem_2d1", genotype)])
@@ -214,17 +125,18 @@ class Network(MatchingNet):
 
     def forward(self, left, right, t, task_arch=None, path=None):   # rag_model.py:369-387
         _require_inference(left, right)
-        x = self.feature(left, task_arch, path)
-        y = self.feature(right, task_arch, path)
-        cost = self.cost_volume(x.to(self.act_dtype).contiguous(), y.to(self.act_dtype).contiguous())
+        # both views share the Feature-Net weights: one batched pass (results are batch-independent) instead of two
+        B = left.shape[0]
+        fea = self.feature(torch.cat([left, right]), task_arch, path).to(self.act_dtype)
+        cost = self.cost_volume(fea[:B].contiguous(), fea[B:].contiguous())
         cost = self.matching(cost, task_arch, path)
         return self.disp(cost)
 
     def search_forward(self, left, right, t, selected_ops):        # rag_model.py:688-706
         _require_inference(left, right)
-        x = self.search_feature(left, selected_ops)
-        y = self.search_feature(right, selected_ops)
-        cost = self.cost_volume(x.to(self.act_dtype).contiguous(), y.to(self.act_dtype).contiguous())
+        B = left.shape[0]
+        fea = self.search_feature(torch.cat([left, right]), selected_ops).to(self.act_dtype)
+        cost = self.cost_volume(fea[:B].contiguous(), fea[B:].contiguous())
         cost = self.search_matching(cost, selected_ops, t)
         return self.disp(cost)
 

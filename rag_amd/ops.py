@@ -270,6 +270,22 @@ def conv3d_k1_resample_pair(specs, size: Sequence[int], out: torch.Tensor) -> to
     return out
 
 
+def conv2d_k3_strided(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu: bool, stride: int) -> torch.Tensor:
+    """2-D 3x3 / pad 1 / stride-s ConvBR of the Feature-Net stem: x[B,Cin,H,W] -> [B,Cout,Ho,Wo]."""
+    _need_gpu(weight, scale, shift)
+    dt = _act(x)
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=x.dtype)
+    w = weight.detach().contiguous()
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(load_library().ragmi_conv2d_k3_strided_fwd(x.data_ptr(), w.data_ptr(), p(scale), p(shift), int(relu), out.data_ptr(),
+                                                     B, Cin, Cout, H, W, int(stride), dt, _stream()), "conv2d_k3_strided")
+    return out
+
+
 def trilinear3d(x: torch.Tensor, size: Sequence[int], align_corners: bool) -> torch.Tensor:
     """F.interpolate(x, size, mode='trilinear', align_corners=...) for x[B,C,D,H,W]."""
     dt = _act(x)

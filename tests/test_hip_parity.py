@@ -277,6 +277,46 @@ def test_conv3d_k1_resample_vs_aten(ra, cin, cout, shape, size):
     assert float(out[:, :1].abs().max()) == 0.0 and float(out[:, 1 + cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,H,W,stride", [(6, 12, 36, 60, 3), (3, 5, 17, 23, 2), (6, 12, 48, 96, 3), (4, 4, 9, 9, 4)])
+def test_conv2d_k3_strided_vs_aten(ra, cin, cout, H, W, stride):
+    """Feature-Net stem2d1 (3x3, pad 1, stride 3; rag_model.py:201)."""
+    x = torch.randn((2, cin, H, W), generator=gen(90))
+    w = torch.randn((cout, cin, 3, 3), generator=gen(91)) * 0.2
+    scale, shift = torch.rand(cout, generator=gen(92)) + 0.5, torch.randn(cout, generator=gen(93)) * 0.1
+    ref = F.relu(F.conv2d(x, w, stride=stride, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    out = ra.ops.conv2d_k3_strided(gpu(x), gpu(w), gpu(scale), gpu(shift), True, stride)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), **TOL)
+
+
+def test_convbr2d_and_cell2d_on_depth1_volumes(ra):
+    """2-D ConvBR / Cell on the 3-D kernels (depth-1 volume) vs PyTorch's 2-D ops with the same parameters."""
+    torch.manual_seed(7)
+    m = ra.ConvBR_2d(3, 6, 3, 1, 1).to(DEV).eval()
+    with torch.no_grad():
+        m.bn.running_mean.normal_(0, 0.1); m.bn.running_var.uniform_(0.5, 1.5); m.bn.weight.uniform_(0.5, 1.5); m.bn.bias.normal_(0, 0.1)
+        x = torch.randn((2, 3, 24, 36), device=DEV)
+        ref = F.relu(F.batch_norm(F.conv2d(x, m.conv.weight, padding=1), m.bn.running_mean, m.bn.running_var, m.bn.weight, m.bn.bias))
+        np.testing.assert_allclose(m(x).cpu().numpy(), ref.cpu().numpy(), **TOL)
+        rows = np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]])
+        cell = ra.Cell_2d(3, 3, 4, 4, ra.Genotype(rows, None, rows, None), 8, -1).to(DEV).eval()
+        s0, s1 = torch.randn((1, 12, 24, 36), device=DEV), torch.randn((1, 12, 24, 36), device=DEV)
+        prev, cat = cell(s0, s1)
+        assert prev is s1 and tuple(cat.shape) == (1, 24, 12, 18)
+        # reference semantics with torch ops on the same parameters
+        def cbr(mod, z, k):
+            y = F.conv2d(z, mod.conv.weight, padding=(k - 1) // 2)
+            y = F.batch_norm(y, mod.bn.running_mean, mod.bn.running_var, mod.bn.weight, mod.bn.bias)
+            return F.relu(y)
+        t1 = F.interpolate(s1, (12, 18), mode="bilinear", align_corners=True)
+        t0 = F.interpolate(s0, (12, 18), mode="bilinear", align_corners=True)
+        st = [cbr(cell.pre_preprocess, t0, 1), cbr(cell.preprocess, t1, 1)]
+        contribs = cell._contributions()
+        for k in sorted(contribs):
+            st.append(sum(cbr(op, st[j], 3) if isinstance(op, ra.ConvBR_2d) else st[j] for (j, op) in contribs[k]))
+        np.testing.assert_allclose(cat.cpu().numpy(), torch.cat(st[-3:], 1).cpu().numpy(), **TOL)
+
+
 def test_add(ra):
     a, b = torch.randn((2, 6, 3, 5, 7), generator=gen(18)), torch.randn((2, 9, 3, 5, 7), generator=gen(19))
     out = torch.zeros((2, 8, 3, 5, 7), device=DEV)
@@ -342,9 +382,8 @@ def test_matchingnet_plumbing_config_golden(ra):
 
 @pytest.mark.parametrize("name", ["conv_48x96_d48", "unsorted_36x60_d24"])
 def test_network_forward_from_images_golden(ra, name):
-    """Full reference-layout Network (PyTorch Feature Net -> HIP Matching Net) from images vs the reference output.
-    The 2-D Feature Net runs in PyTorch-ROCm (not part of the hot path), so features differ from the CPU ones in
-    the last bits; near-tie pixels may flip -> EPE gate with a looser per-pixel quantile."""
+    """Full reference-layout Network from images vs the reference output: Feature Net and Matching
+    Net both on the HIP kernels."""
     g = load_golden("g5_forward_" + name)
     rows = g["rows"]
     net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=int(g["maxdisp"]))
@@ -355,9 +394,9 @@ def test_network_forward_from_images_golden(ra, name):
         fea = net.feature(gpu(g["left"]), net.arch_init, None)
         sel = [0] * 18
         disp_search = net.search_forward(gpu(g["left"]), gpu(g["right"]), 0, sel)
-    np.testing.assert_allclose(fea.cpu().numpy(), g["left_fea"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(fea.cpu().numpy(), g["left_fea"], rtol=2e-4, atol=2e-4)
     ref = torch.from_numpy(g["disp"])
-    assert O.epe(disp.cpu(), ref) <= 5e-3, O.epe(disp.cpu(), ref)
+    assert O.epe(disp.cpu(), ref) <= EPE_GATE, O.epe(disp.cpu(), ref)
     assert torch.equal(disp, disp_search)      # search_forward with all-zero unit choices == forward(arch_init)
 
 
