@@ -241,6 +241,60 @@ int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int d, int h, 
 int ragmi_disparity_regression_fwd(const void* prob, void* out, int B, int D, int H, int W,
                                    int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training step (BASELINE config 5; the reference runs autograd through the same modules, approaches/rag.py:155-219).
+ * fp32 only.  Data-gradients of the convolutions are the forward kernels applied to the output gradient with the
+ * weight transposed (and its taps flipped); the functions below are the pieces with no forward twin.
+ * Buffers marked (+=) are accumulated into with atomics and must be zeroed by the caller.
+ */
+
+/* sum[c] (+=) sum_{b,v} x[b,c,v];  sumsq[c] (+=) sum x^2  — batch statistics of train-mode BatchNorm3d (operations_3d.py:44) */
+int ragmi_bn_stats_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, void* sum, void* sumsq, void* stream);
+
+/* y[b, y_ch0+c] = act(x[b,c] * scale[c] + shift[c]) (+ res[b, res_ch0+c]) — BN affine + ReLU (+ running sum) as one pass */
+int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* scale, const void* shift, int relu,
+                     const void* res, int64_t res_bstride, int res_ch0,
+                     void* y, int64_t y_bstride, int y_ch0, int B, int C, int64_t DHW, void* stream);
+
+/* g = dy * [x*scale+shift > 0];  sum_g[c] (+=) sum g;  sum_gx[c] (+=) sum g*x   (ReLU + BN backward, reduction half) */
+int ragmi_bn_act_bwd_reduce(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
+                            const void* scale, const void* shift, int relu, int B, int C, int64_t DHW,
+                            void* sum_g, void* sum_gx, void* stream);
+
+/* dx[b,c] = g * c1[c] + x * c2[c] + c3[c]   (train-mode BN backward is linear in g and x per channel; eval BN: c2 = c3 = 0) */
+int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
+                           const void* scale, const void* shift, int relu, const void* c1, const void* c2, const void* c3,
+                           void* dx, int64_t dx_bstride, int B, int C, int64_t DHW, void* stream);
+
+/* dw[co][ci][tap] (+=) sum_{b,v} g[b, g_ch0+co, v] * x[b, ci, v + tap]   — weight gradient of the 3x3x3 conv */
+int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw,
+                          int B, int Cin, int Cout, int D, int H, int W, void* stream);
+
+/* dw[co][ci] (+=) sum_{b,v} g[b, g_ch0+co, v] * x[b, ci, v]   — weight gradient of the 1x1x1 conv */
+int ragmi_conv3d_k1_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw,
+                          int B, int Cin, int Cout, int64_t DHW, void* stream);
+
+/* adjoint of ragmi_trilinear3d_fwd: dx[B,C,Di,Hi,Wi] (+=) scatter of dy[B,C,Do,Ho,Wo] through the same taps */
+int ragmi_trilinear3d_bwd(const void* dy, void* dx, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                          int align_corners, void* stream);
+
+/* adjoint of ragmi_costvol_fwd: dleft/dright [B,C,h,w] from dcost [B,2C,d,h,w] */
+int ragmi_costvol_bwd(const void* dcost, void* dleft, void* dright, int B, int C, int d, int h, int w, void* stream);
+
+/* adjoint of ragmi_disp_softargmin_fwd: dcost[B,d,h,w] (+=) from dout[B,Ho,Wo] (recomputes the softmin statistics) */
+int ragmi_disp_softargmin_bwd(const void* cost, const void* dout, void* dcost, int B, int d, int h, int w,
+                              int maxdisp, int Ho, int Wo, void* stream);
+
+/* backward of ragmi_conv2d_k3_strided_fwd's convolution (Feature-Net stem, operations_2d.py ConvBR_2d stride 3):
+ * dx[B,Cin,H,W] from g[B,Cout,Ho,Wo];  dw[Cout,Cin,3,3] (+=) */
+int ragmi_conv2d_k3_strided_dgrad(const void* g, const void* weight, void* dx, int B, int Cin, int Cout, int H, int W, int stride,
+                                  void* stream);
+int ragmi_conv2d_k3_strided_wgrad(const void* x, const void* g, void* dw, int B, int Cin, int Cout, int H, int W, int stride,
+                                  void* stream);
+
+/* adjoint of ragmi_disparity_regression_fwd: dprob[B,D,H,W] = dout[B,H,W] * d */
+int ragmi_disparity_regression_bwd(const void* dout, void* dprob, int B, int D, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,8 +81,10 @@ def conv_br_3d(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, *, pad
     """ConvBR_3d.forward, operations_3d.py:40-47: conv (no bias) -> BN -> ReLU.
 
     `training=True` uses batch statistics (it does not update running stats here;
-    the oracle is functional).
+    the oracle is functional); a callable `training(prefix) -> bool` decides per unit.
     """
+    if callable(training):      # per-unit mode: "reused" units keep BN in eval during training (approaches/rag.py:159-200)
+        training = bool(training(prefix))
     y = F.conv3d(x, sd[prefix + "conv.weight"], None, stride=1, padding=padding)
     if bn:
         y = F.batch_norm(

@@ -1,6 +1,6 @@
 """rag_amd — MI355X-native (gfx950) implementation of the stereo Matching-Net forward path
 of chzhang18/RAG: cost-volume build -> 3-D conv aggregation -> soft-argmin disparity
-regression, behind the reference's own nn.Module interface (src/models/rag_model.py).
+regression (and its training step), behind the reference's own nn.Module interface (src/models/rag_model.py).
 
 Host code is PyTorch-ROCm (device memory, streams, torch.distributed); all arithmetic on
 the path runs in hand-written HIP kernels reached through the C ABI of
@@ -9,6 +9,7 @@ ops raise if the library is missing.
 """
 from ._lib import lib_path, load_library  # noqa: F401
 from . import ops  # noqa: F401
+from . import autograd  # noqa: F401
 from .modules import (  # noqa: F401
     ALL_CONV_GENOTYPE, ALL_SKIP_GENOTYPE, Cell_3d, ConvBR_3d, Disp, DisparityRegression, Genotype,
     Identity_3d, MatchingNet, OPS_3d, PRIMITIVES_3D,

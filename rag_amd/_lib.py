@@ -62,6 +62,22 @@ SIGNATURES = {
                                             c_int, c_int, c_void_p]),
     "ragmi_add_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
                               c_int, c_int, c_int64, c_int, c_void_p]),
+    "ragmi_bn_stats_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "ragmi_bn_act_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
+                                 c_int, c_int, c_int64, c_void_p]),
+    "ragmi_bn_act_bwd_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
+                                        c_void_p, c_void_p, c_void_p]),
+    "ragmi_bn_act_bwd_apply": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "ragmi_conv3d_k3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
+    "ragmi_conv3d_k1_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
+    "ragmi_trilinear3d_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_costvol_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv2d_k3_strided_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv2d_k3_strided_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_disparity_regression_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_disp_softargmin_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_disp_softargmin_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_void_p]),
     "ragmi_disparity_regression_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

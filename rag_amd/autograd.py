@@ -1,0 +1,242 @@
+"""Training step of the Matching-Net path on the HIP kernels (BASELINE config 5).
+
+The reference trains by running PyTorch autograd through the very modules it infers with
+(approaches/rag.py:155-219: `model.train()`, reused units `.eval()`, smooth-L1, `loss.backward()`).
+Here every node of that graph is a `torch.autograd.Function` whose forward AND backward enqueue the
+hand-written kernels of librag_amd.so; autograd only orders the calls.  No ATen convolution,
+batch-norm, interpolate or softmax runs: if the library is missing these raise, there is no fallback.
+
+    ConvBRFn      conv (3x3x3 MFMA kernel / 1x1x1) -> BatchNorm (batch or running statistics) -> ReLU
+                  backward: ReLU+BN adjoint (reduce + apply), data gradient = the forward conv kernel on the
+                  output gradient with the weight transposed and its taps flipped, weight gradient kernels
+    StridedStemFn the Feature Net's stride-3 2-D stem, same structure
+    TrilinearFn   F.interpolate(mode='trilinear') and its scatter adjoint
+    CostVolFn     the concat-and-shift cost volume and its gather adjoint
+    DispFn        fused upsample x3 -> softmin -> expectation and its adjoint
+    AddFn         sum of two branch outputs
+
+Per-channel BatchNorm bookkeeping (mean/var -> scale/shift, the three backward coefficients, running-stat
+updates) is host-side arithmetic on [C]-sized vectors, like the eval-mode folding in modules._ConvBR.prepared.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from . import ops
+
+
+def _dense(t: torch.Tensor) -> torch.Tensor:
+    """Channel planes dense (a channel-slice view of a contiguous buffer qualifies); copy otherwise."""
+    inner = 1
+    for i in range(t.dim() - 1, 0, -1):
+        if t.shape[i] != 1 and t.stride(i) != inner:
+            return t.contiguous()
+        inner *= t.shape[i]
+    return t
+
+
+def _vol(t: torch.Tensor) -> int:
+    n = 1
+    for s in t.shape[2:]:
+        n *= s
+    return n
+
+
+class ConvBRFn(torch.autograd.Function):
+    """y = act(bn(conv(x))) for the stride-1 'same' 1x1x1 / 3x3x3 ConvBR (operations_3d.py:40-47) on 5-D volumes
+    (the 2-D flavour runs on depth-1 volumes with its 3x3 weight embedded in the middle z-slice)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mod):
+        k = mod._geometry()
+        x = _dense(x)
+        B, cout = x.shape[0], weight.shape[0]
+        w5 = mod.weight5(weight.detach())
+        raw = torch.empty((B, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+        if k == 3:
+            ops.conv3d_k3(x, ops.conv3d_k3_pack(w5), cout, None, None, False, raw)
+        else:
+            ops.conv3d_k1(x, w5.reshape(cout, -1).contiguous(), None, None, False, raw)
+        n = B * _vol(x)
+        scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
+        y = ops.bn_act(raw, scale, shift, mod.relu) if (mod.use_bn or mod.relu) else raw
+        ctx.mod, ctx.k, ctx.n, ctx.training = mod, k, n, training
+        ctx.save_for_backward(x, weight, raw, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, raw, scale, shift, mean, invstd = ctx.saved_tensors
+        mod, k, n = ctx.mod, ctx.k, ctx.n
+        need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
+        draw, dgamma, dbeta = _bn_backward(_dense(dy), raw, scale, shift, mean, invstd, mod, n, ctx.training, need_g, need_b)
+        dx = dw = None
+        w5 = mod.weight5(weight.detach())
+        cout, cin = w5.shape[:2]
+        if need_x:
+            dx = torch.empty_like(x)
+            if k == 3:
+                wt = w5.transpose(0, 1).flip(2, 3, 4).contiguous()
+                ops.conv3d_k3(draw, ops.conv3d_k3_pack(wt), cin, None, None, False, dx)
+            else:
+                ops.conv3d_k1(draw, w5.reshape(cout, cin).t().contiguous(), None, None, False, dx)
+        if need_w:
+            if k == 3:
+                dw5 = ops.conv3d_k3_wgrad(x, draw, cout)
+                dw = (dw5[:, :, 1] if mod.NDIM == 2 else dw5).reshape(weight.shape)
+            else:
+                dw = ops.conv3d_k1_wgrad(x, draw, cout).reshape(weight.shape)
+        return dx, dw, dgamma, dbeta, None
+
+
+def _bn_forward(raw, n, gamma, beta, mod):
+    """Shared BatchNorm bookkeeping of the ConvBR forwards: (scale, shift, mean, invstd, training)."""
+    bn = mod.bn
+    cout = raw.shape[1]
+    if not mod.use_bn:
+        return torch.ones(cout, device=raw.device), torch.zeros(cout, device=raw.device), None, None, False
+    training = bool(bn.training)
+    g, b = gamma.detach().float(), beta.detach().float()
+    if training:
+        s, q = ops.bn_stats(raw)
+        mean = s / n
+        var = (q / n - mean * mean).clamp_min_(0.0)
+        with torch.no_grad():                                   # nn.BatchNorm running statistics (momentum form)
+            if bn.track_running_stats and bn.running_mean is not None:
+                bn.num_batches_tracked += 1
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+    else:
+        mean, var = bn.running_mean.detach().float(), bn.running_var.detach().float()
+    invstd = torch.rsqrt(var + bn.eps)
+    scale = (g * invstd).contiguous()
+    shift = (b - mean * scale).contiguous()
+    return scale, shift, mean, invstd, training
+
+
+def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, need_b):
+    """ReLU + BatchNorm adjoint: (gradient w.r.t. the raw conv output, dgamma, dbeta)."""
+    if not (mod.use_bn or mod.relu):
+        return dy, None, None
+    dgamma = dbeta = None
+    zeros = torch.zeros_like(scale)
+    if mod.use_bn and (training or need_g or need_b):
+        sg, sgx = ops.bn_act_bwd_reduce(dy, 0, raw, scale, shift, mod.relu)
+        sgxh = invstd * (sgx - mean * sg)                       # sum of g * xhat
+        dgamma, dbeta = (sgxh if need_g else None), (sg if need_b else None)
+    if training:
+        # dx = a (g - mean(g) - xhat mean(g xhat)), a = gamma * invstd: linear in g and x per channel
+        mg, mgxh = sg / n, sgxh / n
+        c1 = scale
+        c2 = (-scale * invstd * mgxh).contiguous()
+        c3 = (scale * (invstd * mean * mgxh - mg)).contiguous()
+    else:
+        c1, c2, c3 = scale, zeros, zeros
+    return ops.bn_act_bwd_apply(dy, 0, raw, scale, shift, mod.relu, c1, c2, c3), dgamma, dbeta
+
+
+class StridedStemFn(torch.autograd.Function):
+    """The Feature Net's strided 2-D 3x3 ConvBR (rag_model.py:200, stride 3) on 4-D tensors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mod):
+        x = x.contiguous()
+        stride = mod.conv.stride[0]
+        raw = ops.conv2d_k3_strided(x, weight.detach(), None, None, False, stride)
+        n = raw.shape[0] * _vol(raw)
+        scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
+        y = ops.bn_act(raw, scale, shift, mod.relu) if (mod.use_bn or mod.relu) else raw
+        ctx.mod, ctx.n, ctx.training, ctx.stride = mod, n, training, stride
+        ctx.save_for_backward(x, weight, raw, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, raw, scale, shift, mean, invstd = ctx.saved_tensors
+        need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
+        draw, dgamma, dbeta = _bn_backward(_dense(dy), raw, scale, shift, mean, invstd, ctx.mod, ctx.n, ctx.training, need_g, need_b)
+        dx = ops.conv2d_k3_strided_dgrad(draw, weight, x.shape[2:], ctx.stride) if need_x else None
+        dw = ops.conv2d_k3_strided_wgrad(x, draw, ctx.stride) if need_w else None
+        return dx, dw, dgamma, dbeta, None
+
+
+class DispRegFn(torch.autograd.Function):
+    """DisparityRegression.forward (rag_model.py:23-29)."""
+
+    @staticmethod
+    def forward(ctx, prob, maxdisp):
+        ctx.maxdisp = maxdisp
+        return ops.disparity_regression(prob, maxdisp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.disparity_regression_bwd(dout, ctx.maxdisp), None
+
+
+class TrilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='trilinear', align_corners=...) (rag_model.py:146-153, 355-362)."""
+
+    @staticmethod
+    def forward(ctx, x, size, align_corners):
+        ctx.in_size, ctx.align = tuple(x.shape[2:]), bool(align_corners)
+        return ops.trilinear3d(x, size, align_corners)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.trilinear3d_bwd(dy, ctx.in_size, ctx.align), None, None
+
+
+class CostVolFn(torch.autograd.Function):
+    """The cost-volume loop of rag_model.py:375-383 (backward: the 128 CopySlices nodes as one gather kernel)."""
+
+    @staticmethod
+    def forward(ctx, left_fea, right_fea, maxdisp):
+        return ops.costvol(left_fea, right_fea, maxdisp)
+
+    @staticmethod
+    def backward(ctx, dcost):
+        dl, dr = ops.costvol_bwd(dcost)
+        return dl, dr, None
+
+
+class DispFn(torch.autograd.Function):
+    """Disp.forward (rag_model.py:39-44) fused; backward recomputes the softmin statistics."""
+
+    @staticmethod
+    def forward(ctx, cost, maxdisp):
+        ctx.save_for_backward(cost)
+        ctx.maxdisp = maxdisp
+        return ops.disp_softargmin(cost, maxdisp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (cost,) = ctx.saved_tensors
+        return ops.disp_softargmin_bwd(cost, dout, ctx.maxdisp), None
+
+
+class AddFn(torch.autograd.Function):
+    """a + b (the `sum(new_states)` of Cell_3d, rag_model.py:172)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _dense(a), _dense(b)
+        out = torch.empty(a.shape, device=a.device, dtype=a.dtype)
+        return ops.add(a, 0, b, 0, out, 0, a.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def resample(x: torch.Tensor, size: Sequence[int], align_corners: bool = True) -> torch.Tensor:
+    size = tuple(int(v) for v in size)
+    if tuple(x.shape[2:]) == size:
+        return x
+    return TrilinearFn.apply(x, size, align_corners)

@@ -1,0 +1,494 @@
+// Training-step kernels of the Matching-Net path (BASELINE config 5; reference: approaches/rag.py:155-219 drives
+// autograd through ConvBR_3d = Conv3d -> BatchNorm3d(train) -> ReLU, operations_3d.py:40-47, F.interpolate, the cost
+// loop and Disp).  Data-gradients of the convolutions reuse the forward kernels with transposed / flipped weights;
+// this file holds what has no forward twin: batch statistics, the BN+ReLU affine pass and its backward, the weight
+// gradients, and the adjoints of resampling, cost volume and soft-argmin.  fp32 only (training runs in fp32).
+#include "common.h"
+
+namespace ragmi {
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-channel sum / sum of squares of x[B, C, DHW] (batch stride in elements; channel planes dense)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t dhw,
+                                                       float* __restrict__ sum, float* __restrict__ sumsq) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* p = x + b * x_bstride + (int64_t)c * dhw;
+  float s = 0.f, q = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < dhw; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < dhw && (dhw & 3) == 0) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    } else {
+      for (int k = 0; k < 4 && i + k < dhw; ++k) { const float v = p[i + k]; s += v; q += v * v; }
+    }
+  }
+  __shared__ float rs[256], rq[256];
+  rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rq[threadIdx.x] += rq[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(sum + c, rs[0]); atomicAdd(sumsq + c, rq[0]); }
+}
+
+// y[b, y_ch0 + c] = act(x[b, c] * scale[c] + shift[c]) (+ res[b, res_ch0 + c])
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, int64_t x_bstride, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int relu, const float* __restrict__ res,
+                                                     int64_t res_bstride, int res_ch0, float* __restrict__ y, int64_t y_bstride,
+                                                     int y_ch0, int64_t dhw) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= dhw) return;
+  float v = fmaf(x[b * x_bstride + (int64_t)c * dhw + i], scale[c], shift[c]);
+  if (relu) v = fmaxf(v, 0.f);
+  if (res) v += res[b * res_bstride + (int64_t)(res_ch0 + c) * dhw + i];
+  y[b * y_bstride + (int64_t)(y_ch0 + c) * dhw + i] = v;
+}
+
+// g = dy * (x*scale+shift > 0 if relu);  sum_g[c] += sum g;  sum_gx[c] += sum g*x
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dy, int64_t dy_bstride, int dy_ch0,
+                                                                const float* __restrict__ x, int64_t x_bstride,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                int relu, int64_t dhw, float* __restrict__ sum_g,
+                                                                float* __restrict__ sum_gx) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* pd = dy + b * dy_bstride + (int64_t)(dy_ch0 + c) * dhw;
+  const float* px = x + b * x_bstride + (int64_t)c * dhw;
+  const float sc = scale[c], sh = shift[c];
+  float s = 0.f, q = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dhw; i += (int64_t)gridDim.x * 256) {
+    const float xv = px[i];
+    float g = pd[i];
+    if (relu && fmaf(xv, sc, sh) <= 0.f) g = 0.f;
+    s += g;
+    q = fmaf(g, xv, q);
+  }
+  __shared__ float rs[256], rq[256];
+  rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rq[threadIdx.x] += rq[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(sum_g + c, rs[0]); atomicAdd(sum_gx + c, rq[0]); }
+}
+
+// dx[b, c] = g * c1[c] + x * c2[c] + c3[c]   (train-mode BN backward is linear in g and x per channel; eval: c2 = c3 = 0)
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ dy, int64_t dy_bstride, int dy_ch0,
+                                                               const float* __restrict__ x, int64_t x_bstride,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               int relu, const float* __restrict__ c1, const float* __restrict__ c2,
+                                                               const float* __restrict__ c3, float* __restrict__ dx,
+                                                               int64_t dx_bstride, int64_t dhw) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= dhw) return;
+  const float xv = x[b * x_bstride + (int64_t)c * dhw + i];
+  float g = dy[b * dy_bstride + (int64_t)(dy_ch0 + c) * dhw + i];
+  if (relu && fmaf(xv, scale[c], shift[c]) <= 0.f) g = 0.f;
+  dx[b * dx_bstride + (int64_t)c * dhw + i] = fmaf(g, c1[c], fmaf(xv, c2[c], c3[c]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3x3 convolution: dw[co][ci][tap] += sum_v g[co][v] * x[ci][v + tap].
+// A workgroup owns a 4 x 8 x 32 voxel tile: it stages the x halo of 4 input channels and the g tile of up to 16
+// output channels in LDS (8 per pass over blockIdx.z); thread t owns the (co, ci, tap) triples t, t+256, ... of this chunk and walks the tile's
+// voxels (LDS-bound, correctness-first form: ~6x the forward's time); one float atomic per triple per workgroup.
+constexpr int WG_TZ = 4, WG_TY = 8, WG_TX = 32, WG_CI = 4, WG_CO = 8;   // LDS: 32.6 KB (x halo) + 32 KB (g tile) < 64 KB static
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad_kernel(const float* __restrict__ x, int64_t x_bstride, const float* __restrict__ g,
+                                                              int64_t g_bstride, int g_ch0, float* __restrict__ dw, int Cin, int Cout,
+                                                              int D, int H, int W, int tiles_x, int tiles_y, int tiles_z) {
+  constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, NV = WG_TZ * WG_TY * WG_TX;
+  __shared__ float xs[WG_CI][HZ][HY][HX];     // 32.6 KB
+  __shared__ float gs[WG_CO][NV];             // 32 KB
+  int bid = blockIdx.x;
+  const int tx_i = bid % tiles_x; bid /= tiles_x;
+  const int ty_i = bid % tiles_y; bid /= tiles_y;
+  const int tz_i = bid % tiles_z;
+  const int b = bid / tiles_z;
+  const int x0 = tx_i * WG_TX, y0 = ty_i * WG_TY, z0 = tz_i * WG_TZ;
+  const int ci0 = blockIdx.y * WG_CI, co0 = blockIdx.z * WG_CO;
+  const int64_t HW = (int64_t)H * W, DHW = HW * D;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < WG_CI * HZ * HY * HX; e += 256) {
+    const int xx = e % HX, yy = (e / HX) % HY, zz = (e / (HX * HY)) % HZ, c = e / (HX * HY * HZ);
+    const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx, gc = ci0 + c;
+    const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && gc < Cin;
+    xs[c][zz][yy][xx] = ok ? x[b * x_bstride + gc * DHW + gz * HW + (int64_t)gy * W + gx] : 0.f;
+  }
+  for (int e = tid; e < WG_CO * NV; e += 256) {
+    const int v = e % NV, c = e / NV;
+    const int xx = v % WG_TX, yy = (v / WG_TX) % WG_TY, zz = v / (WG_TX * WG_TY);
+    const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx, gc = co0 + c;
+    const bool ok = gz < D && gy < H && gx < W && gc < Cout;
+    gs[c][v] = ok ? g[b * g_bstride + (int64_t)(g_ch0 + gc) * DHW + gz * HW + (int64_t)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  const int nco = min(WG_CO, Cout - co0), nci = min(WG_CI, Cin - ci0);
+  for (int tr = tid; tr < nco * nci * 27; tr += 256) {
+    const int tap = tr % 27, ci = (tr / 27) % nci, co = tr / (27 * nci);
+    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    float acc = 0.f;
+    for (int zz = 0; zz < WG_TZ; ++zz)
+      for (int yy = 0; yy < WG_TY; ++yy) {
+        const float* xr = &xs[ci][zz + dz][yy + dy][dx];
+        const float* gr = &gs[co][(zz * WG_TY + yy) * WG_TX];
+#pragma unroll 8
+        for (int xx = 0; xx < WG_TX; ++xx) acc = fmaf(gr[xx], xr[xx], acc);
+      }
+    atomicAdd(dw + ((int64_t)(co0 + co) * Cin + ci0 + ci) * 27 + tap, acc);
+  }
+}
+
+// dw[co][ci] += sum_v g[co][v] * x[ci][v]   (1x1x1 conv); one workgroup per (voxel slab, co), threads over ci x voxels
+__global__ __launch_bounds__(256) void conv3d_k1_wgrad_kernel(const float* __restrict__ x, int64_t x_bstride, const float* __restrict__ g,
+                                                              int64_t g_bstride, int g_ch0, float* __restrict__ dw, int Cin, int Cout,
+                                                              int64_t dhw) {
+  const int co = blockIdx.y, b = blockIdx.z;
+  const float* pg = g + b * g_bstride + (int64_t)(g_ch0 + co) * dhw;
+  __shared__ float red[256];
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* px = x + b * x_bstride + (int64_t)ci * dhw;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dhw; i += (int64_t)gridDim.x * 256) acc = fmaf(pg[i], px[i], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(dw + (int64_t)co * Cin + ci, red[0]);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// adjoint of the trilinear resample: dx (pre-zeroed) += scatter of dy through the same 8 (index, weight) pairs
+struct TriBwdArgs {
+  const float* dy;
+  float* dx;
+  int C, Di, Hi, Wi, Do, Ho, Wo;
+  float sd, sh, sw;
+  int align;
+};
+__global__ __launch_bounds__(256) void trilinear_bwd_kernel(TriBwdArgs a) {
+  const int64_t ovol = (int64_t)a.Do * a.Ho * a.Wo;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= ovol) return;
+  const int b = blockIdx.y;
+  const int ox = (int)(o % a.Wo);
+  const int64_t t = o / a.Wo;
+  const int oy = (int)(t % a.Ho), oz = (int)(t / a.Ho);
+  const LinIdx lz = lin_index(oz, a.Di, a.Do, a.sd, a.align);
+  const LinIdx ly = lin_index(oy, a.Hi, a.Ho, a.sh, a.align);
+  const LinIdx lx = lin_index(ox, a.Wi, a.Wo, a.sw, a.align);
+  const int64_t ivol = (int64_t)a.Di * a.Hi * a.Wi;
+  const int zi[2] = {lz.i0, lz.i1}, yi[2] = {ly.i0, ly.i1}, xi[2] = {lx.i0, lx.i1};
+  const float zw[2] = {lz.w0, lz.w1}, yw[2] = {ly.w0, ly.w1}, xw[2] = {lx.w0, lx.w1};
+  for (int c = 0; c < a.C; ++c) {
+    const float gv = a.dy[((int64_t)b * a.C + c) * ovol + o];
+    float* pc = a.dx + ((int64_t)b * a.C + c) * ivol;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int kz = k >> 2, ky = (k >> 1) & 1, kx = k & 1;
+      const float w = zw[kz] * yw[ky] * xw[kx];
+      if (w != 0.f) atomicAdd(pc + ((int64_t)zi[kz] * a.Hi + yi[ky]) * a.Wi + xi[kx], gv * w);
+    }
+  }
+}
+
+// adjoint of the cost volume: dL[c,y,x] = sum_{i<=x} dcost[c,i,y,x];  dR[c,y,x] = sum_{i, x+i<w} dcost[C+c,i,y,x+i]
+__global__ __launch_bounds__(256) void costvol_bwd_kernel(const float* __restrict__ dcost, float* __restrict__ dL, float* __restrict__ dR,
+                                                          int C, int d, int h, int w) {
+  const int64_t hw = (int64_t)h * w;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int x = (int)(p % w);
+  const float* pl = dcost + (((int64_t)b * 2 * C + c) * d) * hw + p;
+  const float* pr = dcost + (((int64_t)b * 2 * C + C + c) * d) * hw + p;
+  float sl = 0.f, sr = 0.f;
+  for (int i = 0; i < d; ++i) {
+    if (i <= x) sl += pl[(int64_t)i * hw];
+    if (x + i < w) sr += pr[(int64_t)i * hw + i];
+  }
+  dL[((int64_t)b * C + c) * hw + p] = sl;
+  dR[((int64_t)b * C + c) * hw + p] = sr;
+}
+
+// adjoint of the fused Disp: out = sum_d p_d * d with p = softmin over the upsampled cost.
+// d out / d v_d = -p_d (d - out); v_d = trilinear taps of the coarse cost -> scatter (dcost pre-zeroed).
+struct DispBwdArgs {
+  const float* cost;
+  const float* dout;
+  float* dcost;
+  int d, h, w, maxdisp, Ho, Wo;
+  float sd, sh, sw;
+};
+__global__ __launch_bounds__(256) void disp_softargmin_bwd_kernel(DispBwdArgs a) {
+  const int64_t npix = (int64_t)a.Ho * a.Wo;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= npix) return;
+  const int b = blockIdx.y;
+  const int ox = (int)(o % a.Wo), oy = (int)(o / a.Wo);
+  const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
+  const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
+  const int hw = a.h * a.w;
+  const float* base = a.cost + (int64_t)b * a.d * hw;
+  float* gbase = a.dcost + (int64_t)b * a.d * hw;
+  const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1, o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
+  const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
+  auto plane = [&](int z) -> float {
+    const float* p = base + (int64_t)z * hw;
+    return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
+  };
+  // pass 1: softmax statistics (max, sum, expectation), exactly as the forward
+  float m = -INFINITY, s = 0.f, ws = 0.f;
+  for (int dd = 0; dd < a.maxdisp; ++dd) {
+    const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
+    const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
+    const float mn = fmaxf(m, t);
+    const float r = expf(m - mn), e = expf(t - mn);
+    s = s * r + e;
+    ws = ws * r + e * (float)dd;
+    m = mn;
+  }
+  const float outv = ws / s, gout = a.dout[(int64_t)b * npix + o];
+  // pass 2: walk the fine samples again; a0 / a1 collect the gradient of coarse planes z / z+1 and are flushed with
+  // 4 atomics each when the walk moves on (instead of 8 atomics per fine sample)
+  auto flush = [&](int z, float gv) {
+    if (gv == 0.f) return;
+    float* p = gbase + (int64_t)z * hw;
+    atomicAdd(p + o00, gv * w00); atomicAdd(p + o01, gv * w01); atomicAdd(p + o10, gv * w10); atomicAdd(p + o11, gv * w11);
+  };
+  int z = 0;
+  float a0 = 0.f, a1 = 0.f;
+  for (int dd = 0; dd < a.maxdisp; ++dd) {
+    const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
+    const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
+    const float pd = expf(t - m) / s;
+    const float gv = -gout * pd * ((float)dd - outv);   // d out / d v_fine, v = +cost (softMIN)
+    while (lz.i0 > z) { flush(z, a0); a0 = a1; a1 = 0.f; ++z; }
+    a0 = fmaf(gv, lz.w0, a0);
+    if (lz.i1 != lz.i0) a1 = fmaf(gv, lz.w1, a1); else a0 = fmaf(gv, lz.w1, a0);
+  }
+  flush(z, a0);
+  if (z + 1 < a.d) flush(z + 1, a1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Feature-Net stem (2-D 3x3, pad 1, stride s): data gradient as a gather, weight gradient as a blocked reduction.
+// dx[b,ci,y,x] = sum_{co,ky,kx : (y+1-ky) % s == 0, (x+1-kx) % s == 0} g[b,co,(y+1-ky)/s,(x+1-kx)/s] * w[co,ci,ky,kx]
+__global__ __launch_bounds__(256) void conv2d_strided_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                                   float* __restrict__ dx, int Cin, int Cout, int H, int W, int Ho,
+                                                                   int Wo, int s) {
+  const int64_t pix = (int64_t)H * W, opix = (int64_t)Ho * Wo;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pix) return;
+  const int ci = blockIdx.y, b = blockIdx.z;
+  const int y = (int)(p / W), x = (int)(p % W);
+  float acc = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = y + 1 - ky;
+    if (ty < 0 || ty % s != 0 || ty / s >= Ho) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = x + 1 - kx;
+      if (tx < 0 || tx % s != 0 || tx / s >= Wo) continue;
+      const float* pg = g + (int64_t)b * Cout * opix + (int64_t)(ty / s) * Wo + tx / s;
+      for (int co = 0; co < Cout; ++co) acc = fmaf(pg[co * opix], w[((co * Cin + ci) * 3 + ky) * 3 + kx], acc);
+    }
+  }
+  dx[((int64_t)b * Cin + ci) * pix + p] = acc;
+}
+
+// dw[co,ci,ky,kx] += sum_{b,oy,ox} g[b,co,oy,ox] * x[b,ci,oy*s-1+ky,ox*s-1+kx];  blockIdx.y = co*Cin+ci, blockIdx.x = pixel slab
+__global__ __launch_bounds__(256) void conv2d_strided_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                   float* __restrict__ dw, int B, int Cin, int Cout, int H, int W,
+                                                                   int Ho, int Wo, int s) {
+  const int co = blockIdx.y / Cin, ci = blockIdx.y % Cin;
+  const int64_t opix = (int64_t)Ho * Wo, total = opix * B;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int b = (int)(e / opix);
+    const int64_t o = e % opix;
+    const int oy = (int)(o / Wo), ox = (int)(o % Wo);
+    const float gv = g[((int64_t)b * Cout + co) * opix + o];
+    const float* px = x + ((int64_t)b * Cin + ci) * H * W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = oy * s - 1 + t / 3, ix = ox * s - 1 + t % 3;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) acc[t] = fmaf(gv, px[(int64_t)iy * W + ix], acc[t]);
+    }
+  }
+  __shared__ float red[9][256];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = acc[t];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) atomicAdd(dw + (int64_t)blockIdx.y * 9 + threadIdx.x, red[threadIdx.x][0]);
+}
+
+// adjoint of DisparityRegression: dprob[b,d,y,x] = dout[b,y,x] * d
+__global__ __launch_bounds__(256) void disparity_regression_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dprob, int D,
+                                                                       int64_t hw) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int b = blockIdx.y;
+  const float gv = dout[(int64_t)b * hw + p];
+  for (int d = 0; d < D; ++d) dprob[((int64_t)b * D + d) * hw + p] = gv * (float)d;
+}
+
+}  // namespace ragmi
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int ragmi_bn_stats_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, void* sum, void* sumsq, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && sum && sumsq, RAGMI_EINVAL, "bn_stats: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_stats: bad size");
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(DHW, 1024), 256);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)x, x_bstride, DHW,
+                     (float*)sum, (float*)sumsq);
+  return check_launch("bn_stats");
+}
+
+extern "C" int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* scale, const void* shift, int relu, const void* res,
+                                int64_t res_bstride, int res_ch0, void* y, int64_t y_bstride, int y_ch0, int B, int C, int64_t DHW,
+                                void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && scale && shift && y, RAGMI_EINVAL, "bn_act: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act: bad size");
+  hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)ceil_div(DHW, 256), C, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const float*)x, x_bstride, (const float*)scale, (const float*)shift, relu, (const float*)res, res_bstride, res_ch0,
+                     (float*)y, y_bstride, y_ch0, DHW);
+  return check_launch("bn_act");
+}
+
+extern "C" int ragmi_bn_act_bwd_reduce(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
+                                       const void* scale, const void* shift, int relu, int B, int C, int64_t DHW, void* sum_g,
+                                       void* sum_gx, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(dy && x && scale && shift && sum_g && sum_gx, RAGMI_EINVAL, "bn_act_bwd_reduce: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act_bwd_reduce: bad size");
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(DHW, 256), 256);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(gx, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)dy,
+                     dy_bstride, dy_ch0, (const float*)x, x_bstride, (const float*)scale, (const float*)shift, relu, DHW, (float*)sum_g,
+                     (float*)sum_gx);
+  return check_launch("bn_act_bwd_reduce");
+}
+
+extern "C" int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
+                                      const void* scale, const void* shift, int relu, const void* c1, const void* c2, const void* c3,
+                                      void* dx, int64_t dx_bstride, int B, int C, int64_t DHW, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(dy && x && scale && shift && c1 && c2 && c3 && dx, RAGMI_EINVAL, "bn_act_bwd_apply: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act_bwd_apply: bad size");
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)ceil_div(DHW, 256), C, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const float*)dy, dy_bstride, dy_ch0, (const float*)x, x_bstride, (const float*)scale, (const float*)shift, relu,
+                     (const float*)c1, (const float*)c2, (const float*)c3, (float*)dx, dx_bstride, DHW);
+  return check_launch("bn_act_bwd_apply");
+}
+
+extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw, int B,
+                                     int Cin, int Cout, int D, int H, int W, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && g && dw, RAGMI_EINVAL, "conv3d_k3_wgrad: null pointer");
+  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, RAGMI_EINVAL, "conv3d_k3_wgrad: bad size");
+  const int tx = (int)ceil_div(W, WG_TX), ty = (int)ceil_div(H, WG_TY), tz = (int)ceil_div(D, WG_TZ);
+  const int64_t nblk = (int64_t)tx * ty * tz * B;
+  RAGMI_REQUIRE(nblk < (1ll << 31) && ceil_div(Cin, WG_CI) <= 65535 && ceil_div(Cout, WG_CO) <= 65535, RAGMI_EUNSUPPORTED,
+                "conv3d_k3_wgrad: grid too large");
+  hipLaunchKernelGGL(conv3d_k3_wgrad_kernel, dim3((unsigned)nblk, (unsigned)ceil_div(Cin, WG_CI), (unsigned)ceil_div(Cout, WG_CO)), dim3(256),
+                     0, static_cast<hipStream_t>(stream), (const float*)x, x_bstride, (const float*)g, g_bstride, g_ch0, (float*)dw, Cin,
+                     Cout, D, H, W, tx, ty, tz);
+  return check_launch("conv3d_k3_wgrad");
+}
+
+extern "C" int ragmi_conv3d_k1_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw, int B,
+                                     int Cin, int Cout, int64_t DHW, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && g && dw, RAGMI_EINVAL, "conv3d_k1_wgrad: null pointer");
+  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && DHW > 0 && B <= 65535 && Cout <= 65535, RAGMI_EINVAL, "conv3d_k1_wgrad: bad size");
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(DHW, 1024), 128);
+  hipLaunchKernelGGL(conv3d_k1_wgrad_kernel, dim3(gx, Cout, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)x, x_bstride,
+                     (const float*)g, g_bstride, g_ch0, (float*)dw, Cin, Cout, DHW);
+  return check_launch("conv3d_k1_wgrad");
+}
+
+extern "C" int ragmi_trilinear3d_bwd(const void* dy, void* dx, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                     int align_corners, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(dy && dx, RAGMI_EINVAL, "trilinear3d_bwd: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && B <= 65535, RAGMI_EINVAL,
+                "trilinear3d_bwd: bad size");
+  TriBwdArgs a{(const float*)dy, (float*)dx, C, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do, align_corners),
+               lin_scale(Hi, Ho, align_corners), lin_scale(Wi, Wo, align_corners), align_corners ? 1 : 0};
+  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Do * Ho * Wo, 256), B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return check_launch("trilinear3d_bwd");
+}
+
+extern "C" int ragmi_costvol_bwd(const void* dcost, void* dleft, void* dright, int B, int C, int d, int h, int w, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(dcost && dleft && dright, RAGMI_EINVAL, "costvol_bwd: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && d > 0 && h > 0 && w > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "costvol_bwd: bad size");
+  hipLaunchKernelGGL(costvol_bwd_kernel, dim3((unsigned)ceil_div((int64_t)h * w, 256), C, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const float*)dcost, (float*)dleft, (float*)dright, C, d, h, w);
+  return check_launch("costvol_bwd");
+}
+
+extern "C" int ragmi_disp_softargmin_bwd(const void* cost, const void* dout, void* dcost, int B, int d, int h, int w, int maxdisp,
+                                         int Ho, int Wo, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(cost && dout && dcost, RAGMI_EINVAL, "disp_softargmin_bwd: null pointer");
+  RAGMI_REQUIRE(B > 0 && d > 0 && h > 0 && w > 0 && maxdisp > 0 && Ho > 0 && Wo > 0 && B <= 65535, RAGMI_EINVAL,
+                "disp_softargmin_bwd: bad size");
+  DispBwdArgs a{(const float*)cost, (const float*)dout, (float*)dcost, d, h, w, maxdisp, Ho, Wo,
+                lin_scale(d, maxdisp, 0), lin_scale(h, Ho, 0), lin_scale(w, Wo, 0)};
+  hipLaunchKernelGGL(disp_softargmin_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Ho * Wo, 256), B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return check_launch("disp_softargmin_bwd");
+}
+
+extern "C" int ragmi_conv2d_k3_strided_dgrad(const void* g, const void* weight, void* dx, int B, int Cin, int Cout, int H, int W,
+                                             int stride, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(g && weight && dx, RAGMI_EINVAL, "conv2d_k3_strided_dgrad: null pointer");
+  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && stride >= 1 && B <= 65535 && Cin <= 65535, RAGMI_EINVAL,
+                "conv2d_k3_strided_dgrad: bad size");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  hipLaunchKernelGGL(conv2d_strided_dgrad_kernel, dim3((unsigned)ceil_div((int64_t)H * W, 256), Cin, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const float*)g, (const float*)weight, (float*)dx, Cin, Cout, H, W, Ho, Wo, stride);
+  return check_launch("conv2d_k3_strided_dgrad");
+}
+
+extern "C" int ragmi_conv2d_k3_strided_wgrad(const void* x, const void* g, void* dw, int B, int Cin, int Cout, int H, int W, int stride,
+                                             void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && g && dw, RAGMI_EINVAL, "conv2d_k3_strided_wgrad: null pointer");
+  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && stride >= 1 && (int64_t)Cin * Cout <= 65535, RAGMI_EINVAL,
+                "conv2d_k3_strided_wgrad: bad size");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div((int64_t)B * Ho * Wo, 1024), 64);
+  hipLaunchKernelGGL(conv2d_strided_wgrad_kernel, dim3(gx, Cin * Cout), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)x,
+                     (const float*)g, (float*)dw, B, Cin, Cout, H, W, Ho, Wo, stride);
+  return check_launch("conv2d_k3_strided_wgrad");
+}
+
+extern "C" int ragmi_disparity_regression_bwd(const void* dout, void* dprob, int B, int D, int H, int W, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(dout && dprob, RAGMI_EINVAL, "disparity_regression_bwd: null pointer");
+  RAGMI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && B <= 65535, RAGMI_EINVAL, "disparity_regression_bwd: bad size");
+  hipLaunchKernelGGL(disparity_regression_bwd_kernel, dim3((unsigned)ceil_div((int64_t)H * W, 256), B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const float*)dout, (float*)dprob, D, (int64_t)H * W);
+  return check_launch("disparity_regression_bwd");
+}

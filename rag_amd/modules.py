@@ -9,8 +9,11 @@ PyTorch: every forward below enqueues hand-written HIP kernels through ``rag_amd
 New seam (named by BASELINE.json north_star; the reference inlines it in Network.forward,
 rag_model.py:375-386): ``MatchingNet.forward(left_fea, right_fea) -> disp[B, 3h, 3w]``.
 
-Round-1 scope: inference (eval-mode BatchNorm, no autograd).  Train-mode BN / backward
-raise NotImplementedError rather than falling back to PyTorch.
+Two execution modes, both on the HIP kernels, neither with a PyTorch fallback:
+  * inference (``torch.no_grad()`` + eval-mode BatchNorm): the fused executor below (folded BN, concat-free cells,
+    dual-input launches, cross-module tails);
+  * training (autograd enabled and something requires grad, or a BatchNorm in train mode): the same modules compose
+    the ``rag_amd.autograd`` Functions node by node like the reference's graph (approaches/rag.py:155-219).
 """
 from __future__ import annotations
 
@@ -21,6 +24,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 
 # src/automl/genotypes_2d.py:4-8 — the genotype handed to Network / Cell_3d; 3-D cells read `.reduce`
@@ -32,13 +36,6 @@ ALL_CONV_ROWS = np.array([[0, 1], [1, 1], [2, 1], [3, 1], [5, 1], [6, 1]])
 ALL_SKIP_ROWS = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [5, 0], [6, 0]])
 ALL_CONV_GENOTYPE = Genotype(normal=ALL_CONV_ROWS, normal_concat=None, reduce=ALL_CONV_ROWS, reduce_concat=None)
 ALL_SKIP_GENOTYPE = Genotype(normal=ALL_SKIP_ROWS, normal_concat=None, reduce=ALL_SKIP_ROWS, reduce_concat=None)
-
-
-def _require_inference(*tensors_or_params) -> None:
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors_or_params):
-        raise NotImplementedError(
-            "rag_amd: the HIP Matching-Net path is forward/inference only in this round (no autograd); "
-            "call it under torch.no_grad(). There is no PyTorch fallback by design.")
 
 
 class Identity_3d(nn.Module):
@@ -98,8 +95,8 @@ class _ConvBR(nn.Module):
     def prepared(self) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
         """(weights in kernel layout, scale, shift); scale/shift None when bn=False."""
         if self.use_bn and self.bn.training:
-            raise NotImplementedError("rag_amd ConvBR: train-mode BatchNorm (batch statistics) is not built yet; "
-                                      "put the module in eval() — no PyTorch fallback by design")
+            raise RuntimeError("rag_amd ConvBR: folded BatchNorm parameters requested in train mode (internal error: "
+                               "train-mode units run through rag_amd.autograd)")
         stamp = self.stamp()
         if self._cache is None or self._cache[0] != stamp:
             k = self._geometry()
@@ -125,6 +122,34 @@ class _ConvBR(nn.Module):
             self._cache = (stamp, wk, scale, shift)
         return self._cache[1], self._cache[2], self._cache[3]
 
+    def weight5(self, w: torch.Tensor) -> torch.Tensor:
+        """The conv weight as a 5-D [Cout, Cin, kd, kh, kw] tensor (2-D 3x3: embedded in the middle z-slice of a 3x3x3)."""
+        if self.NDIM == 3:
+            return w
+        if w.shape[-1] == 1:
+            return w.reshape(w.shape[0], w.shape[1], 1, 1, 1)
+        w3 = w.new_zeros((w.shape[0], w.shape[1], 3, 3, 3))
+        w3[:, :, 1] = w
+        return w3
+
+    def autograd_mode(self, *inputs) -> bool:
+        """Training composition needed: a gradient is wanted, or this unit's BatchNorm uses batch statistics."""
+        return (ag.needs_grad(*inputs, self.conv.weight, self.bn.weight, self.bn.bias)
+                or (self.use_bn and self.bn.training))
+
+    def _forward_autograd(self, x: torch.Tensor, resample_to: Optional[Sequence[int]]) -> torch.Tensor:
+        if x.dtype != torch.float32:
+            raise NotImplementedError("rag_amd: the training path is fp32 (bf16 storage is inference only)")
+        if self._geometry() == -3:
+            return ag.StridedStemFn.apply(x if x.dim() == 4 else x[:, :, 0], self.conv.weight, self.bn.weight, self.bn.bias, self)
+        squeeze = x.dim() == 4
+        if squeeze:
+            x = x.unsqueeze(2)
+        if resample_to is not None:
+            x = ag.resample(x, resample_to, True)
+        y = ag.ConvBRFn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias, self)
+        return y[:, :, 0] if squeeze else y
+
     def as_tail(self, out: torch.Tensor, out_ch0: int) -> "ops.Tail":
         """This 1x1(x1) ConvBR (<= 4 output channels) as a tail of the kernel that produces its input."""
         if self._geometry() != 1 or self.conv.out_channels > 4:
@@ -139,7 +164,10 @@ class _ConvBR(nn.Module):
         trilinearly (align_corners=True) to that size inside the same kernel — the reference's
         `conv(F.interpolate(x, size, mode='trilinear', align_corners=True))`.  The 2-D flavour accepts [B,C,H,W] (or an
         already depth-1 5-D view) and returns the same rank."""
-        _require_inference(x, self.conv.weight)
+        if self.autograd_mode(x):
+            if out is not None or tails:
+                raise RuntimeError("rag_amd ConvBR: fused destinations/tails belong to the inference executor")
+            return self._forward_autograd(x, resample_to)
         k = self._geometry()
         wk, scale, shift = self.prepared()
         cout = self.conv.out_channels
@@ -221,7 +249,8 @@ class DisparityRegression(nn.Module):
 
     def forward(self, x):
         assert x.is_contiguous() is True
-        _require_inference(x)
+        if ag.needs_grad(x):
+            return ag.DispRegFn.apply(x, self.maxdisp)
         return ops.disparity_regression(x, self.maxdisp)
 
 
@@ -235,7 +264,8 @@ class Disp(nn.Module):
         self.disparity = DisparityRegression(maxdisp=self.maxdisp)  # idem
 
     def forward(self, x):
-        _require_inference(x)
+        if ag.needs_grad(x):
+            return ag.DispFn.apply(x, self.maxdisp)
         return ops.disp_softargmin(x, self.maxdisp)
 
 
@@ -310,12 +340,36 @@ class _Cell(nn.Module):
             self._fused_cache[key] = hit
         return hit[1]
 
+    def autograd_mode(self, *inputs) -> bool:
+        if ag.needs_grad(*inputs, *self.parameters()):
+            return True
+        return any(m.use_bn and m.bn.training for m in self.modules() if isinstance(m, _ConvBR))
+
     def forward(self, prev_prev_input, prev_input):
+        run = self._run_autograd if self.autograd_mode(prev_prev_input, prev_input) else (lambda a, b: self._run(a, b)[0])
         if prev_input.dim() == 4:     # 2-D cell: run on depth-1 volumes
-            concat_feature, _applied = self._run(prev_prev_input.unsqueeze(2), prev_input.unsqueeze(2))
-            return prev_input, concat_feature[:, :, 0]
-        concat_feature, _applied = self._run(prev_prev_input, prev_input)
-        return prev_input, concat_feature
+            return prev_input, run(prev_prev_input.unsqueeze(2), prev_input.unsqueeze(2))[:, :, 0]
+        return prev_input, run(prev_prev_input, prev_input)
+
+    def _run_autograd(self, prev_prev_input, prev_input):
+        """The reference's forward node by node (rag_model.py:143-177) on the autograd Functions."""
+        s0, s1 = prev_prev_input, prev_input
+        if self.downup_sample != 0:
+            s1 = ag.resample(s1, self.out_size(s1.shape[2:]), True)
+        s0 = ag.resample(s0, s1.shape[2:], True)
+        if s0.shape[1] != self.C_out:
+            s0 = self.pre_preprocess(s0)
+        s1 = self.preprocess(s1)
+        states = [s0, s1]
+        for _k, lst in self._contributions().items():
+            if not lst:
+                raise ValueError("Cell_3d: a step with no selected branch (the reference fails in torch.cat here too)")
+            acc = None
+            for (j, op) in lst:
+                h = op(states[j])
+                acc = h if acc is None else ag.AddFn.apply(acc, h)
+            states.append(acc)
+        return torch.cat(states[-self.block_multiplier:], dim=1)
 
     def out_size(self, prev_size: Sequence[int]) -> Tuple[int, int, int]:
         """Spatial size this cell works at (and outputs) given the size of prev_input."""
@@ -329,7 +383,6 @@ class _Cell(nn.Module):
         `pre`/`pre_has`: the [B, 2C, ...] buffer in which the producers of the inputs have already written s0 (ch 0..C)
         and/or s1 (ch C..2C) as fused tails; `tails`/`store_main`: consumer 1x1x1 convs to compute in THIS cell's final
         conv launch (possible when one dual launch produces all new states).  Returns (concat or None, tails_applied)."""
-        _require_inference(prev_prev_input, prev_input)
         C = self.C_out
         if C % 4 != 0 or self.block_multiplier > self._steps:
             raise NotImplementedError("rag_amd.Cell_3d: filter_multiplier must be a multiple of 4 and "
@@ -574,6 +627,12 @@ class MatchingNet(nn.Module):
         preprocess conv of a cell that needs no resampling is computed in the epilogue of the kernel that PRODUCES its
         input (a "tail"), and a tensor consumed only by tails is never written to HBM.  Tensors: T[-2] = stem0 output,
         T[-1] = stem1 output, T[i] = output of cell i; cell i reads T[i-2] (prev_prev) and T[i-1] (prev)."""
+        if stem0.autograd_mode(x) or stem1.autograd_mode() or any(c.autograd_mode() for c in cells):
+            out = (stem0(x),)                     # training: the reference's graph node by node (rag_model.py:341-351)
+            out = (out[0], stem1(out[0]))
+            for c in cells:
+                out = c(out[0], out[1])
+            return out[-1]
         n = len(cells)
         sizes = {-2: tuple(x.shape[2:]), -1: tuple(x.shape[2:])}
         for i, c in enumerate(cells):
@@ -641,23 +700,26 @@ class MatchingNet(nn.Module):
         d, h, w = x.size()[2], x.size()[3], x.size()[4]
         if last_output.size()[3] == h:
             return self.last_3_3d[i3](last_output)
+        heads = (self.last_3_3d[i3], self.last_6_3d[i6], self.last_12_3d[i12])
+        up = ag.resample if any(m.autograd_mode(last_output) for m in heads) else ops.trilinear3d
         if last_output.size()[3] == h // 2:
-            y = ops.trilinear3d(self.last_6_3d[i6](last_output), (d, h, w), True)
+            y = up(self.last_6_3d[i6](last_output), (d, h, w), True)
             return self.last_3_3d[i3](y)
         if last_output.size()[3] == h // 4:
             # upsample_12 is fused into last_6_3d's 1x1x1 kernel; upsample_6 feeds a 3x3x3 conv and stays a kernel
             y = self.last_6_3d[i6](self.last_12_3d[i12](last_output), resample_to=(d // 2, h // 2, w // 2))
-            y = ops.trilinear3d(y, (d, h, w), True)
+            y = up(y, (d, h, w), True)
             return self.last_3_3d[i3](y)
         # the reference reaches `return mat` with mat unbound here (UnboundLocalError)
         raise ValueError("MatchingNet: feature height must be a multiple of 4 (input H a multiple of 12)")
 
     def cost_volume(self, left_fea, right_fea):
         """The inline loop of rag_model.py:375-383 as one kernel."""
+        if ag.needs_grad(left_fea, right_fea):
+            return ag.CostVolFn.apply(left_fea, right_fea, self.maxdisp)
         return ops.costvol(left_fea, right_fea, self.maxdisp)
 
     def forward(self, left_fea, right_fea, task_arch=None):
-        _require_inference(left_fea, right_fea)
         if task_arch is None:
             task_arch = self.arch_init
         cost = self.cost_volume(left_fea, right_fea)

@@ -19,7 +19,7 @@ from typing import Dict, List
 import torch
 import torch.nn as nn
 
-from .modules import Cell_2d, Cell_3d, ConvBR_2d, ConvBR_3d, MatchingNet, _require_inference  # noqa: F401
+from .modules import Cell_2d, Cell_3d, ConvBR_2d, ConvBR_3d, MatchingNet, _ConvBR  # noqa: F401
 
 # Feature-Net macro architecture, rag_model.py:207-219: (prev_prev_fm, prev_fm, filter_multiplier, downup)
 _CELL2D_ARCH = ((4, 4, 8, -1), (4, 8, 4, 1), (8, 4, 8, -1), (4, 8, 4, 1))
@@ -123,20 +123,30 @@ class Network(MatchingNet):
             raise ValueError("Network.search_feature: H and W must be multiples of 12")
         return self.last_3_2d[selected_ops[7]](out[-1])
 
-    def forward(self, left, right, t, task_arch=None, path=None):   # rag_model.py:369-387
-        _require_inference(left, right)
-        # both views share the Feature-Net weights: one batched pass (results are batch-independent) instead of two
+    def _training_graph(self, *inputs) -> bool:
+        """True when the call must build the reference's autograd graph / use batch statistics (rag.py:155-219)."""
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in self.parameters())):
+            return True
+        return any(m.use_bn and m.bn.training for m in self.modules() if isinstance(m, _ConvBR))
+
+    def _features(self, left, right, feature):
+        if self._training_graph(left, right):
+            # two passes like the reference: train-mode BatchNorm statistics are per view (rag_model.py:371-372)
+            return feature(left), feature(right)
+        # inference: both views share the Feature-Net weights and results are batch-independent -> one batched pass
         B = left.shape[0]
-        fea = self.feature(torch.cat([left, right]), task_arch, path).to(self.act_dtype)
-        cost = self.cost_volume(fea[:B].contiguous(), fea[B:].contiguous())
+        fea = feature(torch.cat([left, right])).to(self.act_dtype)
+        return fea[:B].contiguous(), fea[B:].contiguous()
+
+    def forward(self, left, right, t, task_arch=None, path=None):   # rag_model.py:369-387
+        lf, rf = self._features(left, right, lambda x: self.feature(x, task_arch, path))
+        cost = self.cost_volume(lf, rf)
         cost = self.matching(cost, task_arch, path)
         return self.disp(cost)
 
     def search_forward(self, left, right, t, selected_ops):        # rag_model.py:688-706
-        _require_inference(left, right)
-        B = left.shape[0]
-        fea = self.search_feature(torch.cat([left, right]), selected_ops).to(self.act_dtype)
-        cost = self.cost_volume(fea[:B].contiguous(), fea[B:].contiguous())
+        lf, rf = self._features(left, right, lambda x: self.search_feature(x, selected_ops))
+        cost = self.cost_volume(lf, rf)
         cost = self.search_matching(cost, selected_ops, t)
         return self.disp(cost)
 

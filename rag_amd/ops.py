@@ -335,3 +335,149 @@ def disparity_regression(prob: torch.Tensor, maxdisp: int) -> torch.Tensor:
     check(load_library().ragmi_disparity_regression_fwd(prob.data_ptr(), out.data_ptr(), B, D, H, W, dt, _stream()),
           "disparity_regression")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# training-step pieces (fp32): thin wrappers over the train.hip entry points; rag_amd/autograd.py composes them
+def _vol(t: torch.Tensor) -> int:
+    n = 1
+    for s in t.shape[2:]:
+        n *= s
+    return n
+
+
+def bn_stats(x: torch.Tensor):
+    """per-channel (sum, sum of squares) of x[B,C,...] (fp32 atomics into zeroed buffers)."""
+    _need_gpu(x)
+    B, C = x.shape[:2]
+    s = torch.zeros((2, C), device=x.device, dtype=torch.float32)
+    check(load_library().ragmi_bn_stats_fwd(x.data_ptr(), _planes(x), B, C, _vol(x), s[0].data_ptr(), s[1].data_ptr(), _stream()), "bn_stats")
+    return s[0], s[1]
+
+
+def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool, out: Optional[torch.Tensor] = None,
+           out_ch0: int = 0, res: Optional[torch.Tensor] = None, res_ch0: int = 0) -> torch.Tensor:
+    """out[:, ch0:ch0+C] = act(x * scale + shift) (+ res[:, res_ch0:+C])."""
+    _need_gpu(x, scale, shift, out, res)
+    B, C = x.shape[:2]
+    if out is None:
+        out = torch.empty_like(x)
+    check(load_library().ragmi_bn_act_fwd(x.data_ptr(), _planes(x), scale.data_ptr(), shift.data_ptr(), int(relu),
+                                          res.data_ptr() if res is not None else None, _planes(res) if res is not None else 0, res_ch0,
+                                          out.data_ptr(), _planes(out), out_ch0, B, C, _vol(x), _stream()), "bn_act")
+    return out
+
+
+def bn_act_bwd_reduce(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool):
+    """(sum g, sum g*x) per channel with g = dy * [x*scale+shift > 0]."""
+    _need_gpu(dy, x, scale, shift)
+    B, C = x.shape[:2]
+    s = torch.zeros((2, C), device=x.device, dtype=torch.float32)
+    check(load_library().ragmi_bn_act_bwd_reduce(dy.data_ptr(), _planes(dy), dy_ch0, x.data_ptr(), _planes(x), scale.data_ptr(),
+                                                 shift.data_ptr(), int(relu), B, C, _vol(x), s[0].data_ptr(), s[1].data_ptr(), _stream()),
+          "bn_act_bwd_reduce")
+    return s[0], s[1]
+
+
+def bn_act_bwd_apply(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shift, relu: bool, c1, c2, c3) -> torch.Tensor:
+    """dx = g * c1 + x * c2 + c3 (per channel)."""
+    _need_gpu(dy, x, scale, shift, c1, c2, c3)
+    B, C = x.shape[:2]
+    dx = torch.empty_like(x)
+    check(load_library().ragmi_bn_act_bwd_apply(dy.data_ptr(), _planes(dy), dy_ch0, x.data_ptr(), _planes(x), scale.data_ptr(),
+                                                shift.data_ptr(), int(relu), c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), dx.data_ptr(),
+                                                _planes(dx), B, C, _vol(x), _stream()), "bn_act_bwd_apply")
+    return dx
+
+
+def conv3d_k3_wgrad(x: torch.Tensor, g: torch.Tensor, cout: int, g_ch0: int = 0) -> torch.Tensor:
+    """dW[cout, Cin, 3, 3, 3] of a 3x3x3 / pad 1 conv from its input x and output gradient g."""
+    _need_gpu(x, g)
+    B, Cin, D, H, W = x.shape
+    dw = torch.zeros((cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
+    check(load_library().ragmi_conv3d_k3_wgrad(x.data_ptr(), _planes(x), g.data_ptr(), _planes(g), g_ch0, dw.data_ptr(), B, Cin, cout,
+                                               D, H, W, _stream()), "conv3d_k3_wgrad")
+    return dw
+
+
+def conv3d_k1_wgrad(x: torch.Tensor, g: torch.Tensor, cout: int, g_ch0: int = 0) -> torch.Tensor:
+    """dW[cout, Cin] of a 1x1x1 conv."""
+    _need_gpu(x, g)
+    B, Cin = x.shape[:2]
+    dw = torch.zeros((cout, Cin), device=x.device, dtype=torch.float32)
+    check(load_library().ragmi_conv3d_k1_wgrad(x.data_ptr(), _planes(x), g.data_ptr(), _planes(g), g_ch0, dw.data_ptr(), B, Cin, cout,
+                                               _vol(x), _stream()), "conv3d_k1_wgrad")
+    return dw
+
+
+def trilinear3d_bwd(dy: torch.Tensor, in_size: Sequence[int], align_corners: bool) -> torch.Tensor:
+    """adjoint of trilinear3d: gradient w.r.t. the [B,C,*in_size] input."""
+    _need_gpu(dy)
+    dy = dy.contiguous()
+    B, C, Do, Ho, Wo = dy.shape
+    Di, Hi, Wi = [int(v) for v in in_size]
+    dx = torch.zeros((B, C, Di, Hi, Wi), device=dy.device, dtype=torch.float32)
+    check(load_library().ragmi_trilinear3d_bwd(dy.data_ptr(), dx.data_ptr(), B, C, Di, Hi, Wi, Do, Ho, Wo, int(bool(align_corners)),
+                                               _stream()), "trilinear3d_bwd")
+    return dx
+
+
+def costvol_bwd(dcost: torch.Tensor):
+    """adjoint of costvol: (dleft, dright) [B,C,h,w] from dcost [B,2C,d,h,w]."""
+    _need_gpu(dcost)
+    dcost = dcost.contiguous()
+    B, C2, d, h, w = dcost.shape
+    dl = torch.empty((B, C2 // 2, h, w), device=dcost.device, dtype=torch.float32)
+    dr = torch.empty_like(dl)
+    check(load_library().ragmi_costvol_bwd(dcost.data_ptr(), dl.data_ptr(), dr.data_ptr(), B, C2 // 2, d, h, w, _stream()), "costvol_bwd")
+    return dl, dr
+
+
+def disp_softargmin_bwd(cost: torch.Tensor, dout: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """adjoint of disp_softargmin: dcost with cost's shape."""
+    _need_gpu(cost, dout)
+    shape = cost.shape
+    c4 = (cost[:, 0] if cost.dim() == 5 else cost).contiguous()
+    B, d, h, w = c4.shape
+    dout = dout.contiguous()
+    dc = torch.zeros_like(c4)
+    check(load_library().ragmi_disp_softargmin_bwd(c4.data_ptr(), dout.data_ptr(), dc.data_ptr(), B, d, h, w, int(maxdisp), 3 * h, 3 * w,
+                                                   _stream()), "disp_softargmin_bwd")
+    return dc.reshape(shape)
+
+
+def conv2d_k3_strided_dgrad(g: torch.Tensor, weight: torch.Tensor, in_hw: Sequence[int], stride: int) -> torch.Tensor:
+    """data gradient of the strided 2-D stem conv: g[B,Cout,Ho,Wo] -> dx[B,Cin,H,W]."""
+    _need_gpu(g, weight)
+    g, w = g.contiguous(), weight.detach().contiguous()
+    B, Cout = g.shape[:2]
+    Cin, (H, W) = w.shape[1], [int(v) for v in in_hw]
+    if tuple(g.shape[2:]) != ((H - 1) // stride + 1, (W - 1) // stride + 1):
+        raise ValueError("conv2d_k3_strided_dgrad: gradient size does not match the input size / stride")
+    dx = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32)
+    check(load_library().ragmi_conv2d_k3_strided_dgrad(g.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, int(stride),
+                                                       _stream()), "conv2d_k3_strided_dgrad")
+    return dx
+
+
+def conv2d_k3_strided_wgrad(x: torch.Tensor, g: torch.Tensor, stride: int) -> torch.Tensor:
+    """weight gradient [Cout,Cin,3,3] of the strided 2-D stem conv."""
+    _need_gpu(x, g)
+    x, g = x.contiguous(), g.contiguous()
+    B, Cin, H, W = x.shape
+    Cout = g.shape[1]
+    dw = torch.zeros((Cout, Cin, 3, 3), device=x.device, dtype=torch.float32)
+    check(load_library().ragmi_conv2d_k3_strided_wgrad(x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, Cin, Cout, H, W, int(stride),
+                                                       _stream()), "conv2d_k3_strided_wgrad")
+    return dw
+
+
+def disparity_regression_bwd(dout: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """adjoint of disparity_regression: dprob[B,maxdisp,H,W]."""
+    _need_gpu(dout)
+    dout = dout.contiguous()
+    B, H, W = dout.shape
+    dp = torch.empty((B, int(maxdisp), H, W), device=dout.device, dtype=torch.float32)
+    check(load_library().ragmi_disparity_regression_bwd(dout.data_ptr(), dp.data_ptr(), B, int(maxdisp), H, W, _stream()),
+          "disparity_regression_bwd")
+    return dp

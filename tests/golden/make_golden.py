@@ -45,7 +45,8 @@ def randomize_bn(module, gen):
 
 
 def sd_np(module, prefix="sd::"):
-    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+    # copies: .numpy() aliases the live buffers, which train-mode BatchNorm updates in place
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
 
 
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]   # e.g. `make_golden.py g8` regenerates one fixture family
@@ -195,13 +196,24 @@ def main():
     right = torch.randn((2, 3, 36, 48), generator=g)
     gt = torch.rand((2, 36, 48), generator=g) * 30
     sd_before = sd_np(net)
+    feas = []                      # Feature-Net outputs (left, then right) as the Matching Net sees them in train mode
+    def _keep(_m, _inp, o):
+        o.retain_grad()
+        feas.append(o)
+
+    hk = net.last_3_2d[0].register_forward_hook(_keep)
     out = net.forward(left, right, 0, net.arch_init)
+    hk.remove()
     mask = (gt < 24) & (gt > 0)
     loss = torch.nn.functional.smooth_l1_loss(out[mask], gt[mask], reduction="mean")
     loss.backward()
     arrays = {"left": left.numpy(), "right": right.numpy(), "gt": gt.numpy(), "disp": out.detach().numpy(),
-              "loss": np.float64(loss.item()), "rows": ALL_CONV, "maxdisp": np.int64(24)}
+              "loss": np.float64(loss.item()), "rows": ALL_CONV, "maxdisp": np.int64(24),
+              "left_fea": feas[0].detach().numpy(), "right_fea": feas[1].detach().numpy(),
+              "grad::left_fea": feas[0].grad.numpy(), "grad::right_fea": feas[1].grad.numpy()}
     arrays.update(sd_before)
+    arrays.update({"after::" + k_[4:]: v for k_, v in sd_np(net).items()     # running statistics after the step's forward
+                   if ("running_" in k_ or "num_batches" in k_) and ("3d" in k_)})
     for k_, p_ in net.named_parameters():
         if p_.grad is not None and (k_.startswith("stem3d") or k_.startswith("last_") or k_.startswith("cells_3d.0.")
                                     or k_.startswith("cells_3d.7.")):

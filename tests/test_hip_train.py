@@ -1,0 +1,342 @@
+"""GPU parity tests of the training step (BASELINE config 5): forward AND backward of every autograd Function of
+rag_amd/autograd.py against PyTorch-CPU autograd of the oracle on the same inputs, and the whole step against the
+reference-generated fixture g6_train_step (approaches/rag.py:155-219: train-mode BN, one reused unit in eval,
+smooth-L1 on the 0 < gt < maxdisp mask).
+
+Tolerances: fp32 with a different accumulation order (and fp32 atomics in the reductions): gradients are compared
+relative to the largest magnitude of each tensor, 2e-4 unless stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, split_sd
+from oracle import matching_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def gpu(x):
+    return torch.as_tensor(x).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rag_amd
+    rag_amd.load_library()
+    return rag_amd
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(got, ref, tol=2e-4, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = float((got - ref).abs().max())
+    bound = tol * max(1.0, float(ref.abs().max()))
+    assert err <= bound, (what, err, bound)
+
+
+# --------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("shape", [(2, 5, 3, 7, 9), (1, 12, 8, 16, 32), (3, 4, 1, 5, 1027)])
+def test_bn_stats_and_affine(ra, shape):
+    x = torch.randn(shape, generator=gen(1)) * 2 + 0.5
+    s, q = ra.ops.bn_stats(gpu(x))
+    close(s, x.sum(dim=(0, 2, 3, 4)), 1e-5 * x[0, 0].numel() ** 0.5)
+    close(q, (x * x).sum(dim=(0, 2, 3, 4)), 1e-5 * x[0, 0].numel() ** 0.5)
+    sc, sh = torch.rand(shape[1], generator=gen(2)) + 0.5, torch.randn(shape[1], generator=gen(3))
+    y = ra.ops.bn_act(gpu(x), gpu(sc), gpu(sh), True)
+    close(y, F.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)), 1e-6)
+
+
+def _convbr_case(ra, cin, cout, k, bn, relu, bn_training, shape, seed, ndim=3, train_params=True):
+    """(module on the GPU, x, torch-CPU reference function)"""
+    cls = ra.ConvBR_3d if ndim == 3 else ra.ConvBR_2d
+    torch.manual_seed(seed)
+    m = cls(cin, cout, k, 1, (k - 1) // 2, bn=bn, relu=relu)
+    with torch.no_grad():
+        m.bn.weight.copy_(torch.rand(cout) + 0.5)
+        m.bn.bias.copy_(torch.randn(cout) * 0.1)
+        m.bn.running_mean.copy_(torch.randn(cout) * 0.1)
+        m.bn.running_var.copy_(torch.rand(cout) + 0.5)
+    m.train(bn_training)
+    x = torch.randn(shape, generator=gen(seed + 1))
+    return m, x
+
+
+def _ref_convbr(m, x, ndim=3):
+    """PyTorch-CPU autograd of operations_3d.py:40-47 with a private copy of the module's parameters/buffers."""
+    w = m.conv.weight.detach().cpu().clone().requires_grad_(True)
+    g = m.bn.weight.detach().cpu().clone().requires_grad_(True)
+    b = m.bn.bias.detach().cpu().clone().requires_grad_(True)
+    rm, rv = m.bn.running_mean.detach().cpu().clone(), m.bn.running_var.detach().cpu().clone()
+    xr = x.clone().requires_grad_(True)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    y = conv(xr, w, None, stride=m.conv.stride, padding=m.conv.padding)
+    if m.use_bn:
+        y = F.batch_norm(y, rm, rv, g, b, training=m.bn.training, momentum=0.1, eps=m.bn.eps)
+    if m.relu:
+        y = F.relu(y)
+    return y, xr, w, g, b, rm, rv
+
+
+@pytest.mark.parametrize("cin,cout,k,bn,relu,bn_training,shape", [
+    (12, 12, 3, True, True, True, (2, 12, 5, 9, 33)),
+    (24, 12, 3, True, True, True, (2, 24, 4, 8, 20)),
+    (4, 4, 3, True, True, False, (1, 4, 6, 10, 40)),
+    (16, 16, 3, True, True, True, (2, 16, 3, 7, 13)),
+    (12, 1, 3, False, False, True, (2, 12, 5, 12, 40)),      # last_3_3d
+    (12, 4, 1, True, True, True, (2, 12, 4, 6, 8)),
+    (48, 24, 1, True, True, False, (1, 48, 4, 8, 26)),
+    (24, 12, 1, True, False, True, (3, 24, 3, 5, 7)),
+])
+def test_convbr_fwd_bwd_vs_torch(ra, cin, cout, k, bn, relu, bn_training, shape):
+    m, x = _convbr_case(ra, cin, cout, k, bn, relu, bn_training, shape, seed=10 + cin + cout)
+    yr, xr, w, g, b, rm, rv = _ref_convbr(m, x)
+    dy = torch.randn(yr.shape, generator=gen(7))
+    yr.backward(dy)
+    m = m.to(DEV)
+    xg = gpu(x).requires_grad_(True)
+    y = m(xg)
+    y.backward(gpu(dy))
+    close(y, yr, what="y")
+    close(xg.grad, xr.grad, what="dx")
+    close(m.conv.weight.grad, w.grad, what="dw")
+    if bn:
+        close(m.bn.weight.grad, g.grad, what="dgamma")
+        close(m.bn.bias.grad, b.grad, what="dbeta")
+        close(m.bn.running_mean, rm, 1e-5, "running_mean")
+        close(m.bn.running_var, rv, 1e-5, "running_var")
+        assert int(m.bn.num_batches_tracked) == (1 if bn_training else 0)
+
+
+def test_convbr_frozen_unit_passes_gradient_only(ra):
+    """A reused unit (rag.py:159-200): eval BN, parameters frozen -> only dx flows, no parameter .grad appears."""
+    m, x = _convbr_case(ra, 12, 12, 3, True, True, False, (1, 12, 4, 8, 16), seed=3)
+    for p in m.parameters():
+        p.requires_grad = False
+    yr, xr, *_ = _ref_convbr(m, x)
+    dy = torch.randn(yr.shape, generator=gen(8))
+    yr.backward(dy)
+    m = m.to(DEV)
+    xg = gpu(x).requires_grad_(True)
+    m(xg).backward(gpu(dy))
+    close(xg.grad, xr.grad, what="dx")
+    assert all(p.grad is None for p in m.parameters())
+
+
+def test_train_mode_forward_under_no_grad_uses_batch_statistics(ra):
+    m, x = _convbr_case(ra, 12, 12, 3, True, True, True, (2, 12, 4, 6, 10), seed=5)
+    yr, *_ = _ref_convbr(m, x)
+    with torch.no_grad():
+        y = m.to(DEV)(gpu(x))
+    close(y, yr)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,shape", [(3, 6, 3, 1, (2, 3, 12, 20)), (6, 12, 3, 3, (2, 6, 36, 48)), (12, 12, 3, 1, (2, 12, 9, 13)),
+                                                     (12, 12, 1, 1, (2, 12, 8, 8)), (6, 12, 3, 3, (1, 6, 17, 23))])
+def test_convbr2d_fwd_bwd_vs_torch(ra, cin, cout, k, stride, shape):
+    torch.manual_seed(21)
+    m = ra.ConvBR_2d(cin, cout, k, stride, (k - 1) // 2)
+    with torch.no_grad():
+        m.bn.weight.copy_(torch.rand(cout) + 0.5)
+        m.bn.bias.copy_(torch.randn(cout) * 0.1)
+    m.train()
+    x = torch.randn(shape, generator=gen(22))
+    yr, xr, w, g, b, rm, rv = _ref_convbr(m, x, ndim=2)
+    dy = torch.randn(yr.shape, generator=gen(23))
+    yr.backward(dy)
+    m = m.to(DEV)
+    xg = gpu(x).requires_grad_(True)
+    y = m(xg)
+    y.backward(gpu(dy))
+    close(y, yr, what="y")
+    close(xg.grad, xr.grad, what="dx")
+    close(m.conv.weight.grad, w.grad, what="dw")
+    close(m.bn.weight.grad, g.grad, what="dgamma")
+    close(m.bn.bias.grad, b.grad, what="dbeta")
+    close(m.bn.running_var, rv, 1e-5, "running_var")
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("shape,size", [((2, 3, 8, 12, 20), (4, 6, 10)), ((1, 2, 7, 9, 13), (4, 5, 7)), ((1, 4, 4, 5, 7), (8, 10, 14)),
+                                        ((2, 2, 3, 4, 5), (5, 7, 9)), ((1, 1, 8, 4, 6), (24, 12, 18))])
+def test_trilinear_backward_vs_aten(ra, align, shape, size):
+    x = torch.randn(shape, generator=gen(31), requires_grad=True)
+    yr = F.interpolate(x, size, mode="trilinear", align_corners=align)
+    dy = torch.randn(yr.shape, generator=gen(32))
+    yr.backward(dy)
+    xg = gpu(x.detach()).requires_grad_(True)
+    y = ra.autograd.TrilinearFn.apply(xg, size, align)
+    y.backward(gpu(dy))
+    close(y, yr, 1e-5)
+    close(xg.grad, x.grad, 1e-5)
+
+
+@pytest.mark.parametrize("B,C,h,w,maxdisp", [(2, 12, 6, 20, 24), (1, 3, 5, 7, 30), (1, 12, 4, 9, 48)])
+def test_costvol_backward_vs_oracle(ra, B, C, h, w, maxdisp):
+    L = torch.randn((B, C, h, w), generator=gen(41), requires_grad=True)
+    R = torch.randn((B, C, h, w), generator=gen(42), requires_grad=True)
+    cr = O.cost_volume(L, R, maxdisp)
+    dc = torch.randn(cr.shape, generator=gen(43))
+    cr.backward(dc)
+    Lg, Rg = gpu(L.detach()).requires_grad_(True), gpu(R.detach()).requires_grad_(True)
+    c = ra.autograd.CostVolFn.apply(Lg, Rg, maxdisp)
+    c.backward(gpu(dc))
+    assert torch.equal(c.cpu(), cr.detach())
+    close(Lg.grad, L.grad, 1e-5)
+    close(Rg.grad, R.grad, 1e-5)
+
+
+@pytest.mark.parametrize("B,d,h,w,maxdisp,scale", [(2, 8, 4, 8, 24, 1.0), (1, 16, 6, 10, 48, 3.0), (1, 7, 5, 3, 21, 0.3), (1, 64, 4, 6, 192, 1.0)])
+def test_disp_backward_vs_oracle(ra, B, d, h, w, maxdisp, scale):
+    x = (torch.randn((B, 1, d, h, w), generator=gen(51)) * scale).requires_grad_(True)
+    outr = O.disp_head(x, maxdisp)
+    do = torch.randn(outr.shape, generator=gen(52))
+    outr.backward(do)
+    xg = gpu(x.detach()).requires_grad_(True)
+    out = ra.Disp(maxdisp)(xg)
+    out.backward(gpu(do))
+    close(out, outr, 2e-4)
+    close(xg.grad, x.grad, 2e-4)
+    p = torch.rand((B, maxdisp, 3, 5), generator=gen(53)).requires_grad_(True)
+    rr = O.disparity_regression(p, maxdisp)
+    rr.backward(torch.ones_like(rr))
+    pg = gpu(p.detach()).requires_grad_(True)
+    ra.DisparityRegression(maxdisp)(pg).sum().backward()
+    close(pg.grad, p.grad, 1e-6)
+
+
+# --------------------------------------------------------------------------- cells
+@pytest.mark.parametrize("name", ["same_conv", "same_unsorted", "same_deep", "down_odd", "up", "skip"])
+def test_cell3d_train_step_vs_oracle(ra, name):
+    """Cell_3d in train mode (batch statistics): concat and all gradients vs the oracle under PyTorch-CPU autograd."""
+    g = load_golden("g4_cell3d")
+    pp, p, fm, du = [int(v) for v in g[f"{name}::cfg"]]
+    rows = g[f"{name}::rows"]
+    sd = split_sd(g, f"{name}::sd::")
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    sd2 = dict(sd)
+    sd2.update(params)
+    s0 = torch.from_numpy(g[f"{name}::s0"]).requires_grad_(True)
+    s1 = torch.from_numpy(g[f"{name}::s1"]).requires_grad_(True)
+    _prev, catr = O.cell_3d(s0, s1, sd2, "", rows, fm, du, training=True)
+    dy = torch.randn(catr.shape, generator=gen(61))
+    catr.backward(dy)
+
+    cell = ra.Cell_3d(3, 3, pp, p, ra.Genotype(rows, None, rows, None), fm, du)
+    cell.load_state_dict(sd)
+    cell = cell.to(DEV).train()
+    s0g, s1g = gpu(s0.detach()).requires_grad_(True), gpu(s1.detach()).requires_grad_(True)
+    prev, cat = cell(s0g, s1g)
+    assert prev is s1g
+    cat.backward(gpu(dy))
+    close(cat, catr, what="concat")
+    close(s0g.grad, s0.grad, what="ds0")
+    close(s1g.grad, s1.grad, what="ds1")
+    n = 0
+    for k, pr in params.items():
+        if pr.grad is None:
+            continue
+        close(dict(cell.named_parameters())[k].grad, pr.grad, what=k)
+        n += 1
+    assert n >= 3
+
+
+# --------------------------------------------------------------------------- the whole step vs the reference fixture
+def _smooth_l1_step(disp, gt, maxdisp):
+    mask = (gt < maxdisp) & (gt > 0)
+    return F.smooth_l1_loss(disp[mask], gt[mask], reduction="mean")
+
+
+def _check_g6_grads(net, g, tol, skip_2d):
+    named = dict(net.named_parameters())
+    n = 0
+    for k, ref in g.items():
+        if not k.startswith("grad::") or k.endswith("_fea") or (skip_2d and "_2d" in k):
+            continue
+        close(named[k[6:]].grad, torch.from_numpy(ref), tol, k)
+        n += 1
+    return n
+
+
+def test_matchingnet_train_step_golden(ra):
+    """Features -> disp -> smooth-L1 -> backward, against the reference's own training step (g6)."""
+    g = load_golden("g6_train_step")
+    maxdisp = int(g["maxdisp"])
+    rows = g["rows"]
+    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=maxdisp)
+    sd = {k: v for k, v in split_sd(g).items()
+          if k.split(".")[0] in ("stem3d0", "stem3d1", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d")}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    net.stem3d0[0].eval()
+    lf, rf = gpu(g["left_fea"]).requires_grad_(True), gpu(g["right_fea"]).requires_grad_(True)
+    disp = net(lf, rf)
+    loss = _smooth_l1_step(disp, gpu(g["gt"]), maxdisp)
+    loss.backward()
+    close(disp, torch.from_numpy(g["disp"]), 2e-4, "disp")
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    assert _check_g6_grads(net, g, 5e-4, skip_2d=True) > 40
+    close(lf.grad, torch.from_numpy(g["grad::left_fea"]), 5e-4, "dleft_fea")
+    close(rf.grad, torch.from_numpy(g["grad::right_fea"]), 5e-4, "dright_fea")
+    # running statistics after the step (momentum update of train-mode units; the reused stem is untouched)
+    state = net.state_dict()
+    n = 0
+    for k, ref in g.items():
+        if k.startswith("after::") and k[7:] in state:
+            close(state[k[7:]].float(), torch.from_numpy(np.asarray(ref)).float(), 1e-4, k)
+            n += 1
+    assert n > 100
+    assert torch.equal(state["stem3d0.0.bn.running_mean"].cpu(), split_sd(g)["stem3d0.0.bn.running_mean"])
+
+
+def test_network_train_step_from_images_golden(ra):
+    """The reference's whole training step from images (Feature Net in train mode too) against g6."""
+    g = load_golden("g6_train_step")
+    maxdisp = int(g["maxdisp"])
+    rows = g["rows"]
+    net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=maxdisp)
+    net.load_state_dict(split_sd(g), strict=True)
+    net = net.to(DEV).train()
+    net.stem3d0[0].eval()
+    disp = net(gpu(g["left"]), gpu(g["right"]), 0, net.arch_init)
+    loss = _smooth_l1_step(disp, gpu(g["gt"]), maxdisp)
+    loss.backward()
+    close(disp, torch.from_numpy(g["disp"]), 5e-4, "disp")
+    assert abs(loss.item() - float(g["loss"])) < 2e-4
+    assert _check_g6_grads(net, g, 1e-3, skip_2d=False) > 40
+
+
+def test_sgd_step_changes_only_trained_units(ra):
+    """rag.py:69,101-102,213-216: SGD over requires_grad parameters after freezing reused units; clip_grad_norm_."""
+    g = load_golden("g6_train_step")
+    maxdisp = int(g["maxdisp"])
+    rows = g["rows"]
+    net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=maxdisp)
+    net.load_state_dict(split_sd(g), strict=True)
+    net = net.to(DEV).train()
+    frozen = {"stem_3d0": [0], "cell_3d1": [0]}
+    net.modify_param(frozen, requires_grad=False)
+    net.stem3d0[0].eval()
+    net.cells_3d[1][0].eval()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = torch.optim.SGD(filter(lambda p: p.requires_grad, net.parameters()), lr=1e-3, momentum=0.9, weight_decay=3e-3)
+    disp = net(gpu(g["left"]), gpu(g["right"]), 0, net.arch_init)
+    loss = _smooth_l1_step(disp, gpu(g["gt"]), maxdisp)
+    opt.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(net.parameters(), 5)
+    opt.step()
+    after = net.state_dict()
+    for k in before:
+        same = torch.equal(before[k], after[k])
+        if k.startswith("stem3d0.0.") or k.startswith("cells_3d.1.0."):
+            assert same, k
+        elif k.startswith("last_3_"):
+            assert same == (not k.endswith("conv.weight")), k      # bn=False heads: the unused BatchNorm never moves
+        elif k.endswith("conv.weight") or k.endswith("running_mean"):
+            assert not same, k

@@ -111,14 +111,26 @@ def test_reference_interface_names():
     assert list(rag_amd.OPS_3d) == ["skip_connect_3d", "3d_conv_3x3"] == rag_amd.PRIMITIVES_3D
 
 
-def test_training_mode_is_refused_not_emulated():
+def test_training_mode_runs_on_hip_or_fails_loudly():
+    """Train-mode BN / autograd route to the HIP autograd Functions; on a machine without a GPU they raise
+    (no PyTorch emulation), and folded BN parameters are never handed out for a train-mode unit."""
     import rag_amd
+    from rag_amd import autograd as ag
     m = rag_amd.ConvBR_3d(4, 4, 3, 1, 1)
     m.train()
-    with pytest.raises(NotImplementedError):
+    assert m.autograd_mode(torch.zeros(1))                      # batch statistics -> training composition
+    with pytest.raises(RuntimeError):
         m.prepared()
-    with pytest.raises(NotImplementedError):   # autograd through the HIP path is not silently dropped
-        m.eval()(torch.zeros(1, 4, 2, 2, 2, requires_grad=True))
+    m.eval()
+    x = torch.zeros(1, 4, 2, 2, 2, requires_grad=True)
+    assert m.autograd_mode(x)
+    with torch.no_grad():
+        assert not m.autograd_mode(x)
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, OSError)):            # CPU tensor: "rag_amd ops run on the MI355X only"
+            m(x)
+    for fn in (ag.ConvBRFn, ag.StridedStemFn, ag.TrilinearFn, ag.CostVolFn, ag.DispFn, ag.DispRegFn, ag.AddFn):
+        assert issubclass(fn, torch.autograd.Function)
 
 
 # ------------------------------------------------------------------ Network (growth loop surface)

@@ -115,3 +115,41 @@ def test_conv3d_explicit_matches_aten():
     w1 = torch.randn((4, 5, 1, 1, 1), generator=g)
     np.testing.assert_allclose(O.conv3d_explicit(x.numpy(), w1.numpy(), 0), F.conv3d(x, w1).numpy(),
                                rtol=1e-4, atol=1e-4)
+
+
+def oracle_train_step(g, sd=None):
+    """One training step of the Matching Net through the oracle + PyTorch-CPU autograd, as approaches/rag.py:208-214
+    (stem3d0 is a 'reused' unit: BN in eval).  Returns (disp, loss, grads by parameter name incl. left_fea/right_fea)."""
+    sd = split_sd(g) if sd is None else sd
+    maxdisp = int(g["maxdisp"])
+    lf = torch.from_numpy(g["left_fea"]).requires_grad_(True)
+    rf = torch.from_numpy(g["right_fea"]).requires_grad_(True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k
+              and any(s in k for s in ("stem3d", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d"))}
+    sd2 = dict(sd)
+    sd2.update(params)
+    disp = O.matching_net_forward(lf, rf, sd2, g["rows"], maxdisp, training=lambda prefix: not prefix.startswith("stem3d0."))
+    gt = torch.from_numpy(g["gt"])
+    mask = (gt < maxdisp) & (gt > 0)
+    loss = F.smooth_l1_loss(disp[mask], gt[mask], reduction="mean")
+    loss.backward()
+    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+    grads["left_fea"], grads["right_fea"] = lf.grad, rf.grad
+    return disp.detach(), loss.item(), grads
+
+
+def test_g6_train_step():
+    """fwd+bwd of the reference's training step (rag.py:155-219): disp, loss and parameter/feature gradients."""
+    g = load_golden("g6_train_step")
+    torch.set_num_threads(8)
+    disp, loss, grads = oracle_train_step(g)
+    np.testing.assert_allclose(disp.numpy(), g["disp"], rtol=1e-4, atol=1e-4)
+    assert abs(loss - float(g["loss"])) < 1e-5
+    checked = 0
+    for k, ref in g.items():
+        if not k.startswith("grad::") or "_2d" in k:      # Feature-Net gradients are outside the oracle
+            continue
+        got = grads[k[6:]].numpy()
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+        checked += 1
+    assert checked > 40
