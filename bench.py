@@ -180,6 +180,78 @@ def end_to_end(device, steps, seed=0):
             "what": f"(left,right)[1,3,{H},{W}] -> disp, Feature Net + Matching Net on HIP, B=1 fp32"}
 
 
+def randomize_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.BatchNorm2d)):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+TRAIN_H, TRAIN_W, TRAIN_B = 192, 384, 4     # reference train crop and per-GPU batch (stereo_dataset.py:59, run_rag.sh)
+
+
+def train_bench(args, device, dist, rank, n_gpus):
+    """BASELINE configs[4]: one data-parallel training step per `step` — images -> Feature Net -> cost volume ->
+    Matching Net -> Disp -> masked smooth-L1 -> backward -> flat-bucket gradient all-reduce (RCCL) -> clip -> SGD,
+    forward and backward on the HIP kernels (rag_amd.autograd).  All units trainable (task 0 of the growth loop)."""
+    import rag_amd
+    from rag_amd.train import GradBucket, make_optimizer, train_step
+    B = args.batch if args.batch > 1 else TRAIN_B
+    torch.manual_seed(0)                                   # identical replicas
+    net = rag_amd.Network(rag_amd.ALL_CONV_GENOTYPE, device, maxdisp=MAXDISP)
+    randomize_bn(net, 1)
+    net = net.to(device).train()
+    bucket = GradBucket(net.parameters())
+    opt = make_optimizer(net.parameters())
+    g = torch.Generator().manual_seed(1234 + rank)         # each replica its own shard of the global batch
+    left = torch.randn((B, 3, TRAIN_H, TRAIN_W), generator=g).to(device)
+    right = torch.randn((B, 3, TRAIN_H, TRAIN_W), generator=g).to(device)
+    gt = (torch.rand((B, TRAIN_H, TRAIN_W), generator=g) * 200).to(device)
+    losses = []
+
+    def step():
+        losses.append(train_step(net, opt, bucket, left, right, gt, clip=5.0, dist=dist))
+
+    dt = timed_region(step, args.steps, args.warmup, dist, torch.cuda.synchronize, device)
+    if rank != 0:
+        return
+    # phase split on rank 0 (extra untimed steps): forward / backward / exchange+update, HIP events on the stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    from rag_amd.train import masked_smooth_l1
+    ev[0].record()
+    disp = net(left, right, 0, net.arch_init)
+    loss = masked_smooth_l1(disp, gt, MAXDISP)
+    ev[1].record()
+    bucket.zero()
+    loss.backward()
+    ev[2].record()
+    bucket.all_reduce_mean(dist)
+    bucket.clip_(5.0)
+    opt.step()
+    ev[3].record()
+    torch.cuda.synchronize()
+    phases = {"forward_ms": round(ev[0].elapsed_time(ev[1]), 3), "backward_ms": round(ev[1].elapsed_time(ev[2]), 3),
+              "allreduce_clip_sgd_ms": round(ev[2].elapsed_time(ev[3]), 3)}
+    ms = dt / args.steps * 1e3
+    line = {
+        "metric": "training stereo pairs/sec at 192x384 D=192 (fwd+bwd+grad all-reduce+SGD step)",
+        "value": round(n_gpus * B * args.steps / dt, 3), "unit": "stereo pairs/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4]: training step, {B} pairs/GPU at {TRAIN_H}x{TRAIN_W}, D={MAXDISP}, all-conv genotype, "
+                               "all units trainable, train-mode BN, SGD(1e-3, 0.9, wd 3e-3), clip 5",
+                   "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}", "collective": "one flat fp32 gradient bucket all-reduce/step",
+                   "grad_bucket_bytes": int(bucket.flat.numel() * 4)},
+        "phases_rank0": phases, "loss_first_last": [round(float(losses[0]), 5), round(float(losses[-1]), 5)],
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
 def cpu_baseline(net, lf, rf):
     """Oracle leg (checker code, allowed here only): one pair of the same workload on host cores."""
     from oracle import matching_oracle as O
@@ -206,6 +278,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="activation storage: f32 (configs[1], default) or bf16 storage / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: time the data-parallel training step instead")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,6 +299,12 @@ def main():
 
     import rag_amd
     rag_amd.load_library()          # fail loudly if the HIP extension is missing
+    if args.train:
+        train_bench(args, device, dist, rank, n_gpus)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     net = build_net(device)
     B, h, w = args.batch, H // 3, W // 3
     g = torch.Generator().manual_seed(1234 + rank)

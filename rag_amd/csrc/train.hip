@@ -92,54 +92,93 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Weight gradient of the 3x3x3 convolution: dw[co][ci][tap] += sum_v g[co][v] * x[ci][v + tap].
-// A workgroup owns a 4 x 8 x 32 voxel tile: it stages the x halo of 4 input channels and the g tile of up to 16
-// output channels in LDS (8 per pass over blockIdx.z); thread t owns the (co, ci, tap) triples t, t+256, ... of this chunk and walks the tile's
-// voxels (LDS-bound, correctness-first form: ~6x the forward's time); one float atomic per triple per workgroup.
-constexpr int WG_TZ = 4, WG_TY = 8, WG_TX = 32, WG_CI = 4, WG_CO = 8;   // LDS: 32.6 KB (x halo) + 32 KB (g tile) < 64 KB static
-__global__ __launch_bounds__(256) void conv3d_k3_wgrad_kernel(const float* __restrict__ x, int64_t x_bstride, const float* __restrict__ g,
-                                                              int64_t g_bstride, int g_ch0, float* __restrict__ dw, int Cin, int Cout,
-                                                              int D, int H, int W, int tiles_x, int tiles_y, int tiles_z) {
-  constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, NV = WG_TZ * WG_TY * WG_TX;
-  __shared__ float xs[WG_CI][HZ][HY][HX];     // 32.6 KB
-  __shared__ float gs[WG_CO][NV];             // 32 KB
-  int bid = blockIdx.x;
-  const int tx_i = bid % tiles_x; bid /= tiles_x;
-  const int ty_i = bid % tiles_y; bid /= tiles_y;
-  const int tz_i = bid % tiles_z;
-  const int b = bid / tiles_z;
-  const int x0 = tx_i * WG_TX, y0 = ty_i * WG_TY, z0 = tz_i * WG_TZ;
-  const int ci0 = blockIdx.y * WG_CI, co0 = blockIdx.z * WG_CO;
-  const int64_t HW = (int64_t)H * W, DHW = HW * D;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < WG_CI * HZ * HY * HX; e += 256) {
-    const int xx = e % HX, yy = (e / HX) % HY, zz = (e / (HX * HY)) % HZ, c = e / (HX * HY * HZ);
-    const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx, gc = ci0 + c;
-    const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && gc < Cin;
-    xs[c][zz][yy][xx] = ok ? x[b * x_bstride + gc * DHW + gz * HW + (int64_t)gy * W + gx] : 0.f;
-  }
-  for (int e = tid; e < WG_CO * NV; e += 256) {
-    const int v = e % NV, c = e / NV;
-    const int xx = v % WG_TX, yy = (v / WG_TX) % WG_TY, zz = v / (WG_TX * WG_TY);
-    const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx, gc = co0 + c;
-    const bool ok = gz < D && gy < H && gx < W && gc < Cout;
-    gs[c][v] = ok ? g[b * g_bstride + (int64_t)(g_ch0 + gc) * DHW + gz * HW + (int64_t)gy * W + gx] : 0.f;
-  }
-  __syncthreads();
-  const int nco = min(WG_CO, Cout - co0), nci = min(WG_CI, Cin - ci0);
-  for (int tr = tid; tr < nco * nci * 27; tr += 256) {
-    const int tap = tr % 27, ci = (tr / 27) % nci, co = tr / (27 * nci);
-    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-    float acc = 0.f;
-    for (int zz = 0; zz < WG_TZ; ++zz)
-      for (int yy = 0; yy < WG_TY; ++yy) {
-        const float* xr = &xs[ci][zz + dz][yy + dy][dx];
-        const float* gr = &gs[co][(zz * WG_TY + yy) * WG_TX];
-#pragma unroll 8
-        for (int xx = 0; xx < WG_TX; ++xx) acc = fmaf(gr[xx], xr[xx], acc);
+// Weight gradient of the 3x3x3 convolution on the MFMA: dw[co][ci][tap] += sum_v g[co][v] * x[ci][v + tap].
+// The contraction index is the voxel.  v_mfma_f32_4x4x1 does 16 independent 4x4 outer products per instruction
+// (D[lane 4b+n][reg m] += A[lane 4b+m] * B[lane 4b+n]); block b takes voxel v_b, its A lanes hold g[co0+m][v_b], its
+// B lanes x[ci0+n][v_b + tap], so one instruction adds 16 voxels to a 4(co) x 4(ci) tile of one tap (256 MACs, the
+// forward kernel's rate).  A workgroup is 3 waves (wave = dz plane of the taps) over a 2 x 8 x 32 voxel tile with the
+// x halo of 4 input channels and the g tile of CG*4 output channels in LDS; each wave keeps 9 (dy,dx) x CG
+// accumulator tiles.  Workgroups are persistent (grid-stride over tiles), so the 16 per-block partial sums are
+// reduced across lanes and flushed with float atomics once per workgroup, not per tile.
+// LDS plane strides are = 16 mod 32 banks: the 4 channel lanes of a block land 2 per bank, the minimum for 64 lanes.
+constexpr int WG_TZ = 2, WG_TY = 8, WG_TX = 32, WG_XS = WG_TX + 2, WG_PS = (WG_TZ + 2) * (WG_TY + 2) * WG_XS;   // 1360
+constexpr int WG_NV = WG_TZ * WG_TY * WG_TX, WG_GP = WG_NV + 16;                                                 // 512, 528
+static_assert(WG_PS % 32 == 16 && WG_GP % 32 == 16, "LDS plane strides must be 16 mod 32");
+struct WgradArgs {
+  const float* x;
+  const float* g;
+  float* dw;
+  int64_t x_bstride, g_bstride;
+  int g_ch0, Cin, Cout, D, H, W, tiles_x, tiles_y, tiles_z, ntiles;
+};
+template <int CG>
+__global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
+  __shared__ float xs[4 * WG_PS];
+  __shared__ float gs[CG * 4 * WG_GP];
+  const int tid = threadIdx.x, dz = tid >> 6, lane = tid & 63, blk = lane >> 2, n = lane & 3;
+  const int ci0 = blockIdx.y * 4, co0 = blockIdx.z * (CG * 4);
+  const int64_t HW = (int64_t)a.H * a.W, DHW = HW * a.D;
+  f32x4 acc[9][CG];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int x0 = (t % a.tiles_x) * WG_TX; t /= a.tiles_x;
+    const int y0 = (t % a.tiles_y) * WG_TY; t /= a.tiles_y;
+    const int z0 = (t % a.tiles_z) * WG_TZ;
+    const int b = t / a.tiles_z;
+    __syncthreads();                                   // the previous tile's reads are done
+    const float* xb = a.x + b * a.x_bstride;
+    for (int e = tid; e < 4 * WG_PS; e += 192) {
+      const int c = e / WG_PS, r = e % WG_PS;
+      const int zz = r / ((WG_TY + 2) * WG_XS), yy = (r / WG_XS) % (WG_TY + 2), xx = r % WG_XS;
+      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx, gc = ci0 + c;
+      const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && gc < a.Cin;
+      xs[e] = ok ? xb[gc * DHW + gz * HW + (int64_t)gy * a.W + gx] : 0.f;
+    }
+    const float* gb = a.g + b * a.g_bstride + (int64_t)(a.g_ch0 + co0) * DHW;
+    for (int e = tid; e < CG * 4 * WG_NV; e += 192) {
+      const int c = e / WG_NV, v = e % WG_NV;
+      const int xx = v % WG_TX, yy = (v / WG_TX) % WG_TY, zz = v / (WG_TX * WG_TY);
+      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx;
+      const bool ok = gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout;
+      gs[c * WG_GP + v] = ok ? gb[c * DHW + gz * HW + (int64_t)gy * a.W + gx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int s = 0; s < WG_NV / 16; ++s) {
+      const int v = s * 16 + blk;                      // this block's voxel of the step: 16 consecutive x
+      const int xx = v % WG_TX, yy = (v / WG_TX) % WG_TY, zz = v / (WG_TX * WG_TY);
+      float av[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) av[c] = gs[(c * 4 + n) * WG_GP + v];
+      const float* xr = xs + n * WG_PS + ((zz + dz) * (WG_TY + 2) + yy) * WG_XS + xx;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const float bv = xr[(t9 / 3) * WG_XS + (t9 % 3)];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[t9][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c], bv, acc[t9][c], 0, 0, 0);
       }
-    atomicAdd(dw + ((int64_t)(co0 + co) * Cin + ci0 + ci) * 27 + tap, acc);
+    }
   }
+  // sum the 16 blocks (lanes 4b+n, fixed n), then lanes 0..3 flush: reg m of lane n is dw[co0+4c+m][ci0+n][dz*9+t9]
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float v = acc[t9][c][m];
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int co = co0 + c * 4 + m, ci = ci0 + n;
+        if (blk == 0 && co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * 27 + dz * 9 + t9, v);
+      }
 }
 
 // dw[co][ci] += sum_v g[co][v] * x[ci][v]   (1x1x1 conv); one workgroup per (voxel slab, co), threads over ci x voxels
@@ -404,12 +443,25 @@ extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const voi
   RAGMI_REQUIRE(x && g && dw, RAGMI_EINVAL, "conv3d_k3_wgrad: null pointer");
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, RAGMI_EINVAL, "conv3d_k3_wgrad: bad size");
   const int tx = (int)ceil_div(W, WG_TX), ty = (int)ceil_div(H, WG_TY), tz = (int)ceil_div(D, WG_TZ);
-  const int64_t nblk = (int64_t)tx * ty * tz * B;
-  RAGMI_REQUIRE(nblk < (1ll << 31) && ceil_div(Cin, WG_CI) <= 65535 && ceil_div(Cout, WG_CO) <= 65535, RAGMI_EUNSUPPORTED,
-                "conv3d_k3_wgrad: grid too large");
-  hipLaunchKernelGGL(conv3d_k3_wgrad_kernel, dim3((unsigned)nblk, (unsigned)ceil_div(Cin, WG_CI), (unsigned)ceil_div(Cout, WG_CO)), dim3(256),
-                     0, static_cast<hipStream_t>(stream), (const float*)x, x_bstride, (const float*)g, g_bstride, g_ch0, (float*)dw, Cin,
-                     Cout, D, H, W, tx, ty, tz);
+  const int64_t ntiles = (int64_t)tx * ty * tz * B;
+  // output-channel groups per workgroup: the largest of 4,3,2,1 that divides the group count (12 -> 3, 16 -> 4, 24 -> 3 x 2)
+  const int ngroups = (int)ceil_div(Cout, 4);
+  int cg = 1;
+  for (int c = 4; c >= 1; --c)
+    if (ngroups % c == 0) { cg = c; break; }
+  const int gy = (int)ceil_div(Cin, 4), gz = ngroups / cg;
+  RAGMI_REQUIRE(ntiles < (1ll << 31) && gy <= 65535 && gz <= 65535, RAGMI_EUNSUPPORTED, "conv3d_k3_wgrad: grid too large");
+  // persistent workgroups: about two per CU over the whole launch; each flushes its partial sums once
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, 512 / ((int64_t)gy * gz)));
+  WgradArgs a{(const float*)x, (const float*)g, (float*)dw, x_bstride, g_bstride, g_ch0, Cin, Cout, D, H, W, tx, ty, tz, (int)ntiles};
+  const dim3 grid(gx, gy, gz), block(192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (cg) {
+    case 4: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<4>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<3>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<1>, grid, block, 0, st, a); break;
+  }
   return check_launch("conv3d_k3_wgrad");
 }
 

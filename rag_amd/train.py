@@ -1,0 +1,84 @@
+"""Host side of the training step (BASELINE config 5; reference: approaches/rag.py:155-219, Appr.train_epoch).
+
+One step = forward (HIP) -> masked smooth-L1 -> backward (HIP, rag_amd.autograd) -> gradient all-reduce ->
+clip_grad_norm_ -> SGD.  Data-parallel replicas (one process per GPU) exchange gradients as ONE flat fp32
+bucket: the `.grad` of every trainable parameter is a view into `GradBucket.flat`, so autograd accumulates
+straight into the buffer RCCL reduces — no pack/unpack copies and a single collective per step (the message is
+< 1 MB, i.e. latency-bound on xGMI: one call is what matters).  Train-mode BatchNorm keeps
+per-replica statistics, like the single-GPU reference per replica.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+class GradBucket:
+    """All trainable parameters' gradients as views of one flat buffer (`requires_grad` is read at construction:
+    build it after `freeze_model` / `modify_param`, rag.py:101-102)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradBucket: no trainable parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self) -> None:
+        """optimizer.zero_grad() that keeps the views (rag.py:213)."""
+        self.flat.zero_()
+        for p, g in zip(self.params, self._views()):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def _views(self):
+        off = 0
+        for p in self.params:
+            yield self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def all_reduce_mean(self, dist=None) -> None:
+        """Sum over replicas in one collective, then divide by the world size."""
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat)
+            self.flat.div_(dist.get_world_size())
+
+    def clip_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ over the bucket (rag.py:215); returns the total norm."""
+        total = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        return total
+
+
+def masked_smooth_l1(disp: torch.Tensor, gt: torch.Tensor, maxdisp: int) -> torch.Tensor:
+    """F.smooth_l1_loss(disp[mask], gt[mask]) with mask = 0 < gt < maxdisp (rag.py:210-211), written without the
+    boolean gather so the step does not synchronise the stream."""
+    mask = ((gt < maxdisp) & (gt > 0)).to(disp.dtype)
+    per = F.smooth_l1_loss(disp, gt, reduction="none")
+    return (per * mask).sum() / mask.sum().clamp_min(1.0)
+
+
+def train_step(net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
+               features: bool = False):
+    """One optimisation step as in Appr.train_epoch (rag.py:204-216).  `features=True`: `net` is a MatchingNet and
+    left/right are Feature-Net outputs.  Returns the (detached) loss."""
+    disp = net(left, right, task_arch) if features else net(left, right, 0, task_arch if task_arch is not None else net.arch_init)
+    loss = masked_smooth_l1(disp, gt, net.maxdisp)
+    bucket.zero()
+    loss.backward()
+    bucket.all_reduce_mean(dist)
+    bucket.clip_(clip)
+    optimizer.step()
+    return loss.detach()
+
+
+def make_optimizer(params, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 3e-3):
+    """rag.py:64-70: SGD over the parameters that require grad."""
+    return torch.optim.SGD([p for p in params if p.requires_grad], lr=lr, momentum=momentum, weight_decay=weight_decay)

@@ -4,6 +4,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -54,3 +55,51 @@ def test_two_rank_gloo_timing_and_sharding(tmp_path):
     assert r["calls"] == 7                                   # W + K steps exactly
     assert 5 * 0.06 * 0.9 <= r["dt"] <= 5 * 0.06 * 3         # max over ranks = the straggler's 5 x 60 ms
     assert torch.equal(r["gathered"], torch.arange(5.0) * 2 + 1)
+
+
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import torch.nn as nn
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rag_amd.train import GradBucket, make_optimizer
+    torch.manual_seed(0)                       # identical replicas
+    model = nn.Sequential(nn.Linear(5, 7), nn.ReLU(), nn.Linear(7, 3))
+    for p in model[0].parameters():            # a frozen ("reused") unit stays out of the bucket
+        p.requires_grad = False
+    bucket = GradBucket(model.parameters())
+    opt = make_optimizer(model.parameters(), lr=0.1, momentum=0.0, weight_decay=0.0)
+    x = torch.randn((4, 5), generator=torch.Generator().manual_seed(100 + rank))
+    bucket.zero()
+    model(x).square().sum().backward()
+    local = bucket.flat.clone()
+    bucket.all_reduce_mean(dist)
+    norm = bucket.clip_(1e9)
+    opt.step()
+    q.put((rank, local.numpy(), bucket.flat.clone().numpy(), float(norm), [p.detach().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_allreduce_two_ranks_gloo():
+    """Config 5's gradient exchange: one flat bucket, sum then / N, identical parameters afterwards on both ranks."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, a0, n0, p0), (_, l1, a1, n1, p1) = res
+    assert l0.shape == (7 * 3 + 3,)                               # only the trainable layer is in the bucket
+    np.testing.assert_allclose(a0, (l0 + l1) / 2, rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(a0, a1)
+    assert n0 == n1
+    for u, v in zip(p0, p1):
+        np.testing.assert_array_equal(u, v)
