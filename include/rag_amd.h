@@ -241,6 +241,11 @@ int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int d, int h, 
 int ragmi_disparity_regression_fwd(const void* prob, void* out, int B, int D, int H, int W,
                                    int dtype, void* stream);
 
+/* ragmi_conv3d_k3_pack with two options used by the training step: transpose != 0 packs the DATA-GRADIENT conv of a forward
+ * weight (source [Cin][Cout][taps], taps flipped), Cout/Cin being those of the packed conv; planar2d != 0: the source is a 2-D
+ * [.,.,3,3] weight living in the dz = 1 plane (Feature Net on depth-1 volumes). */
+int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Training step (BASELINE config 5; the reference runs autograd through the same modules, approaches/rag.py:155-219).
  * fp32 only.  Data-gradients of the convolutions are the forward kernels applied to the output gradient with the
@@ -248,18 +253,27 @@ int ragmi_disparity_regression_fwd(const void* prob, void* out, int B, int D, in
  * Buffers marked (+=) are accumulated into with atomics and must be zeroed by the caller.
  */
 
-/* sum[c] (+=) sum_{b,v} x[b,c,v];  sumsq[c] (+=) sum x^2  — batch statistics of train-mode BatchNorm3d (operations_3d.py:44) */
-int ragmi_bn_stats_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, void* sum, void* sumsq, void* stream);
+/* Train-mode BatchNorm3d statistics (operations_3d.py:44) of the raw conv output x[B,C,DHW]: batch mean / biased variance ->
+ * mean[c], invstd[c], scale[c] = gamma*invstd, shift[c] = beta - mean*scale, and (running_mean != NULL) the momentum update of
+ * running_mean / running_var (unbiased) / num_batches_tracked (int64, may be NULL) with nn.BatchNorm semantics.  Two-level
+ * deterministic reduction; `workspace` holds ragmi_bn_workspace_elems(B, C, DHW) floats (no initialisation needed). */
+int64_t ragmi_bn_workspace_elems(int B, int C, int64_t DHW);
+int ragmi_bn_train_stats_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, const void* gamma, const void* beta,
+                             void* running_mean, void* running_var, void* num_batches_tracked, float momentum, float eps,
+                             void* workspace, void* mean, void* invstd, void* scale, void* shift, void* stream);
 
 /* y[b, y_ch0+c] = act(x[b,c] * scale[c] + shift[c]) (+ res[b, res_ch0+c]) — BN affine + ReLU (+ running sum) as one pass */
 int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* scale, const void* shift, int relu,
                      const void* res, int64_t res_bstride, int res_ch0,
                      void* y, int64_t y_bstride, int y_ch0, int B, int C, int64_t DHW, void* stream);
 
-/* g = dy * [x*scale+shift > 0];  sum_g[c] (+=) sum g;  sum_gx[c] (+=) sum g*x   (ReLU + BN backward, reduction half) */
-int ragmi_bn_act_bwd_reduce(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
-                            const void* scale, const void* shift, int relu, int B, int C, int64_t DHW,
-                            void* sum_g, void* sum_gx, void* stream);
+/* ReLU + BatchNorm adjoint, reduction half: with g = dy * [x*scale+shift > 0] (x = the raw conv output) it reduces sum g and
+ * sum g*x per channel and writes dgamma[c], dbeta[c] and the coefficients of dx = g*c1 + x*c2 + c3 (training != 0: batch
+ * statistics were used; 0: running statistics, c2 = c3 = 0).  Same workspace as ragmi_bn_train_stats_fwd. */
+int ragmi_bn_act_bwd_coeffs(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
+                            const void* scale, const void* shift, int relu, const void* mean, const void* invstd, int training,
+                            int B, int C, int64_t DHW, void* workspace, void* c1, void* c2, void* c3, void* dgamma, void* dbeta,
+                            void* stream);
 
 /* dx[b,c] = g * c1[c] + x * c2[c] + c3[c]   (train-mode BN backward is linear in g and x per channel; eval BN: c2 = c3 = 0) */
 int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
@@ -274,7 +288,7 @@ int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64
 int ragmi_conv3d_k1_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw,
                           int B, int Cin, int Cout, int64_t DHW, void* stream);
 
-/* adjoint of ragmi_trilinear3d_fwd: dx[B,C,Di,Hi,Wi] (+=) scatter of dy[B,C,Do,Ho,Wo] through the same taps */
+/* adjoint of ragmi_trilinear3d_fwd: dx[B,C,Di,Hi,Wi] gathers dy[B,C,Do,Ho,Wo] through the forward's taps (no atomics) */
 int ragmi_trilinear3d_bwd(const void* dy, void* dx, int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                           int align_corners, void* stream);
 

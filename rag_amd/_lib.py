@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _LOCK = threading.Lock()
 
-c_void_p, c_int, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
 class TailSpec(ctypes.Structure):
@@ -62,11 +62,14 @@ SIGNATURES = {
                                             c_int, c_int, c_void_p]),
     "ragmi_add_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
                               c_int, c_int, c_int64, c_int, c_void_p]),
-    "ragmi_bn_stats_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "ragmi_bn_workspace_elems": (c_int64, [c_int, c_int, c_int64]),
+    "ragmi_bn_train_stats_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ragmi_conv3d_k3_pack_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_bn_act_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
                                  c_int, c_int, c_int64, c_void_p]),
-    "ragmi_bn_act_bwd_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
-                                        c_void_p, c_void_p, c_void_p]),
+    "ragmi_bn_act_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                        c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ragmi_bn_act_bwd_apply": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "ragmi_conv3d_k3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

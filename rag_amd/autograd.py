@@ -53,12 +53,12 @@ class ConvBRFn(torch.autograd.Function):
         k = mod._geometry()
         x = _dense(x)
         B, cout = x.shape[0], weight.shape[0]
-        w5 = mod.weight5(weight.detach())
+        w = weight.detach()
         raw = torch.empty((B, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
         if k == 3:
-            ops.conv3d_k3(x, ops.conv3d_k3_pack(w5), cout, None, None, False, raw)
+            ops.conv3d_k3(x, ops.conv3d_k3_pack(w), cout, None, None, False, raw)
         else:
-            ops.conv3d_k1(x, w5.reshape(cout, -1).contiguous(), None, None, False, raw)
+            ops.conv3d_k1(x, w.reshape(cout, -1), None, None, False, raw)
         n = B * _vol(x)
         scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
         y = ops.bn_act(raw, scale, shift, mod.relu) if (mod.use_bn or mod.relu) else raw
@@ -73,15 +73,14 @@ class ConvBRFn(torch.autograd.Function):
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         draw, dgamma, dbeta = _bn_backward(_dense(dy), raw, scale, shift, mean, invstd, mod, n, ctx.training, need_g, need_b)
         dx = dw = None
-        w5 = mod.weight5(weight.detach())
-        cout, cin = w5.shape[:2]
+        w = weight.detach()
+        cout, cin = w.shape[:2]
         if need_x:
             dx = torch.empty_like(x)
             if k == 3:
-                wt = w5.transpose(0, 1).flip(2, 3, 4).contiguous()
-                ops.conv3d_k3(draw, ops.conv3d_k3_pack(wt), cin, None, None, False, dx)
+                ops.conv3d_k3(draw, ops.conv3d_k3_pack(w, transpose=True), cin, None, None, False, dx)
             else:
-                ops.conv3d_k1(draw, w5.reshape(cout, cin).t().contiguous(), None, None, False, dx)
+                ops.conv3d_k1(draw, w.reshape(cout, cin).t().contiguous(), None, None, False, dx)
         if need_w:
             if k == 3:
                 dw5 = ops.conv3d_k3_wgrad(x, draw, cout)
@@ -92,29 +91,25 @@ class ConvBRFn(torch.autograd.Function):
 
 
 def _bn_forward(raw, n, gamma, beta, mod):
-    """Shared BatchNorm bookkeeping of the ConvBR forwards: (scale, shift, mean, invstd, training)."""
+    """BatchNorm bookkeeping of the ConvBR forwards: (scale, shift, mean, invstd, training).  Train mode: one call computes the
+    batch statistics, folds them and updates the running statistics (ragmi_bn_train_stats_fwd)."""
     bn = mod.bn
     cout = raw.shape[1]
     if not mod.use_bn:
         return torch.ones(cout, device=raw.device), torch.zeros(cout, device=raw.device), None, None, False
-    training = bool(bn.training)
-    g, b = gamma.detach().float(), beta.detach().float()
-    if training:
-        s, q = ops.bn_stats(raw)
-        mean = s / n
-        var = (q / n - mean * mean).clamp_min_(0.0)
-        with torch.no_grad():                                   # nn.BatchNorm running statistics (momentum form)
-            if bn.track_running_stats and bn.running_mean is not None:
-                bn.num_batches_tracked += 1
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
-    else:
-        mean, var = bn.running_mean.detach().float(), bn.running_var.detach().float()
+    g, b = gamma.detach(), beta.detach()
+    if bn.training:
+        if bn.momentum is None:
+            raise NotImplementedError("rag_amd: BatchNorm momentum=None (cumulative average) is not built; the reference uses 0.1")
+        track = bn.track_running_stats and bn.running_mean is not None
+        st = ops.bn_train_stats(raw, g, b, bn.running_mean if track else None, bn.running_var if track else None,
+                                bn.num_batches_tracked if track else None, bn.momentum, bn.eps)
+        return st[2], st[3], st[0], st[1], True
+    mean, var = bn.running_mean.detach(), bn.running_var.detach()
     invstd = torch.rsqrt(var + bn.eps)
     scale = (g * invstd).contiguous()
     shift = (b - mean * scale).contiguous()
-    return scale, shift, mean, invstd, training
+    return scale, shift, mean, invstd, False
 
 
 def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, need_b):
@@ -122,19 +117,13 @@ def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, 
     if not (mod.use_bn or mod.relu):
         return dy, None, None
     dgamma = dbeta = None
-    zeros = torch.zeros_like(scale)
     if mod.use_bn and (training or need_g or need_b):
-        sg, sgx = ops.bn_act_bwd_reduce(dy, 0, raw, scale, shift, mod.relu)
-        sgxh = invstd * (sgx - mean * sg)                       # sum of g * xhat
-        dgamma, dbeta = (sgxh if need_g else None), (sg if need_b else None)
-    if training:
-        # dx = a (g - mean(g) - xhat mean(g xhat)), a = gamma * invstd: linear in g and x per channel
-        mg, mgxh = sg / n, sgxh / n
-        c1 = scale
-        c2 = (-scale * invstd * mgxh).contiguous()
-        c3 = (scale * (invstd * mean * mgxh - mg)).contiguous()
+        co = ops.bn_act_bwd_coeffs(dy, 0, raw, scale, shift, mod.relu, mean, invstd, training)
+        c1, c2, c3 = co[0], co[1], co[2]
+        dgamma, dbeta = (co[3] if need_g else None), (co[4] if need_b else None)
     else:
-        c1, c2, c3 = scale, zeros, zeros
+        c1 = scale
+        c2 = c3 = torch.zeros_like(scale)
     return ops.bn_act_bwd_apply(dy, 0, raw, scale, shift, mod.relu, c1, c2, c3), dgamma, dbeta
 
 

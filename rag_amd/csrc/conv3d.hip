@@ -24,8 +24,10 @@
 namespace ragmi {
 
 // one pack element per thread: packed[((g*nchunks + ch)*NVG + v)*64 + lane]
+// transpose: the source is the weight of the FORWARD conv, [Cin][Cout][taps]; pack its data-gradient conv
+// W'[co][ci][tap] = W[ci][co][taps-1-tap].  planar: the source has 9 taps (a 2-D 3x3 weight) living in the dz = 1 plane.
 __global__ void conv3d_k3_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin,
-                                      int nchunks, int64_t total) {
+                                      int nchunks, int64_t total, int transpose, int planar) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int lane = (int)(idx & 63);
@@ -39,7 +41,14 @@ __global__ void conv3d_k3_pack_kernel(const float* __restrict__ w, float* __rest
   float val = 0.f;
   if (q < NPAIR) {
     const int ci = ch * CK + q / 27, tap = q % 27, co = g * 4 + m;
-    if (ci < Cin && co < Cout) val = w[((int64_t)co * Cin + ci) * 27 + tap];
+    if (ci < Cin && co < Cout) {
+      const int taps = planar ? 9 : 27;
+      int t = planar ? tap - 9 : tap;                    // planar: only dz == 1 (taps 9..17) is non-zero
+      if (t >= 0 && t < taps) {
+        if (transpose) t = taps - 1 - t;
+        val = transpose ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t];
+      }
+    }
   }
   packed[idx] = val;
 }
@@ -102,6 +111,11 @@ extern "C" int64_t ragmi_conv3d_k3_packed_elems(int Cout, int Cin) {
 }
 
 extern "C" int ragmi_conv3d_k3_pack(const void* weight, void* packed, int Cout, int Cin, int dtype, void* stream) {
+  return ragmi_conv3d_k3_pack_ex(weight, packed, Cout, Cin, 0, 0, dtype, stream);
+}
+
+extern "C" int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int dtype,
+                                       void* stream) {
   using namespace ragmi;
   RAGMI_REQUIRE(weight && packed, RAGMI_EINVAL, "conv3d_k3_pack: null pointer");
   RAGMI_REQUIRE(Cout > 0 && Cin > 0, RAGMI_EINVAL, "conv3d_k3_pack: non-positive size");
@@ -109,7 +123,7 @@ extern "C" int ragmi_conv3d_k3_pack(const void* weight, void* packed, int Cout, 
   const int64_t total = ragmi_conv3d_k3_packed_elems(Cout, Cin);
   hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), (const float*)weight, (float*)packed, Cout, Cin,
-                     (Cin + CK - 1) / CK, total);
+                     (Cin + CK - 1) / CK, total, transpose ? 1 : 0, planar2d ? 1 : 0);
   return check_launch("conv3d_k3_pack");
 }
 

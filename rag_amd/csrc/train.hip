@@ -8,21 +8,11 @@
 namespace ragmi {
 
 // ---------------------------------------------------------------------------------------------------------------
-// per-channel sum / sum of squares of x[B, C, DHW] (batch stride in elements; channel planes dense)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t dhw,
-                                                       float* __restrict__ sum, float* __restrict__ sumsq) {
-  const int c = blockIdx.y, b = blockIdx.z;
-  const float* p = x + b * x_bstride + (int64_t)c * dhw;
-  float s = 0.f, q = 0.f;
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < dhw; i += (int64_t)gridDim.x * 1024) {
-    if (i + 3 < dhw && (dhw & 3) == 0) {
-      const float4 v = *reinterpret_cast<const float4*>(p + i);
-      s += (v.x + v.y) + (v.z + v.w);
-      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-    } else {
-      for (int k = 0; k < 4 && i + k < dhw; ++k) { const float v = p[i + k]; s += v; q += v * v; }
-    }
-  }
+// Per-channel reductions are two-level and deterministic: every workgroup writes its partial pair to
+// part[(c * nparts + b * gridDim.x + blockIdx.x) * 2 + {0,1}], a one-workgroup-per-channel kernel then sums the
+// partials in double and does the per-channel arithmetic (no same-address float atomics, no zero-filled buffers,
+// no host-side vector math).
+__device__ __forceinline__ void block_pair_store(float s, float q, float* __restrict__ part, int64_t slot) {
   __shared__ float rs[256], rq[256];
   rs[threadIdx.x] = s; rq[threadIdx.x] = q;
   __syncthreads();
@@ -30,7 +20,77 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rq[threadIdx.x] += rq[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { atomicAdd(sum + c, rs[0]); atomicAdd(sumsq + c, rq[0]); }
+  if (threadIdx.x == 0) { part[slot * 2] = rs[0]; part[slot * 2 + 1] = rq[0]; }
+}
+__device__ __forceinline__ void block_pair_sum(const float* __restrict__ part, int nparts, int c, double& s, double& q) {
+  __shared__ double ds[256], dq[256];
+  double ls = 0.0, lq = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { ls += part[((int64_t)c * nparts + i) * 2]; lq += part[((int64_t)c * nparts + i) * 2 + 1]; }
+  ds[threadIdx.x] = ls; dq[threadIdx.x] = lq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ds[threadIdx.x] += ds[threadIdx.x + o]; dq[threadIdx.x] += dq[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  s = ds[0]; q = dq[0];
+}
+
+// partial (sum, sum of squares) of x[B, C, DHW] (batch stride in elements; channel planes dense)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t dhw,
+                                                       float* __restrict__ part, int nparts) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* p = x + b * x_bstride + (int64_t)c * dhw;
+  const bool vec = (dhw & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  float s = 0.f, q = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < dhw; i += (int64_t)gridDim.x * 1024) {
+    if (vec) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    } else {
+      for (int k = 0; k < 4 && i + k < dhw; ++k) { const float v = p[i + k]; s += v; q += v * v; }
+    }
+  }
+  block_pair_store(s, q, part, (int64_t)c * nparts + (int64_t)b * gridDim.x + blockIdx.x);
+}
+
+// train-mode BatchNorm bookkeeping of one channel per workgroup: batch mean / biased variance -> (mean, invstd, scale,
+// shift) and the momentum update of the running statistics (unbiased variance), nn.BatchNorm semantics
+struct BnFinalizeArgs {
+  const float* part;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  long long* num_batches_tracked;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+  int nparts;
+  double n;
+  float eps, momentum;
+};
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalizeArgs a) {
+  const int c = blockIdx.x;
+  double s, q;
+  block_pair_sum(a.part, a.nparts, c, s, q);
+  if (threadIdx.x != 0) return;
+  const double mean = s / a.n;
+  double var = q / a.n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float sc = a.gamma[c] * invstd;
+  a.mean[c] = (float)mean;
+  a.invstd[c] = invstd;
+  a.scale[c] = sc;
+  a.shift[c] = a.beta[c] - (float)mean * sc;
+  if (a.running_mean) {
+    const float m = a.momentum;
+    a.running_mean[c] = (1.f - m) * a.running_mean[c] + m * (float)mean;
+    a.running_var[c] = (1.f - m) * a.running_var[c] + m * (float)(var * (a.n / (a.n > 1.0 ? a.n - 1.0 : 1.0)));
+    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+  }
 }
 
 // y[b, y_ch0 + c] = act(x[b, c] * scale[c] + shift[c]) (+ res[b, res_ch0 + c])
@@ -39,40 +99,87 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
                                                      int64_t res_bstride, int res_ch0, float* __restrict__ y, int64_t y_bstride,
                                                      int y_ch0, int64_t dhw) {
   const int c = blockIdx.y, b = blockIdx.z;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= dhw) return;
-  float v = fmaf(x[b * x_bstride + (int64_t)c * dhw + i], scale[c], shift[c]);
-  if (relu) v = fmaxf(v, 0.f);
-  if (res) v += res[b * res_bstride + (int64_t)(res_ch0 + c) * dhw + i];
-  y[b * y_bstride + (int64_t)(y_ch0 + c) * dhw + i] = v;
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= dhw) return;
+  const float* px = x + b * x_bstride + (int64_t)c * dhw;
+  const float* pr = res ? res + b * res_bstride + (int64_t)(res_ch0 + c) * dhw : nullptr;
+  float* py = y + b * y_bstride + (int64_t)(y_ch0 + c) * dhw;
+  const float sc = scale[c], sh = shift[c];
+  auto one = [&](float xv, float rv) {
+    float v = fmaf(xv, sc, sh);
+    if (relu) v = fmaxf(v, 0.f);
+    return v + rv;
+  };
+  const uintptr_t al = reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(py) | reinterpret_cast<uintptr_t>(pr);
+  if ((dhw & 3) == 0 && (al & 15) == 0) {
+    const float4 xv = *reinterpret_cast<const float4*>(px + i0);
+    const float4 rv = pr ? *reinterpret_cast<const float4*>(pr + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(py + i0) = make_float4(one(xv.x, rv.x), one(xv.y, rv.y), one(xv.z, rv.z), one(xv.w, rv.w));
+  } else {
+    for (int k = 0; k < 4 && i0 + k < dhw; ++k) py[i0 + k] = one(px[i0 + k], pr ? pr[i0 + k] : 0.f);
+  }
 }
 
-// g = dy * (x*scale+shift > 0 if relu);  sum_g[c] += sum g;  sum_gx[c] += sum g*x
+// g = dy * (x*scale+shift > 0 if relu);  partial (sum g, sum g*x) per workgroup
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dy, int64_t dy_bstride, int dy_ch0,
                                                                 const float* __restrict__ x, int64_t x_bstride,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                int relu, int64_t dhw, float* __restrict__ sum_g,
-                                                                float* __restrict__ sum_gx) {
+                                                                int relu, int64_t dhw, float* __restrict__ part, int nparts) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float* pd = dy + b * dy_bstride + (int64_t)(dy_ch0 + c) * dhw;
   const float* px = x + b * x_bstride + (int64_t)c * dhw;
   const float sc = scale[c], sh = shift[c];
+  const bool vec = (dhw & 3) == 0 && (((reinterpret_cast<uintptr_t>(pd) | reinterpret_cast<uintptr_t>(px)) & 15) == 0);
   float s = 0.f, q = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dhw; i += (int64_t)gridDim.x * 256) {
-    const float xv = px[i];
-    float g = pd[i];
+  auto one = [&](float g, float xv) {
     if (relu && fmaf(xv, sc, sh) <= 0.f) g = 0.f;
     s += g;
     q = fmaf(g, xv, q);
+  };
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < dhw; i += (int64_t)gridDim.x * 1024) {
+    if (vec) {
+      const float4 g4 = *reinterpret_cast<const float4*>(pd + i), x4 = *reinterpret_cast<const float4*>(px + i);
+      one(g4.x, x4.x); one(g4.y, x4.y); one(g4.z, x4.z); one(g4.w, x4.w);
+    } else {
+      for (int k = 0; k < 4 && i + k < dhw; ++k) one(pd[i + k], px[i + k]);
+    }
   }
-  __shared__ float rs[256], rq[256];
-  rs[threadIdx.x] = s; rq[threadIdx.x] = q;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rq[threadIdx.x] += rq[threadIdx.x + o]; }
-    __syncthreads();
+  block_pair_store(s, q, part, (int64_t)c * nparts + (int64_t)b * gridDim.x + blockIdx.x);
+}
+
+// per-channel coefficients of the ReLU+BN adjoint dx = g*c1 + x*c2 + c3, plus dgamma / dbeta
+struct BnCoeffArgs {
+  const float* part;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  float* c1;
+  float* c2;
+  float* c3;
+  float* dgamma;
+  float* dbeta;
+  int nparts, training;
+  double n;
+};
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(BnCoeffArgs a) {
+  const int c = blockIdx.x;
+  double sg, sgx;
+  block_pair_sum(a.part, a.nparts, c, sg, sgx);
+  if (threadIdx.x != 0) return;
+  const double mean = a.mean[c], invstd = a.invstd[c], sc = a.scale[c];
+  const double sgxh = invstd * (sgx - mean * sg);          // sum of g * xhat
+  a.dgamma[c] = (float)sgxh;
+  a.dbeta[c] = (float)sg;
+  a.c1[c] = (float)sc;
+  if (a.training) {
+    // dx = a (g - mean(g) - xhat mean(g xhat)), a = gamma * invstd: linear in g and x per channel
+    const double mg = sg / a.n, mgxh = sgxh / a.n;
+    a.c2[c] = (float)(-sc * invstd * mgxh);
+    a.c3[c] = (float)(sc * (invstd * mean * mgxh - mg));
+  } else {
+    a.c2[c] = 0.f;
+    a.c3[c] = 0.f;
   }
-  if (threadIdx.x == 0) { atomicAdd(sum_g + c, rs[0]); atomicAdd(sum_gx + c, rq[0]); }
 }
 
 // dx[b, c] = g * c1[c] + x * c2[c] + c3[c]   (train-mode BN backward is linear in g and x per channel; eval: c2 = c3 = 0)
@@ -83,12 +190,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                                const float* __restrict__ c3, float* __restrict__ dx,
                                                                int64_t dx_bstride, int64_t dhw) {
   const int c = blockIdx.y, b = blockIdx.z;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= dhw) return;
-  const float xv = x[b * x_bstride + (int64_t)c * dhw + i];
-  float g = dy[b * dy_bstride + (int64_t)(dy_ch0 + c) * dhw + i];
-  if (relu && fmaf(xv, scale[c], shift[c]) <= 0.f) g = 0.f;
-  dx[b * dx_bstride + (int64_t)c * dhw + i] = fmaf(g, c1[c], fmaf(xv, c2[c], c3[c]));
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= dhw) return;
+  const float* px = x + b * x_bstride + (int64_t)c * dhw;
+  const float* pg = dy + b * dy_bstride + (int64_t)(dy_ch0 + c) * dhw;
+  float* po = dx + b * dx_bstride + (int64_t)c * dhw;
+  const float sc = scale[c], sh = shift[c], k1 = c1[c], k2 = c2[c], k3 = c3[c];
+  auto one = [&](float g, float xv) {
+    if (relu && fmaf(xv, sc, sh) <= 0.f) g = 0.f;
+    return fmaf(g, k1, fmaf(xv, k2, k3));
+  };
+  const uintptr_t al = reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(pg) | reinterpret_cast<uintptr_t>(po);
+  if ((dhw & 3) == 0 && (al & 15) == 0) {
+    const float4 g4 = *reinterpret_cast<const float4*>(pg + i0), x4 = *reinterpret_cast<const float4*>(px + i0);
+    *reinterpret_cast<float4*>(po + i0) = make_float4(one(g4.x, x4.x), one(g4.y, x4.y), one(g4.z, x4.z), one(g4.w, x4.w));
+  } else {
+    for (int k = 0; k < 4 && i0 + k < dhw; ++k) po[i0 + k] = one(pg[i0 + k], px[i0 + k]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -204,7 +322,10 @@ __global__ __launch_bounds__(256) void conv3d_k1_wgrad_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// adjoint of the trilinear resample: dx (pre-zeroed) += scatter of dy through the same 8 (index, weight) pairs
+// adjoint of the trilinear resample as a GATHER: one thread per input voxel sums, over the output voxels whose taps
+// touch it, dy * (product of the per-axis tap weights) — no atomics, no zero-filled destination, deterministic.
+// Per axis the touching outputs are a contiguous range found from the inverse of ATen's source-index map and then
+// trimmed with the exact forward rule (lin_index), so the weights are the forward's bit for bit.
 struct TriBwdArgs {
   const float* dy;
   float* dx;
@@ -212,29 +333,46 @@ struct TriBwdArgs {
   float sd, sh, sw;
   int align;
 };
+__device__ __forceinline__ float tap_weight(int o, int i, int in_size, int out_size, float scale, int align) {
+  const LinIdx l = lin_index(o, in_size, out_size, scale, align);
+  return (l.i0 == i ? l.w0 : 0.f) + (l.i1 == i ? l.w1 : 0.f);     // i0 == i1 at the clamped end: both taps land here
+}
+__device__ __forceinline__ void tap_range(int i, int in_size, int out_size, float scale, int align, int& lo, int& hi) {
+  if (in_size == out_size) { lo = hi = i; return; }
+  float a = 0.f, b = (float)(out_size - 1);
+  if (scale > 0.f) {
+    if (align) { a = ((float)i - 1.f) / scale; b = ((float)i + 1.f) / scale; }
+    else { a = ((float)i - 0.5f) / scale - 0.5f; b = ((float)i + 1.5f) / scale - 0.5f; }
+  }
+  lo = max(0, (int)floorf(a) - 1);
+  hi = min(out_size - 1, (int)ceilf(b) + 1);
+  while (lo <= hi && tap_weight(lo, i, in_size, out_size, scale, align) == 0.f) ++lo;
+  while (hi >= lo && tap_weight(hi, i, in_size, out_size, scale, align) == 0.f) --hi;
+}
 __global__ __launch_bounds__(256) void trilinear_bwd_kernel(TriBwdArgs a) {
-  const int64_t ovol = (int64_t)a.Do * a.Ho * a.Wo;
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= ovol) return;
+  const int64_t ivol = (int64_t)a.Di * a.Hi * a.Wi, ovol = (int64_t)a.Do * a.Ho * a.Wo;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= ivol) return;
   const int b = blockIdx.y;
-  const int ox = (int)(o % a.Wo);
-  const int64_t t = o / a.Wo;
-  const int oy = (int)(t % a.Ho), oz = (int)(t / a.Ho);
-  const LinIdx lz = lin_index(oz, a.Di, a.Do, a.sd, a.align);
-  const LinIdx ly = lin_index(oy, a.Hi, a.Ho, a.sh, a.align);
-  const LinIdx lx = lin_index(ox, a.Wi, a.Wo, a.sw, a.align);
-  const int64_t ivol = (int64_t)a.Di * a.Hi * a.Wi;
-  const int zi[2] = {lz.i0, lz.i1}, yi[2] = {ly.i0, ly.i1}, xi[2] = {lx.i0, lx.i1};
-  const float zw[2] = {lz.w0, lz.w1}, yw[2] = {ly.w0, ly.w1}, xw[2] = {lx.w0, lx.w1};
+  const int ix = (int)(p % a.Wi);
+  const int64_t t = p / a.Wi;
+  const int iy = (int)(t % a.Hi), iz = (int)(t / a.Hi);
+  int z0, z1, y0, y1, x0, x1;
+  tap_range(iz, a.Di, a.Do, a.sd, a.align, z0, z1);
+  tap_range(iy, a.Hi, a.Ho, a.sh, a.align, y0, y1);
+  tap_range(ix, a.Wi, a.Wo, a.sw, a.align, x0, x1);
   for (int c = 0; c < a.C; ++c) {
-    const float gv = a.dy[((int64_t)b * a.C + c) * ovol + o];
-    float* pc = a.dx + ((int64_t)b * a.C + c) * ivol;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int kz = k >> 2, ky = (k >> 1) & 1, kx = k & 1;
-      const float w = zw[kz] * yw[ky] * xw[kx];
-      if (w != 0.f) atomicAdd(pc + ((int64_t)zi[kz] * a.Hi + yi[ky]) * a.Wi + xi[kx], gv * w);
+    const float* pc = a.dy + ((int64_t)b * a.C + c) * ovol;
+    float acc = 0.f;
+    for (int oz = z0; oz <= z1; ++oz) {
+      const float wz = tap_weight(oz, iz, a.Di, a.Do, a.sd, a.align);
+      for (int oy = y0; oy <= y1; ++oy) {
+        const float wzy = wz * tap_weight(oy, iy, a.Hi, a.Ho, a.sh, a.align);
+        const float* pr = pc + ((int64_t)oz * a.Ho + oy) * a.Wo;
+        for (int ox = x0; ox <= x1; ++ox) acc = fmaf(pr[ox], wzy * tap_weight(ox, ix, a.Wi, a.Wo, a.sw, a.align), acc);
+      }
     }
+    a.dx[((int64_t)b * a.C + c) * ivol + p] = acc;
   }
 }
 
@@ -390,14 +528,36 @@ __global__ __launch_bounds__(256) void disparity_regression_bwd_kernel(const flo
 }  // namespace ragmi
 
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int ragmi_bn_stats_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, void* sum, void* sumsq, void* stream) {
+// workgroups along the voxel axis of the two-level reductions: enough to fill the chip, few enough that the second level is short
+namespace ragmi {
+static unsigned reduce_blocks(int B, int C, int64_t DHW) {
+  const int64_t want = ceil_div(4096, (int64_t)B * C);
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, ceil_div(DHW, 1024)), 256));
+}
+}  // namespace ragmi
+
+extern "C" int64_t ragmi_bn_workspace_elems(int B, int C, int64_t DHW) {
+  if (B <= 0 || C <= 0 || DHW <= 0) return 0;
+  return (int64_t)2 * C * B * ragmi::reduce_blocks(B, C, DHW);
+}
+
+extern "C" int ragmi_bn_train_stats_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, const void* gamma, const void* beta,
+                                        void* running_mean, void* running_var, void* num_batches_tracked, float momentum, float eps,
+                                        void* workspace, void* mean, void* invstd, void* scale, void* shift, void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(x && sum && sumsq, RAGMI_EINVAL, "bn_stats: null pointer");
-  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_stats: bad size");
-  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(DHW, 1024), 256);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)x, x_bstride, DHW,
-                     (float*)sum, (float*)sumsq);
-  return check_launch("bn_stats");
+  RAGMI_REQUIRE(x && gamma && beta && workspace && mean && invstd && scale && shift, RAGMI_EINVAL, "bn_train_stats: null pointer");
+  RAGMI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), RAGMI_EINVAL, "bn_train_stats: running_mean/var go together");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_train_stats: bad size");
+  RAGMI_REQUIRE(momentum >= 0.f && momentum <= 1.f, RAGMI_EUNSUPPORTED, "bn_train_stats: momentum must be in [0,1] (cumulative average not built)");
+  const unsigned gx = reduce_blocks(B, C, DHW);
+  const int nparts = (int)(gx * B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, st, (const float*)x, x_bstride, DHW, (float*)workspace, nparts);
+  BnFinalizeArgs a{(const float*)workspace, (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var,
+                   (long long*)num_batches_tracked, (float*)mean, (float*)invstd, (float*)scale, (float*)shift, nparts,
+                   (double)B * (double)DHW, eps, momentum};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, a);
+  return check_launch("bn_train_stats");
 }
 
 extern "C" int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* scale, const void* shift, int relu, const void* res,
@@ -406,23 +566,29 @@ extern "C" int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* sc
   using namespace ragmi;
   RAGMI_REQUIRE(x && scale && shift && y, RAGMI_EINVAL, "bn_act: null pointer");
   RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act: bad size");
-  hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)ceil_div(DHW, 256), C, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)ceil_div(DHW, 1024), C, B), dim3(256), 0, static_cast<hipStream_t>(stream),
                      (const float*)x, x_bstride, (const float*)scale, (const float*)shift, relu, (const float*)res, res_bstride, res_ch0,
                      (float*)y, y_bstride, y_ch0, DHW);
   return check_launch("bn_act");
 }
 
-extern "C" int ragmi_bn_act_bwd_reduce(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
-                                       const void* scale, const void* shift, int relu, int B, int C, int64_t DHW, void* sum_g,
-                                       void* sum_gx, void* stream) {
+extern "C" int ragmi_bn_act_bwd_coeffs(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
+                                      const void* scale, const void* shift, int relu, const void* mean, const void* invstd, int training,
+                                      int B, int C, int64_t DHW, void* workspace, void* c1, void* c2, void* c3, void* dgamma, void* dbeta,
+                                      void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(dy && x && scale && shift && sum_g && sum_gx, RAGMI_EINVAL, "bn_act_bwd_reduce: null pointer");
-  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act_bwd_reduce: bad size");
-  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(DHW, 256), 256);
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(gx, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)dy,
-                     dy_bstride, dy_ch0, (const float*)x, x_bstride, (const float*)scale, (const float*)shift, relu, DHW, (float*)sum_g,
-                     (float*)sum_gx);
-  return check_launch("bn_act_bwd_reduce");
+  RAGMI_REQUIRE(dy && x && scale && shift && mean && invstd && workspace && c1 && c2 && c3 && dgamma && dbeta, RAGMI_EINVAL,
+                "bn_act_bwd_coeffs: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act_bwd_coeffs: bad size");
+  const unsigned gx = reduce_blocks(B, C, DHW);
+  const int nparts = (int)(gx * B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(gx, C, B), dim3(256), 0, st, (const float*)dy, dy_bstride, dy_ch0, (const float*)x,
+                     x_bstride, (const float*)scale, (const float*)shift, relu, DHW, (float*)workspace, nparts);
+  BnCoeffArgs a{(const float*)workspace, (const float*)mean, (const float*)invstd, (const float*)scale, (float*)c1, (float*)c2, (float*)c3,
+                (float*)dgamma, (float*)dbeta, nparts, training ? 1 : 0, (double)B * (double)DHW};
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, st, a);
+  return check_launch("bn_act_bwd_coeffs");
 }
 
 extern "C" int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
@@ -431,7 +597,7 @@ extern "C" int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy
   using namespace ragmi;
   RAGMI_REQUIRE(dy && x && scale && shift && c1 && c2 && c3 && dx, RAGMI_EINVAL, "bn_act_bwd_apply: null pointer");
   RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act_bwd_apply: bad size");
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)ceil_div(DHW, 256), C, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)ceil_div(DHW, 1024), C, B), dim3(256), 0, static_cast<hipStream_t>(stream),
                      (const float*)dy, dy_bstride, dy_ch0, (const float*)x, x_bstride, (const float*)scale, (const float*)shift, relu,
                      (const float*)c1, (const float*)c2, (const float*)c3, (float*)dx, dx_bstride, DHW);
   return check_launch("bn_act_bwd_apply");
@@ -484,7 +650,7 @@ extern "C" int ragmi_trilinear3d_bwd(const void* dy, void* dx, int B, int C, int
                 "trilinear3d_bwd: bad size");
   TriBwdArgs a{(const float*)dy, (float*)dx, C, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do, align_corners),
                lin_scale(Hi, Ho, align_corners), lin_scale(Wi, Wo, align_corners), align_corners ? 1 : 0};
-  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Do * Ho * Wo, 256), B), dim3(256), 0,
+  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Di * Hi * Wi, 256), B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("trilinear3d_bwd");
 }

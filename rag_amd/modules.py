@@ -105,11 +105,7 @@ class _ConvBR(nn.Module):
                 if k == -3 or (k == 3 and self._small()):
                     wk = w.contiguous()                      # strided 2-D stem / VALU form read the raw weight
                 elif k == 3:
-                    if self.NDIM == 2:                       # 2-D 3x3 = 3-D 3x3x3 on a depth-1 volume: only the middle z-slice is non-zero
-                        w3 = w.new_zeros((w.shape[0], w.shape[1], 3, 3, 3))
-                        w3[:, :, 1] = w
-                        w = w3
-                    wk = ops.conv3d_k3_pack(w)
+                    wk = ops.conv3d_k3_pack(w)               # a 2-D 3x3 packs as the dz = 1 plane of a 3x3x3 (depth-1 volumes)
                 else:
                     wk = w.reshape(w.shape[0], w.shape[1]).contiguous()
                 if self.use_bn:
@@ -121,16 +117,6 @@ class _ConvBR(nn.Module):
                     scale = shift = None
             self._cache = (stamp, wk, scale, shift)
         return self._cache[1], self._cache[2], self._cache[3]
-
-    def weight5(self, w: torch.Tensor) -> torch.Tensor:
-        """The conv weight as a 5-D [Cout, Cin, kd, kh, kw] tensor (2-D 3x3: embedded in the middle z-slice of a 3x3x3)."""
-        if self.NDIM == 3:
-            return w
-        if w.shape[-1] == 1:
-            return w.reshape(w.shape[0], w.shape[1], 1, 1, 1)
-        w3 = w.new_zeros((w.shape[0], w.shape[1], 3, 3, 3))
-        w3[:, :, 1] = w
-        return w3
 
     def autograd_mode(self, *inputs) -> bool:
         """Training composition needed: a gradient is wanted, or this unit's BatchNorm uses batch statistics."""

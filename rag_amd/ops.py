@@ -105,17 +105,21 @@ def costvol(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, out: 
     return out
 
 
-def conv3d_k3_pack(weight: torch.Tensor) -> torch.Tensor:
-    """Pre-pack an nn.Conv3d weight [Cout, Cin, 3, 3, 3] for conv3d_k3."""
+def conv3d_k3_pack(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """Pre-pack an nn.Conv3d weight [Cout, Cin, 3, 3, 3] (or an nn.Conv2d weight [Cout, Cin, 3, 3], run as the dz = 1 plane of
+    a 3x3x3 on depth-1 volumes) for conv3d_k3.  transpose=True packs the conv that computes the DATA GRADIENT of this weight's
+    conv (channels swapped, taps flipped): conv3d_k3(dy, packed, cout=Cin, ...) is then dL/dx."""
     _need_gpu(weight)
-    Cout, Cin = weight.shape[:2]
-    if tuple(weight.shape[2:]) != (3, 3, 3):
-        raise ValueError("conv3d_k3_pack: weight must be [Cout, Cin, 3, 3, 3]")
+    planar = weight.dim() == 4
+    if tuple(weight.shape[2:]) != ((3, 3) if planar else (3, 3, 3)):
+        raise ValueError("conv3d_k3_pack: weight must be [Cout, Cin, 3, 3, 3] (or [Cout, Cin, 3, 3])")
+    Cout, Cin = (weight.shape[1], weight.shape[0]) if transpose else (weight.shape[0], weight.shape[1])
     lib = load_library()
     n = lib.ragmi_conv3d_k3_packed_elems(Cout, Cin)
     packed = torch.empty((n,), device=weight.device, dtype=torch.float32)
     w = weight.detach().contiguous()
-    check(lib.ragmi_conv3d_k3_pack(w.data_ptr(), packed.data_ptr(), Cout, Cin, F32, _stream()), "conv3d_k3_pack")
+    check(lib.ragmi_conv3d_k3_pack_ex(w.data_ptr(), packed.data_ptr(), Cout, Cin, int(transpose), int(planar), F32, _stream()),
+          "conv3d_k3_pack")
     return packed
 
 
@@ -346,13 +350,23 @@ def _vol(t: torch.Tensor) -> int:
     return n
 
 
-def bn_stats(x: torch.Tensor):
-    """per-channel (sum, sum of squares) of x[B,C,...] (fp32 atomics into zeroed buffers)."""
-    _need_gpu(x)
+def bn_train_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
+                   running_var: Optional[torch.Tensor], num_batches_tracked: Optional[torch.Tensor], momentum: float, eps: float):
+    """Train-mode BatchNorm statistics of the raw conv output x[B,C,...]: returns the [4, C] tensor (mean, invstd, scale, shift)
+    and updates the running statistics in place (ragmi_bn_train_stats_fwd)."""
+    _need_gpu(x, gamma, beta, running_mean, running_var)
     B, C = x.shape[:2]
-    s = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-    check(load_library().ragmi_bn_stats_fwd(x.data_ptr(), _planes(x), B, C, _vol(x), s[0].data_ptr(), s[1].data_ptr(), _stream()), "bn_stats")
-    return s[0], s[1]
+    lib = load_library()
+    ws = torch.empty((lib.ragmi_bn_workspace_elems(B, C, _vol(x)),), device=x.device, dtype=torch.float32)
+    out = torch.empty((4, C), device=x.device, dtype=torch.float32)
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise RuntimeError("bn_train_stats: num_batches_tracked must be int64")
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(lib.ragmi_bn_train_stats_fwd(x.data_ptr(), _planes(x), B, C, _vol(x), gamma.data_ptr(), beta.data_ptr(), p(running_mean),
+                                       p(running_var), p(num_batches_tracked), float(momentum), float(eps), ws.data_ptr(),
+                                       out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream()),
+          "bn_train_stats")
+    return out
 
 
 def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool, out: Optional[torch.Tensor] = None,
@@ -368,15 +382,19 @@ def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool
     return out
 
 
-def bn_act_bwd_reduce(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool):
-    """(sum g, sum g*x) per channel with g = dy * [x*scale+shift > 0]."""
-    _need_gpu(dy, x, scale, shift)
+def bn_act_bwd_coeffs(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shift, relu: bool, mean, invstd, training: bool):
+    """Reduction half of the ReLU+BN adjoint: returns the [5, C] tensor (c1, c2, c3, dgamma, dbeta) with
+    dx = g*c1 + x*c2 + c3, g = dy * [x*scale+shift > 0] (ragmi_bn_act_bwd_coeffs)."""
+    _need_gpu(dy, x, scale, shift, mean, invstd)
     B, C = x.shape[:2]
-    s = torch.zeros((2, C), device=x.device, dtype=torch.float32)
-    check(load_library().ragmi_bn_act_bwd_reduce(dy.data_ptr(), _planes(dy), dy_ch0, x.data_ptr(), _planes(x), scale.data_ptr(),
-                                                 shift.data_ptr(), int(relu), B, C, _vol(x), s[0].data_ptr(), s[1].data_ptr(), _stream()),
-          "bn_act_bwd_reduce")
-    return s[0], s[1]
+    lib = load_library()
+    ws = torch.empty((lib.ragmi_bn_workspace_elems(B, C, _vol(x)),), device=x.device, dtype=torch.float32)
+    out = torch.empty((5, C), device=x.device, dtype=torch.float32)
+    check(lib.ragmi_bn_act_bwd_coeffs(dy.data_ptr(), _planes(dy), dy_ch0, x.data_ptr(), _planes(x), scale.data_ptr(), shift.data_ptr(),
+                                      int(relu), mean.data_ptr(), invstd.data_ptr(), int(training), B, C, _vol(x), ws.data_ptr(),
+                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(),
+                                      _stream()), "bn_act_bwd_coeffs")
+    return out
 
 
 def bn_act_bwd_apply(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shift, relu: bool, c1, c2, c3) -> torch.Tensor:
@@ -416,7 +434,7 @@ def trilinear3d_bwd(dy: torch.Tensor, in_size: Sequence[int], align_corners: boo
     dy = dy.contiguous()
     B, C, Do, Ho, Wo = dy.shape
     Di, Hi, Wi = [int(v) for v in in_size]
-    dx = torch.zeros((B, C, Di, Hi, Wi), device=dy.device, dtype=torch.float32)
+    dx = torch.empty((B, C, Di, Hi, Wi), device=dy.device, dtype=torch.float32)
     check(load_library().ragmi_trilinear3d_bwd(dy.data_ptr(), dx.data_ptr(), B, C, Di, Hi, Wi, Do, Ho, Wo, int(bool(align_corners)),
                                                _stream()), "trilinear3d_bwd")
     return dx

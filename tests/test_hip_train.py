@@ -41,13 +41,25 @@ def close(got, ref, tol=2e-4, what=""):
 
 
 # --------------------------------------------------------------------------- kernels
-@pytest.mark.parametrize("shape", [(2, 5, 3, 7, 9), (1, 12, 8, 16, 32), (3, 4, 1, 5, 1027)])
-def test_bn_stats_and_affine(ra, shape):
+@pytest.mark.parametrize("shape", [(2, 5, 3, 7, 9), (1, 12, 8, 16, 32), (3, 4, 1, 5, 1027), (4, 12, 16, 32, 64)])
+def test_bn_train_stats_and_affine(ra, shape):
+    C = shape[1]
     x = torch.randn(shape, generator=gen(1)) * 2 + 0.5
-    s, q = ra.ops.bn_stats(gpu(x))
-    close(s, x.sum(dim=(0, 2, 3, 4)), 1e-5 * x[0, 0].numel() ** 0.5)
-    close(q, (x * x).sum(dim=(0, 2, 3, 4)), 1e-5 * x[0, 0].numel() ** 0.5)
-    sc, sh = torch.rand(shape[1], generator=gen(2)) + 0.5, torch.randn(shape[1], generator=gen(3))
+    gm, bt = torch.rand(C, generator=gen(2)) + 0.5, torch.randn(C, generator=gen(3))
+    rm, rv = torch.randn(C, generator=gen(4)), torch.rand(C, generator=gen(5)) + 0.5
+    rm_g, rv_g, nbt = gpu(rm), gpu(rv), torch.zeros((), dtype=torch.int64, device=DEV)
+    st = ra.ops.bn_train_stats(gpu(x), gpu(gm), gpu(bt), rm_g, rv_g, nbt, 0.1, 1e-5)
+    yr = F.batch_norm(x, rm, rv, gm, bt, training=True, momentum=0.1, eps=1e-5)      # also updates rm / rv
+    mean = x.mean(dim=(0, 2, 3, 4))
+    var = x.var(dim=(0, 2, 3, 4), unbiased=False)
+    close(st[0], mean, 1e-5, "mean")
+    close(st[1], torch.rsqrt(var + 1e-5), 1e-5, "invstd")
+    close(rm_g, rm, 1e-5, "running_mean")
+    close(rv_g, rv, 1e-5, "running_var")
+    assert int(nbt) == 1
+    y = ra.ops.bn_act(gpu(x), st[2].contiguous(), st[3].contiguous(), False)
+    close(y, yr, 1e-5, "y")
+    sc, sh = torch.rand(C, generator=gen(2)) + 0.5, torch.randn(C, generator=gen(3))
     y = ra.ops.bn_act(gpu(x), gpu(sc), gpu(sh), True)
     close(y, F.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)), 1e-6)
 
