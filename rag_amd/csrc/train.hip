@@ -299,25 +299,49 @@ __global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
       }
 }
 
-// dw[co][ci] += sum_v g[co][v] * x[ci][v]   (1x1x1 conv); one workgroup per (voxel slab, co), threads over ci x voxels
+// dw[co][ci] += sum_v g[co][v] * x[ci][v]   (1x1x1 conv).  A workgroup owns a 4 (co) x 12 (ci) block of dw and a slab of
+// voxels: each thread keeps the 48 partial sums of its voxels in registers (x and g are each read once per block row /
+// column), the workgroup reduces them (wave shuffles, then LDS across the 4 waves) and flushes 48 float atomics.
+constexpr int K1W_CO = 4, K1W_CI = 12;
 __global__ __launch_bounds__(256) void conv3d_k1_wgrad_kernel(const float* __restrict__ x, int64_t x_bstride, const float* __restrict__ g,
                                                               int64_t g_bstride, int g_ch0, float* __restrict__ dw, int Cin, int Cout,
-                                                              int64_t dhw) {
-  const int co = blockIdx.y, b = blockIdx.z;
-  const float* pg = g + b * g_bstride + (int64_t)(g_ch0 + co) * dhw;
-  __shared__ float red[256];
-  for (int ci = 0; ci < Cin; ++ci) {
-    const float* px = x + b * x_bstride + (int64_t)ci * dhw;
-    float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dhw; i += (int64_t)gridDim.x * 256) acc = fmaf(pg[i], px[i], acc);
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
+                                                              int64_t dhw, int nci_blocks) {
+  const int co0 = (blockIdx.y / nci_blocks) * K1W_CO, ci0 = (blockIdx.y % nci_blocks) * K1W_CI, b = blockIdx.z;
+  const float* pg = g + b * g_bstride + (int64_t)(g_ch0 + co0) * dhw;
+  const float* px = x + b * x_bstride + (int64_t)ci0 * dhw;
+  const int nco = min(K1W_CO, Cout - co0), nci = min(K1W_CI, Cin - ci0);
+  float acc[K1W_CO][K1W_CI];
+#pragma unroll
+  for (int i = 0; i < K1W_CO; ++i)
+#pragma unroll
+    for (int j = 0; j < K1W_CI; ++j) acc[i][j] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < dhw; v += (int64_t)gridDim.x * 256) {
+    float gv[K1W_CO], xv[K1W_CI];
+#pragma unroll
+    for (int i = 0; i < K1W_CO; ++i) gv[i] = i < nco ? pg[i * dhw + v] : 0.f;
+#pragma unroll
+    for (int j = 0; j < K1W_CI; ++j) xv[j] = j < nci ? px[j * dhw + v] : 0.f;
+#pragma unroll
+    for (int i = 0; i < K1W_CO; ++i)
+#pragma unroll
+      for (int j = 0; j < K1W_CI; ++j) acc[i][j] = fmaf(gv[i], xv[j], acc[i][j]);
+  }
+  __shared__ float red[4][K1W_CO * K1W_CI];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < K1W_CO; ++i)
+#pragma unroll
+    for (int j = 0; j < K1W_CI; ++j) {
+      float v = acc[i][j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wave][i * K1W_CI + j] = v;
     }
-    if (threadIdx.x == 0) atomicAdd(dw + (int64_t)co * Cin + ci, red[0]);
-    __syncthreads();
+  __syncthreads();
+  if (threadIdx.x < K1W_CO * K1W_CI) {
+    const int i = threadIdx.x / K1W_CI, j = threadIdx.x % K1W_CI;
+    if (i < nco && j < nci)
+      atomicAdd(dw + (int64_t)(co0 + i) * Cin + ci0 + j, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
   }
 }
 
@@ -404,55 +428,74 @@ struct DispBwdArgs {
   int d, h, w, maxdisp, Ho, Wo;
   float sd, sh, sw;
 };
+// A workgroup owns a 16 x 16 tile of fine pixels.  The coarse cells its pixels touch form a small window (about
+// 16/3 + 2 per axis); the per-plane contributions are summed in an LDS copy of that window (LDS float atomics) and the
+// window is flushed with one global atomic per cell per workgroup — ~40x fewer global atomics than one per tap.
+constexpr int DB_T = 16, DB_WIN = 8;      // fine tile edge; coarse window edge (16/3 -> 6 cells + 1 each side for the taps)
 __global__ __launch_bounds__(256) void disp_softargmin_bwd_kernel(DispBwdArgs a) {
-  const int64_t npix = (int64_t)a.Ho * a.Wo;
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= npix) return;
-  const int b = blockIdx.y;
-  const int ox = (int)(o % a.Wo), oy = (int)(o / a.Wo);
-  const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
-  const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
+  extern __shared__ float win[];           // [d][DB_WIN][DB_WIN]
+  const int b = blockIdx.z;
+  const int ox = blockIdx.x * DB_T + (threadIdx.x & (DB_T - 1)), oy = blockIdx.y * DB_T + (threadIdx.x >> 4);
+  const bool live = ox < a.Wo && oy < a.Ho;
+  // window origin: the first coarse cell touched by the tile's first pixel (uniform over the workgroup)
+  const int wy0 = lin_index(min(blockIdx.y * DB_T, a.Ho - 1), a.h, a.Ho, a.sh, 0).i0;
+  const int wx0 = lin_index(min(blockIdx.x * DB_T, a.Wo - 1), a.w, a.Wo, a.sw, 0).i0;
+  const int nwin = a.d * DB_WIN * DB_WIN;
+  for (int e = threadIdx.x; e < nwin; e += 256) win[e] = 0.f;
+  __syncthreads();
   const int hw = a.h * a.w;
   const float* base = a.cost + (int64_t)b * a.d * hw;
+  if (live) {
+    const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
+    const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
+    const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1, o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
+    const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
+    const int l00 = (ly.i0 - wy0) * DB_WIN + (lx.i0 - wx0), l01 = (ly.i0 - wy0) * DB_WIN + (lx.i1 - wx0);
+    const int l10 = (ly.i1 - wy0) * DB_WIN + (lx.i0 - wx0), l11 = (ly.i1 - wy0) * DB_WIN + (lx.i1 - wx0);
+    auto plane = [&](int z) -> float {
+      const float* p = base + (int64_t)z * hw;
+      return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
+    };
+    // pass 1: softmax statistics (max, sum, expectation), exactly as the forward
+    float m = -INFINITY, s = 0.f, ws = 0.f;
+    for (int dd = 0; dd < a.maxdisp; ++dd) {
+      const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
+      const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
+      const float mn = fmaxf(m, t);
+      const float r = expf(m - mn), e = expf(t - mn);
+      s = s * r + e;
+      ws = ws * r + e * (float)dd;
+      m = mn;
+    }
+    const float outv = ws / s, gout = a.dout[((int64_t)b * a.Ho + oy) * a.Wo + ox];
+    // pass 2: walk the fine samples again; a0 / a1 collect the gradient of coarse planes z / z+1
+    auto flush = [&](int z, float gv) {
+      if (gv == 0.f) return;
+      float* p = win + z * (DB_WIN * DB_WIN);
+      atomicAdd(p + l00, gv * w00); atomicAdd(p + l01, gv * w01); atomicAdd(p + l10, gv * w10); atomicAdd(p + l11, gv * w11);
+    };
+    int z = 0;
+    float a0 = 0.f, a1 = 0.f;
+    for (int dd = 0; dd < a.maxdisp; ++dd) {
+      const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
+      const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
+      const float pd = expf(t - m) / s;
+      const float gv = -gout * pd * ((float)dd - outv);   // d out / d v_fine, v = +cost (softMIN)
+      while (lz.i0 > z) { flush(z, a0); a0 = a1; a1 = 0.f; ++z; }
+      a0 = fmaf(gv, lz.w0, a0);
+      if (lz.i1 != lz.i0) a1 = fmaf(gv, lz.w1, a1); else a0 = fmaf(gv, lz.w1, a0);
+    }
+    flush(z, a0);
+    if (z + 1 < a.d) flush(z + 1, a1);
+  }
+  __syncthreads();
   float* gbase = a.dcost + (int64_t)b * a.d * hw;
-  const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1, o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
-  const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
-  auto plane = [&](int z) -> float {
-    const float* p = base + (int64_t)z * hw;
-    return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
-  };
-  // pass 1: softmax statistics (max, sum, expectation), exactly as the forward
-  float m = -INFINITY, s = 0.f, ws = 0.f;
-  for (int dd = 0; dd < a.maxdisp; ++dd) {
-    const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
-    const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
-    const float mn = fmaxf(m, t);
-    const float r = expf(m - mn), e = expf(t - mn);
-    s = s * r + e;
-    ws = ws * r + e * (float)dd;
-    m = mn;
+  for (int e = threadIdx.x; e < nwin; e += 256) {
+    const float v = win[e];
+    if (v == 0.f) continue;
+    const int cx = wx0 + e % DB_WIN, cy = wy0 + (e / DB_WIN) % DB_WIN, z = e / (DB_WIN * DB_WIN);
+    if (cx < a.w && cy < a.h) atomicAdd(gbase + (int64_t)z * hw + cy * a.w + cx, v);
   }
-  const float outv = ws / s, gout = a.dout[(int64_t)b * npix + o];
-  // pass 2: walk the fine samples again; a0 / a1 collect the gradient of coarse planes z / z+1 and are flushed with
-  // 4 atomics each when the walk moves on (instead of 8 atomics per fine sample)
-  auto flush = [&](int z, float gv) {
-    if (gv == 0.f) return;
-    float* p = gbase + (int64_t)z * hw;
-    atomicAdd(p + o00, gv * w00); atomicAdd(p + o01, gv * w01); atomicAdd(p + o10, gv * w10); atomicAdd(p + o11, gv * w11);
-  };
-  int z = 0;
-  float a0 = 0.f, a1 = 0.f;
-  for (int dd = 0; dd < a.maxdisp; ++dd) {
-    const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
-    const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
-    const float pd = expf(t - m) / s;
-    const float gv = -gout * pd * ((float)dd - outv);   // d out / d v_fine, v = +cost (softMIN)
-    while (lz.i0 > z) { flush(z, a0); a0 = a1; a1 = 0.f; ++z; }
-    a0 = fmaf(gv, lz.w0, a0);
-    if (lz.i1 != lz.i0) a1 = fmaf(gv, lz.w1, a1); else a0 = fmaf(gv, lz.w1, a0);
-  }
-  flush(z, a0);
-  if (z + 1 < a.d) flush(z + 1, a1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -636,9 +679,12 @@ extern "C" int ragmi_conv3d_k1_wgrad(const void* x, int64_t x_bstride, const voi
   using namespace ragmi;
   RAGMI_REQUIRE(x && g && dw, RAGMI_EINVAL, "conv3d_k1_wgrad: null pointer");
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && DHW > 0 && B <= 65535 && Cout <= 65535, RAGMI_EINVAL, "conv3d_k1_wgrad: bad size");
-  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(DHW, 1024), 128);
-  hipLaunchKernelGGL(conv3d_k1_wgrad_kernel, dim3(gx, Cout, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)x, x_bstride,
-                     (const float*)g, g_bstride, g_ch0, (float*)dw, Cin, Cout, DHW);
+  const int nci = (int)ceil_div(Cin, K1W_CI), nco = (int)ceil_div(Cout, K1W_CO);
+  RAGMI_REQUIRE((int64_t)nci * nco <= 65535, RAGMI_EUNSUPPORTED, "conv3d_k1_wgrad: too many channel blocks");
+  // about four workgroups per CU over the launch; each flushes 48 atomics
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(DHW, 256), ceil_div(1024, (int64_t)nci * nco * B)));
+  hipLaunchKernelGGL(conv3d_k1_wgrad_kernel, dim3(gx, nci * nco, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)x,
+                     x_bstride, (const float*)g, g_bstride, g_ch0, (float*)dw, Cin, Cout, DHW, nci);
   return check_launch("conv3d_k1_wgrad");
 }
 
@@ -672,7 +718,11 @@ extern "C" int ragmi_disp_softargmin_bwd(const void* cost, const void* dout, voi
                 "disp_softargmin_bwd: bad size");
   DispBwdArgs a{(const float*)cost, (const float*)dout, (float*)dcost, d, h, w, maxdisp, Ho, Wo,
                 lin_scale(d, maxdisp, 0), lin_scale(h, Ho, 0), lin_scale(w, Wo, 0)};
-  hipLaunchKernelGGL(disp_softargmin_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Ho * Wo, 256), B), dim3(256), 0,
+  // the coarse window of a 16 x 16 fine tile must fit DB_WIN cells per axis: holds for the x3 upsample of Disp (16/3 + 2 taps <= 8)
+  RAGMI_REQUIRE(Ho == 3 * h && Wo == 3 * w, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: built for the x3 upsample of Disp (Ho = 3h, Wo = 3w)");
+  const size_t lds = (size_t)d * DB_WIN * DB_WIN * sizeof(float);
+  RAGMI_REQUIRE(lds <= 64 * 1024, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: d = %d planes exceed the LDS window (max 256)", d);
+  hipLaunchKernelGGL(disp_softargmin_bwd_kernel, dim3((unsigned)ceil_div(Wo, DB_T), (unsigned)ceil_div(Ho, DB_T), B), dim3(256), lds,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("disp_softargmin_bwd");
 }
