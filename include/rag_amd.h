@@ -280,8 +280,11 @@ int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy_ch0, const
                            const void* scale, const void* shift, int relu, const void* c1, const void* c2, const void* c3,
                            void* dx, int64_t dx_bstride, int B, int C, int64_t DHW, void* stream);
 
-/* dw[co][ci][tap] (+=) sum_{b,v} g[b, g_ch0+co, v] * x[b, ci, v + tap]   — weight gradient of the 3x3x3 conv */
-int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw,
+/* dw[co][ci][tap] = sum_{b,v} g[b, g_ch0+co, v] * x[b, ci, v + tap]   — weight gradient of the 3x3x3 conv (MFMA; persistent
+ * workgroups write partial sums to `workspace`, ragmi_conv3d_k3_wgrad_workspace_elems(...) floats, and a second kernel adds them:
+ * deterministic, dw needs no initialisation) */
+int64_t ragmi_conv3d_k3_wgrad_workspace_elems(int B, int Cin, int Cout, int D, int H, int W);
+int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw, void* workspace,
                           int B, int Cin, int Cout, int D, int H, int W, void* stream);
 
 /* dw[co][ci] (+=) sum_{b,v} g[b, g_ch0+co, v] * x[b, ci, v]   — weight gradient of the 1x1x1 conv */

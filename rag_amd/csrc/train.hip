@@ -3,6 +3,8 @@
 // loop and Disp).  Data-gradients of the convolutions reuse the forward kernels with transposed / flipped weights;
 // this file holds what has no forward twin: batch statistics, the BN+ReLU affine pass and its backward, the weight
 // gradients, and the adjoints of resampling, cost volume and soft-argmin.  fp32 only (training runs in fp32).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ragmi {
@@ -225,47 +227,126 @@ static_assert(WG_PS % 32 == 16 && WG_GP % 32 == 16, "LDS plane strides must be 1
 struct WgradArgs {
   const float* x;
   const float* g;
-  float* dw;
+  float* part;           // [gridDim.x][CoutP][CinP][27] partial sums, CoutP / CinP = channel counts padded to the grid
   int64_t x_bstride, g_bstride;
-  int g_ch0, Cin, Cout, D, H, W, tiles_x, tiles_y, tiles_z, ntiles;
+  int g_ch0, Cin, Cout, D, H, W, tiles_x, tiles_y, tiles_z, ntiles, diag;
 };
-template <int CG>
+template <int CG, bool VEC>
 __global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
+  constexpr int XROWS = 4 * (WG_TZ + 2) * (WG_TY + 2);            // 160 halo rows of 34
+  constexpr int GROWS = CG * 4 * WG_TZ * WG_TY;                    // rows of 32 of the g tile
+  constexpr int NXQ = (XROWS * 8 + 191) / 192, NXH = (XROWS * 2 + 191) / 192, NGQ = (GROWS * 8 + 191) / 192;
+  static_assert(NXQ + NXH + NGQ <= 32, "validity mask is one 32-bit word");
   __shared__ float xs[4 * WG_PS];
-  __shared__ float gs[CG * 4 * WG_GP];
+  __shared__ __attribute__((aligned(16))) float gs[CG * 4 * WG_GP];
   const int tid = threadIdx.x, dz = tid >> 6, lane = tid & 63, blk = lane >> 2, n = lane & 3;
   const int ci0 = blockIdx.y * 4, co0 = blockIdx.z * (CG * 4);
-  const int64_t HW = (int64_t)a.H * a.W, DHW = HW * a.D;
+  const int HW = a.H * a.W;
+  const int64_t DHW = (int64_t)HW * a.D;
   f32x4 acc[9][CG];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int c = 0; c < CG; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  // software pipeline: the next tile's x halo / g tile travel HBM -> registers while the MFMAs of this tile run.
+  // The loads are unconditional (addresses clamped into the volume, like the forward kernel's staging) so that they
+  // stay straight-line code ahead of the MFMA loop; what lies outside the volume is zeroed at commit through `valid`.
+  float4 xq[NXQ], gq[NGQ];
+  float xh[NXH];
+  unsigned valid = 0;
+  auto row4 = [&](const float* row, int gx) -> float4 {
+    if constexpr (VEC) return *reinterpret_cast<const float4*>(row + gx);
+    else return make_float4(row[gx], row[min(gx + 1, a.W - 1)], row[min(gx + 2, a.W - 1)], row[min(gx + 3, a.W - 1)]);
+  };
+  auto prefetch = [&](int tile) {
     int t = tile;
     const int x0 = (t % a.tiles_x) * WG_TX; t /= a.tiles_x;
     const int y0 = (t % a.tiles_y) * WG_TY; t /= a.tiles_y;
     const int z0 = (t % a.tiles_z) * WG_TZ;
     const int b = t / a.tiles_z;
-    __syncthreads();                                   // the previous tile's reads are done
     const float* xb = a.x + b * a.x_bstride;
-    for (int e = tid; e < 4 * WG_PS; e += 192) {
-      const int c = e / WG_PS, r = e % WG_PS;
-      const int zz = r / ((WG_TY + 2) * WG_XS), yy = (r / WG_XS) % (WG_TY + 2), xx = r % WG_XS;
-      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx, gc = ci0 + c;
-      const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && gc < a.Cin;
-      xs[e] = ok ? xb[gc * DHW + gz * HW + (int64_t)gy * a.W + gx] : 0.f;
+    const float* gb = a.g + b * a.g_bstride + (int64_t)a.g_ch0 * DHW;
+    valid = 0;
+#pragma unroll
+    for (int p = 0; p < NXQ; ++p) {
+      const int f = p * 192 + tid, row = f >> 3, q = f & 7;
+      const int c = row / ((WG_TZ + 2) * (WG_TY + 2)), zz = (row / (WG_TY + 2)) % (WG_TZ + 2), yy = row % (WG_TY + 2);
+      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 + 4 * q;
+      const bool ok = row < XROWS && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && gx < a.W && ci0 + c < a.Cin;
+      valid |= (ok ? 1u : 0u) << p;
+      const int cc = min(ci0 + c, a.Cin - 1), cz = min(max(gz, 0), a.D - 1), cy = min(max(gy, 0), a.H - 1);
+      xq[p] = row4(xb + cc * DHW + (unsigned)(cz * HW + cy * a.W), VEC ? min(gx, a.W - 4) : min(gx, a.W - 1));
     }
-    const float* gb = a.g + b * a.g_bstride + (int64_t)(a.g_ch0 + co0) * DHW;
-    for (int e = tid; e < CG * 4 * WG_NV; e += 192) {
-      const int c = e / WG_NV, v = e % WG_NV;
-      const int xx = v % WG_TX, yy = (v / WG_TX) % WG_TY, zz = v / (WG_TX * WG_TY);
-      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx;
-      const bool ok = gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout;
-      gs[c * WG_GP + v] = ok ? gb[c * DHW + gz * HW + (int64_t)gy * a.W + gx] : 0.f;
+#pragma unroll
+    for (int p = 0; p < NXH; ++p) {
+      const int f = p * 192 + tid, row = f >> 1, side = f & 1;
+      const int c = row / ((WG_TZ + 2) * (WG_TY + 2)), zz = (row / (WG_TY + 2)) % (WG_TZ + 2), yy = row % (WG_TY + 2);
+      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = side ? x0 + WG_TX : x0 - 1;
+      const bool ok = row < XROWS && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                      ci0 + c < a.Cin;
+      valid |= (ok ? 1u : 0u) << (NXQ + p);
+      const int cc = min(ci0 + c, a.Cin - 1), cz = min(max(gz, 0), a.D - 1), cy = min(max(gy, 0), a.H - 1);
+      xh[p] = xb[cc * DHW + (unsigned)(cz * HW + cy * a.W + min(max(gx, 0), a.W - 1))];
     }
+#pragma unroll
+    for (int p = 0; p < NGQ; ++p) {
+      const int f = p * 192 + tid, row = f >> 3, q = f & 7;
+      const int c = row / (WG_TZ * WG_TY), zz = (row / WG_TY) % WG_TZ, yy = row % WG_TY;
+      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + 4 * q;
+      const bool ok = row < GROWS && gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout;
+      valid |= (ok ? 1u : 0u) << (NXQ + NXH + p);
+      const int cc = min(co0 + c, a.Cout - 1), cz = min(gz, a.D - 1), cy = min(gy, a.H - 1);
+      gq[p] = row4(gb + cc * DHW + (unsigned)(cz * HW + cy * a.W), VEC ? min(gx, a.W - 4) : min(gx, a.W - 1));
+    }
+  };
+  auto commit = [&](int x0) {                         // x0: the tile's first x (scalar path: per-element validity along x)
+    auto masked = [&](float4 v, bool ok, int gx) -> float4 {
+      if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (!VEC) {
+        if (gx + 1 >= a.W) v.y = 0.f;
+        if (gx + 2 >= a.W) v.z = 0.f;
+        if (gx + 3 >= a.W) v.w = 0.f;
+      }
+      return v;
+    };
+#pragma unroll
+    for (int p = 0; p < NXQ; ++p) {
+      const int f = p * 192 + tid, row = f >> 3, q = f & 7;
+      if (row < XROWS) {
+        const int c = row / ((WG_TZ + 2) * (WG_TY + 2)), r = row % ((WG_TZ + 2) * (WG_TY + 2));
+        const float4 v = masked(xq[p], (valid >> p) & 1u, x0 + 4 * q);
+        float* d = xs + c * WG_PS + r * WG_XS + 1 + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NXH; ++p) {
+      const int f = p * 192 + tid, row = f >> 1, side = f & 1;
+      if (row < XROWS) {
+        const int c = row / ((WG_TZ + 2) * (WG_TY + 2)), r = row % ((WG_TZ + 2) * (WG_TY + 2));
+        xs[c * WG_PS + r * WG_XS + (side ? WG_TX + 1 : 0)] = ((valid >> (NXQ + p)) & 1u) ? xh[p] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NGQ; ++p) {
+      const int f = p * 192 + tid, row = f >> 3, q = f & 7;
+      if (row < GROWS) {
+        const int c = row / (WG_TZ * WG_TY), r = row % (WG_TZ * WG_TY);
+        *reinterpret_cast<float4*>(gs + c * WG_GP + r * WG_TX + 4 * q) = masked(gq[p], (valid >> (NXQ + NXH + p)) & 1u, x0 + 4 * q);
+      }
+    }
+  };
+
+  const int diag = a.diag;                             // RAGMI_WGRAD_DIAG (profiling only): 2 no MFMA, 4 no loads
+  int tile = blockIdx.x;
+  if (tile < a.ntiles && !(diag & 4)) prefetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();                                   // the previous tile's LDS reads are done
+    commit((tile % a.tiles_x) * WG_TX);
     __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles && !(diag & 4)) prefetch(tile + gridDim.x);
+    if (diag & 2) continue;
 #pragma unroll 2
     for (int s = 0; s < WG_NV / 16; ++s) {
       const int v = s * 16 + blk;                      // this block's voxel of the step: 16 consecutive x
@@ -282,7 +363,10 @@ __global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
       }
     }
   }
-  // sum the 16 blocks (lanes 4b+n, fixed n), then lanes 0..3 flush: reg m of lane n is dw[co0+4c+m][ci0+n][dz*9+t9]
+  // sum the 16 blocks (lanes 4b+n, fixed n); lanes 0..3 store this workgroup's partial: reg m of lane n is
+  // dw[co0+4c+m][ci0+n][dz*9+t9].  Every workgroup writes its whole slice (zeros included): no initialisation needed.
+  const int CinP = gridDim.y * 4, CoutP = gridDim.z * CG * 4;
+  float* part = a.part + (int64_t)blockIdx.x * CoutP * CinP * 27;
 #pragma unroll
   for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
@@ -294,9 +378,22 @@ __global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
         v += __shfl_xor(v, 8);
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        const int co = co0 + c * 4 + m, ci = ci0 + n;
-        if (blk == 0 && co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * 27 + dz * 9 + t9, v);
+        if (blk == 0) part[((int64_t)(co0 + c * 4 + m) * CinP + ci0 + n) * 27 + dz * 9 + t9] = v;
       }
+}
+
+// dw[co][ci][tap] = sum over the workgroups' partials: one wave per output element, lanes stride over the partials
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nparts,
+                                                                     int Cin, int Cout, int CinP, int CoutP) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= Cout * Cin * 27) return;
+  const int tap = i % 27, ci = (i / 27) % Cin, co = i / (27 * Cin);
+  const int64_t stride = (int64_t)CoutP * CinP * 27, off = ((int64_t)co * CinP + ci) * 27 + tap;
+  float s = 0.f;
+  for (int p = lane; p < nparts; p += 64) s += part[p * stride + off];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) dw[i] = s;
 }
 
 // dw[co][ci] += sum_v g[co][v] * x[ci][v]   (1x1x1 conv).  A workgroup owns a 4 (co) x 12 (ci) block of dw and a slab of
@@ -385,7 +482,8 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(TriBwdArgs a) {
   tap_range(iz, a.Di, a.Do, a.sd, a.align, z0, z1);
   tap_range(iy, a.Hi, a.Ho, a.sh, a.align, y0, y1);
   tap_range(ix, a.Wi, a.Wo, a.sw, a.align, x0, x1);
-  for (int c = 0; c < a.C; ++c) {
+  {
+    const int c = blockIdx.z;
     const float* pc = a.dy + ((int64_t)b * a.C + c) * ovol;
     float acc = 0.f;
     for (int oz = z0; oz <= z1; ++oz) {
@@ -646,31 +744,77 @@ extern "C" int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy
   return check_launch("bn_act_bwd_apply");
 }
 
-extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw, int B,
-                                     int Cin, int Cout, int D, int H, int W, void* stream) {
-  using namespace ragmi;
-  RAGMI_REQUIRE(x && g && dw, RAGMI_EINVAL, "conv3d_k3_wgrad: null pointer");
-  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, RAGMI_EINVAL, "conv3d_k3_wgrad: bad size");
-  const int tx = (int)ceil_div(W, WG_TX), ty = (int)ceil_div(H, WG_TY), tz = (int)ceil_div(D, WG_TZ);
-  const int64_t ntiles = (int64_t)tx * ty * tz * B;
+namespace ragmi {
+struct WgradPlan {
+  int cg, gx, gy, gz, tx, ty, tz;
+  int64_t ntiles;
+};
+// launch geometry shared by the workspace query and the launch
+static int wgrad_plan(int B, int Cin, int Cout, int D, int H, int W, WgradPlan& p) {
+  p.tx = (int)ceil_div(W, WG_TX); p.ty = (int)ceil_div(H, WG_TY); p.tz = (int)ceil_div(D, WG_TZ);
+  p.ntiles = (int64_t)p.tx * p.ty * p.tz * B;
   // output-channel groups per workgroup: the largest of 4,3,2,1 that divides the group count (12 -> 3, 16 -> 4, 24 -> 3 x 2)
   const int ngroups = (int)ceil_div(Cout, 4);
-  int cg = 1;
+  p.cg = 1;
   for (int c = 4; c >= 1; --c)
-    if (ngroups % c == 0) { cg = c; break; }
-  const int gy = (int)ceil_div(Cin, 4), gz = ngroups / cg;
-  RAGMI_REQUIRE(ntiles < (1ll << 31) && gy <= 65535 && gz <= 65535, RAGMI_EUNSUPPORTED, "conv3d_k3_wgrad: grid too large");
-  // persistent workgroups: about two per CU over the whole launch; each flushes its partial sums once
-  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, 512 / ((int64_t)gy * gz)));
-  WgradArgs a{(const float*)x, (const float*)g, (float*)dw, x_bstride, g_bstride, g_ch0, Cin, Cout, D, H, W, tx, ty, tz, (int)ntiles};
-  const dim3 grid(gx, gy, gz), block(192);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (cg) {
-    case 4: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<4>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<3>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<1>, grid, block, 0, st, a); break;
+    if (ngroups % c == 0) { p.cg = c; break; }
+  p.gy = (int)ceil_div(Cin, 4);
+  p.gz = ngroups / p.cg;
+  RAGMI_REQUIRE(p.ntiles < (1ll << 31) && p.gy <= 65535 && p.gz <= 65535, RAGMI_EUNSUPPORTED, "conv3d_k3_wgrad: grid too large");
+  RAGMI_REQUIRE((int64_t)std::max(Cin, Cout) * D * H * W < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k3_wgrad: volume too large for 32-bit offsets");
+  // persistent workgroups: as many as are resident at once (occupancy x CUs)
+  static int resident[5] = {0, 0, 0, 0, 0};
+  if (!resident[p.cg]) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    const void* fn = p.cg == 4 ? (const void*)conv3d_k3_wgrad_kernel<4, true> : p.cg == 3 ? (const void*)conv3d_k3_wgrad_kernel<3, true>
+                   : p.cg == 2 ? (const void*)conv3d_k3_wgrad_kernel<2, true> : (const void*)conv3d_k3_wgrad_kernel<1, true>;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 192, 0) != hipSuccess || per_cu < 1)
+      return fail(RAGMI_ELAUNCH, "conv3d_k3_wgrad: occupancy query failed");
+    resident[p.cg] = per_cu * prop.multiProcessorCount;
   }
+  p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(p.ntiles, resident[p.cg] / ((int64_t)p.gy * p.gz)));
+  return RAGMI_OK;
+}
+}  // namespace ragmi
+
+extern "C" int64_t ragmi_conv3d_k3_wgrad_workspace_elems(int B, int Cin, int Cout, int D, int H, int W) {
+  using namespace ragmi;
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  WgradPlan p;
+  if (wgrad_plan(B, Cin, Cout, D, H, W, p) != RAGMI_OK) return -1;
+  return (int64_t)p.gx * (p.gz * p.cg * 4) * (p.gy * 4) * 27;
+}
+
+extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw,
+                                     void* workspace, int B, int Cin, int Cout, int D, int H, int W, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && g && dw && workspace, RAGMI_EINVAL, "conv3d_k3_wgrad: null pointer");
+  RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, RAGMI_EINVAL, "conv3d_k3_wgrad: bad size");
+  WgradPlan p;
+  const int rc = wgrad_plan(B, Cin, Cout, D, H, W, p);
+  if (rc != RAGMI_OK) return rc;
+  const bool vec = W % 4 == 0 && x_bstride % 4 == 0 && g_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+  static const int diag = getenv("RAGMI_WGRAD_DIAG") ? atoi(getenv("RAGMI_WGRAD_DIAG")) : 0;
+  WgradArgs a{(const float*)x, (const float*)g, (float*)workspace, x_bstride, g_bstride, g_ch0, Cin, Cout, D, H, W, p.tx, p.ty, p.tz,
+              (int)p.ntiles, diag};
+  const dim3 grid(p.gx, p.gy, p.gz), block(192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define RAGMI_WGRAD_LAUNCH(CGV)                                                                   \
+  if (vec) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<CGV, true>), grid, block, 0, st, a);        \
+  else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<CGV, false>), grid, block, 0, st, a)
+  switch (p.cg) {
+    case 4: RAGMI_WGRAD_LAUNCH(4); break;
+    case 3: RAGMI_WGRAD_LAUNCH(3); break;
+    case 2: RAGMI_WGRAD_LAUNCH(2); break;
+    default: RAGMI_WGRAD_LAUNCH(1); break;
+  }
+#undef RAGMI_WGRAD_LAUNCH
+  const int total = Cout * Cin * 27;
+  hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, (const float*)workspace,
+                     (float*)dw, p.gx, Cin, Cout, p.gy * 4, p.gz * p.cg * 4);
   return check_launch("conv3d_k3_wgrad");
 }
 
@@ -696,7 +840,8 @@ extern "C" int ragmi_trilinear3d_bwd(const void* dy, void* dx, int B, int C, int
                 "trilinear3d_bwd: bad size");
   TriBwdArgs a{(const float*)dy, (float*)dx, C, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do, align_corners),
                lin_scale(Hi, Ho, align_corners), lin_scale(Wi, Wo, align_corners), align_corners ? 1 : 0};
-  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Di * Hi * Wi, 256), B), dim3(256), 0,
+  RAGMI_REQUIRE(C <= 65535, RAGMI_EUNSUPPORTED, "trilinear3d_bwd: more than 65535 channels");
+  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Di * Hi * Wi, 256), B, C), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("trilinear3d_bwd");
 }

@@ -412,9 +412,14 @@ def conv3d_k3_wgrad(x: torch.Tensor, g: torch.Tensor, cout: int, g_ch0: int = 0)
     """dW[cout, Cin, 3, 3, 3] of a 3x3x3 / pad 1 conv from its input x and output gradient g."""
     _need_gpu(x, g)
     B, Cin, D, H, W = x.shape
-    dw = torch.zeros((cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
-    check(load_library().ragmi_conv3d_k3_wgrad(x.data_ptr(), _planes(x), g.data_ptr(), _planes(g), g_ch0, dw.data_ptr(), B, Cin, cout,
-                                               D, H, W, _stream()), "conv3d_k3_wgrad")
+    lib = load_library()
+    n = lib.ragmi_conv3d_k3_wgrad_workspace_elems(B, Cin, cout, D, H, W)
+    if n < 0:
+        check(-2, "conv3d_k3_wgrad_workspace_elems")
+    ws = torch.empty((n,), device=x.device, dtype=torch.float32)
+    dw = torch.empty((cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
+    check(lib.ragmi_conv3d_k3_wgrad(x.data_ptr(), _planes(x), g.data_ptr(), _planes(g), g_ch0, dw.data_ptr(), ws.data_ptr(), B, Cin, cout,
+                                    D, H, W, _stream()), "conv3d_k3_wgrad")
     return dw
 
 
