@@ -199,7 +199,7 @@ def train_bench(args, device, dist, rank, n_gpus):
     Matching Net -> Disp -> masked smooth-L1 -> backward -> flat-bucket gradient all-reduce (RCCL) -> clip -> SGD,
     forward and backward on the HIP kernels (rag_amd.autograd).  All units trainable (task 0 of the growth loop)."""
     import rag_amd
-    from rag_amd.train import GradBucket, make_optimizer, train_step
+    from rag_amd.train import GradBucket, GraphedTrainStep, make_optimizer, train_step
     B = args.batch if args.batch > 1 else TRAIN_B
     torch.manual_seed(0)                                   # identical replicas
     net = rag_amd.Network(rag_amd.ALL_CONV_GENOTYPE, device, maxdisp=MAXDISP)
@@ -212,9 +212,13 @@ def train_bench(args, device, dist, rank, n_gpus):
     right = torch.randn((B, 3, TRAIN_H, TRAIN_W), generator=g).to(device)
     gt = (torch.rand((B, TRAIN_H, TRAIN_W), generator=g) * 200).to(device)
     losses = []
+    graphed = GraphedTrainStep(net, opt, bucket, left, right, gt, clip=5.0, dist=dist) if args.graph else None
 
     def step():
-        losses.append(train_step(net, opt, bucket, left, right, gt, clip=5.0, dist=dist))
+        if graphed is not None:
+            losses.append(graphed().clone())
+        else:
+            losses.append(train_step(net, opt, bucket, left, right, gt, clip=5.0, dist=dist))
 
     dt = timed_region(step, args.steps, args.warmup, dist, torch.cuda.synchronize, device)
     if rank != 0:
@@ -245,7 +249,8 @@ def train_bench(args, device, dist, rank, n_gpus):
         "config": {"workload": f"BASELINE configs[4]: training step, {B} pairs/GPU at {TRAIN_H}x{TRAIN_W}, D={MAXDISP}, all-conv genotype, "
                                "all units trainable, train-mode BN, SGD(1e-3, 0.9, wd 3e-3), clip 5",
                    "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}", "collective": "one flat fp32 gradient bucket all-reduce/step",
-                   "grad_bucket_bytes": int(bucket.flat.numel() * 4)},
+                   "grad_bucket_bytes": int(bucket.flat.numel() * 4),
+                   "launch": "forward+backward as one hipGraph, exchange/clip/SGD eager" if graphed is not None else "eager"},
         "phases_rank0": phases, "loss_first_last": [round(float(losses[0]), 5), round(float(losses[-1]), 5)],
         "roofline": None, "cpu_baseline": None,
     }
@@ -274,12 +279,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (configs[1]: 1)")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the step as a captured hipGraph")
+    ap.add_argument("--graph", type=int, default=None,
+                    help="1: replay the step as a captured hipGraph (default: 0 for inference, 1 for --train)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="activation storage: f32 (configs[1], default) or bf16 storage / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: time the data-parallel training step instead")
     args = ap.parse_args()
+    if args.graph is None:
+        args.graph = 1 if args.train else 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

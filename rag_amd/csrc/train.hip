@@ -452,7 +452,7 @@ struct TriBwdArgs {
   float* dx;
   int C, Di, Hi, Wi, Do, Ho, Wo;
   float sd, sh, sw;
-  int align;
+  int align, cpt;
 };
 __device__ __forceinline__ float tap_weight(int o, int i, int in_size, int out_size, float scale, int align) {
   const LinIdx l = lin_index(o, in_size, out_size, scale, align);
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(TriBwdArgs a) {
   tap_range(iz, a.Di, a.Do, a.sd, a.align, z0, z1);
   tap_range(iy, a.Hi, a.Ho, a.sh, a.align, y0, y1);
   tap_range(ix, a.Wi, a.Wo, a.sw, a.align, x0, x1);
-  {
-    const int c = blockIdx.z;
+  // channels per thread: the tap ranges / weights depend on the voxel only, so a thread reuses them over `cpt` channels
+  for (int c = blockIdx.z * a.cpt; c < min(a.C, (int)(blockIdx.z + 1) * a.cpt); ++c) {
     const float* pc = a.dy + ((int64_t)b * a.C + c) * ovol;
     float acc = 0.f;
     for (int oz = z0; oz <= z1; ++oz) {
@@ -839,9 +839,12 @@ extern "C" int ragmi_trilinear3d_bwd(const void* dy, void* dx, int B, int C, int
   RAGMI_REQUIRE(B > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && B <= 65535, RAGMI_EINVAL,
                 "trilinear3d_bwd: bad size");
   TriBwdArgs a{(const float*)dy, (float*)dx, C, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do, align_corners),
-               lin_scale(Hi, Ho, align_corners), lin_scale(Wi, Wo, align_corners), align_corners ? 1 : 0};
-  RAGMI_REQUIRE(C <= 65535, RAGMI_EUNSUPPORTED, "trilinear3d_bwd: more than 65535 channels");
-  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Di * Hi * Wi, 256), B, C), dim3(256), 0,
+               lin_scale(Hi, Ho, align_corners), lin_scale(Wi, Wo, align_corners), align_corners ? 1 : 0, 1};
+  // enough threads to fill the chip (>= ~256K), otherwise as many channels per thread as possible
+  const int64_t vox_threads = (int64_t)Di * Hi * Wi * B;
+  a.cpt = (int)std::max<int64_t>(1, std::min<int64_t>(C, vox_threads * C / (256 * 1024)));
+  RAGMI_REQUIRE(ceil_div(C, a.cpt) <= 65535, RAGMI_EUNSUPPORTED, "trilinear3d_bwd: too many channels");
+  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3((unsigned)ceil_div((int64_t)Di * Hi * Wi, 256), B, (unsigned)ceil_div(C, a.cpt)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("trilinear3d_bwd");
 }

@@ -65,18 +65,60 @@ def masked_smooth_l1(disp: torch.Tensor, gt: torch.Tensor, maxdisp: int) -> torc
     return (per * mask).sum() / mask.sum().clamp_min(1.0)
 
 
-def train_step(net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
-               features: bool = False):
-    """One optimisation step as in Appr.train_epoch (rag.py:204-216).  `features=True`: `net` is a MatchingNet and
-    left/right are Feature-Net outputs.  Returns the (detached) loss."""
+def forward_backward(net, bucket: GradBucket, left, right, gt, *, task_arch=None, features: bool = False):
+    """forward -> masked smooth-L1 -> zero the bucket -> backward (rag.py:208-214).  `features=True`: `net` is a
+    MatchingNet and left/right are Feature-Net outputs.  Returns the (detached) loss."""
     disp = net(left, right, task_arch) if features else net(left, right, 0, task_arch if task_arch is not None else net.arch_init)
     loss = masked_smooth_l1(disp, gt, net.maxdisp)
     bucket.zero()
     loss.backward()
+    return loss.detach()
+
+
+def exchange_and_update(optimizer, bucket: GradBucket, *, clip: float = 5.0, dist=None) -> None:
+    """gradient all-reduce (mean over replicas) -> clip_grad_norm_ -> optimizer step (rag.py:215-216)."""
     bucket.all_reduce_mean(dist)
     bucket.clip_(clip)
     optimizer.step()
-    return loss.detach()
+
+
+def train_step(net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
+               features: bool = False):
+    """One optimisation step as in Appr.train_epoch (rag.py:204-216).  Returns the (detached) loss."""
+    loss = forward_backward(net, bucket, left, right, gt, task_arch=task_arch, features=features)
+    exchange_and_update(optimizer, bucket, clip=clip, dist=dist)
+    return loss
+
+
+class GraphedTrainStep:
+    """The same step with forward + loss + backward replayed as ONE captured hipGraph (the ~2500 kernel launches of a
+    step cost more host time than GPU time when issued one by one); the gradient exchange, clipping and the optimizer
+    step stay eager (a handful of launches, and the collective stays outside the graph).  Inputs are copied into static
+    buffers; shapes, the architecture and which parameters train must not change after capture."""
+
+    def __init__(self, net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
+                 features: bool = False, warmup: int = 2):
+        self.net, self.opt, self.bucket, self.clip, self.dist = net, optimizer, bucket, clip, dist
+        self.left, self.right, self.gt = left.clone(), right.clone(), gt.clone()
+        kw = dict(task_arch=task_arch, features=features)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # warm-up on a side stream: lazy state (allocator pools, occupancy
+            for _ in range(max(warmup, 1)):            # queries, momentum buffers) exists before capture
+                forward_backward(net, bucket, self.left, self.right, self.gt, **kw)
+                exchange_and_update(optimizer, bucket, clip=clip, dist=dist)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = forward_backward(net, bucket, self.left, self.right, self.gt, **kw)
+
+    def __call__(self, left=None, right=None, gt=None):
+        for dst, src in ((self.left, left), (self.right, right), (self.gt, gt)):
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        exchange_and_update(self.opt, self.bucket, clip=self.clip, dist=self.dist)
+        return self.loss
 
 
 def make_optimizer(params, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 3e-3):

@@ -352,3 +352,34 @@ def test_sgd_step_changes_only_trained_units(ra):
             assert same == (not k.endswith("conv.weight")), k      # bn=False heads: the unused BatchNorm never moves
         elif k.endswith("conv.weight") or k.endswith("running_mean"):
             assert not same, k
+
+
+def test_graphed_train_step_matches_eager(ra):
+    """forward+backward replayed as one hipGraph (rag_amd.train.GraphedTrainStep) == the eager step, three steps in a row."""
+    from rag_amd.train import GradBucket, GraphedTrainStep, make_optimizer, train_step
+    g = load_golden("g6_train_step")
+    maxdisp = int(g["maxdisp"])
+    rows = g["rows"]
+    left, right, gt = gpu(g["left"]), gpu(g["right"]), gpu(g["gt"])
+    finals = []
+    for graphed in (False, True):
+        net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=maxdisp)
+        net.load_state_dict(split_sd(g), strict=True)
+        net = net.to(DEV).train()
+        net.stem3d0[0].eval()
+        net.modify_param({"stem_3d0": [0]}, requires_grad=False)
+        bucket = GradBucket(net.parameters())
+        opt = make_optimizer(net.parameters(), lr=1e-3)
+        losses = []
+        if graphed:
+            # the capture warm-up runs optimisation steps too: give the eager run the same number of steps
+            step = GraphedTrainStep(net, opt, bucket, left, right, gt, warmup=2)
+            losses = [None, None] + [float(step()) for _ in range(3)]
+        else:
+            losses = [float(train_step(net, opt, bucket, left, right, gt)) for _ in range(5)]
+        finals.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    (l0, s0), (l1, s1) = finals
+    for a, b in zip(l0[2:], l1[2:]):
+        assert abs(a - b) < 1e-3 * max(1.0, abs(a)), (l0, l1)
+    for k in s0:
+        close(s1[k].float(), s0[k].float(), 1e-3, k)
