@@ -6,6 +6,7 @@ Here every node of that graph is a `torch.autograd.Function` whose forward AND b
 hand-written kernels of librag_amd.so; autograd only orders the calls.  No ATen convolution,
 batch-norm, interpolate or softmax runs: if the library is missing these raise, there is no fallback.
 
+    ConvBRGroupFn sibling ConvBRs reading one tensor, as one stacked convolution (forward, data and weight gradient)
     ConvBRFn      conv (3x3x3 MFMA kernel / 1x1x1) -> BatchNorm (batch or running statistics) -> ReLU
                   backward: ReLU+BN adjoint (reduce + apply), data gradient = the forward conv kernel on the
                   output gradient with the weight transposed and its taps flipped, weight gradient kernels
@@ -112,9 +113,12 @@ def _bn_forward(raw, n, gamma, beta, mod):
     return scale, shift, mean, invstd, False
 
 
-def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, need_b):
-    """ReLU + BatchNorm adjoint: (gradient w.r.t. the raw conv output, dgamma, dbeta)."""
+def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, need_b, out=None):
+    """ReLU + BatchNorm adjoint: (gradient w.r.t. the raw conv output, dgamma, dbeta); `out`: destination channel slice."""
     if not (mod.use_bn or mod.relu):
+        if out is not None:
+            out.copy_(dy)
+            return out, None, None
         return dy, None, None
     dgamma = dbeta = None
     if mod.use_bn and (training or need_g or need_b):
@@ -124,7 +128,61 @@ def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, 
     else:
         c1 = scale
         c2 = c3 = torch.zeros_like(scale)
-    return ops.bn_act_bwd_apply(dy, 0, raw, scale, shift, mod.relu, c1, c2, c3), dgamma, dbeta
+    return ops.bn_act_bwd_apply(dy, 0, raw, scale, shift, mod.relu, c1, c2, c3, out=out), dgamma, dbeta
+
+
+class ConvBRGroupFn(torch.autograd.Function):
+    """Sibling 3x3(x3) ConvBRs that read the SAME tensor (a cell state feeding several new states, rag_model.py:163-172) as
+    one convolution with the weights stacked along Cout: one forward conv, one data-gradient conv (which also sums the
+    siblings' contributions to dx) and one weight-gradient launch instead of one of each per sibling; BatchNorm stays per
+    unit (each keeps its own mode, statistics and parameters).  apply(x, mods, w0, gamma0, beta0, w1, ...) -> (y0, y1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, mods, *params):
+        x = _dense(x)
+        n, C = len(mods), mods[0].conv.out_channels
+        B = x.shape[0]
+        wcat = torch.cat([params[3 * i].detach() for i in range(n)])
+        raw = torch.empty((B, n * C) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+        ops.conv3d_k3(x, ops.conv3d_k3_pack(wcat), n * C, None, None, False, raw)
+        nvox = B * _vol(x)
+        outs, saved = [], [x, wcat, raw]
+        ctx.training = []
+        for i, m in enumerate(mods):
+            r = raw[:, i * C:(i + 1) * C]
+            scale, shift, mean, invstd, training = _bn_forward(r, nvox, params[3 * i + 1], params[3 * i + 2], m)
+            outs.append(ops.bn_act(r, scale, shift, m.relu))
+            saved += [scale, shift, mean, invstd]
+            ctx.training.append(training)
+        ctx.mods, ctx.n = mods, nvox
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, wcat, raw = ctx.saved_tensors[:3]
+        mods, n = ctx.mods, len(ctx.mods)
+        C = mods[0].conv.out_channels
+        draw = torch.empty_like(raw)
+        grads = [None] * (3 * n)
+        for i, m in enumerate(mods):
+            scale, shift, mean, invstd = ctx.saved_tensors[3 + 4 * i: 7 + 4 * i]
+            need_g, need_b = ctx.needs_input_grad[2 + 3 * i + 1], ctx.needs_input_grad[2 + 3 * i + 2]
+            r = raw[:, i * C:(i + 1) * C]
+            d, grads[3 * i + 1], grads[3 * i + 2] = _bn_backward(_dense(dys[i]), r, scale, shift, mean, invstd, m, ctx.n, ctx.training[i],
+                                                                 need_g, need_b, out=draw[:, i * C:(i + 1) * C])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ops.conv3d_k3(draw, ops.conv3d_k3_pack(wcat, transpose=True), x.shape[1], None, None, False, dx)
+        if any(ctx.needs_input_grad[2 + 3 * i] for i in range(n)):
+            dw = ops.conv3d_k3_wgrad(x, draw, n * C)
+            planar = mods[0].NDIM == 2
+            for i in range(n):
+                if ctx.needs_input_grad[2 + 3 * i]:
+                    part = dw[i * C:(i + 1) * C]
+                    grads[3 * i] = (part[:, :, 1] if planar else part).reshape(mods[i].conv.weight.shape)
+        return (dx, None, *grads)
 
 
 class StridedStemFn(torch.autograd.Function):

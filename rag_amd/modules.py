@@ -347,14 +347,29 @@ class _Cell(nn.Module):
             s0 = self.pre_preprocess(s0)
         s1 = self.preprocess(s1)
         states = [s0, s1]
-        for _k, lst in self._contributions().items():
+        contribs = self._contributions()
+        n_states = 2 + self._steps
+        pending: Dict[int, list] = {k: [] for k in contribs}
+        for k, lst in contribs.items():
             if not lst:
                 raise ValueError("Cell_3d: a step with no selected branch (the reference fails in torch.cat here too)")
-            acc = None
-            for (j, op) in lst:
-                h = op(states[j])
-                acc = h if acc is None else ag.AddFn.apply(acc, h)
-            states.append(acc)
+        # Sources in ascending order: state j is complete once every source < j has been applied (targets are always
+        # later states).  The conv branches leaving one state run as ONE stacked convolution (ag.ConvBRGroupFn).
+        for j in range(n_states):
+            if j >= 2:
+                acc = pending[j][0]
+                for h in pending[j][1:]:
+                    acc = ag.AddFn.apply(acc, h)
+                states.append(acc)
+            out_ops = [(k, op) for k, lst in contribs.items() for (src, op) in lst if src == j]
+            convs = [(k, op) for (k, op) in out_ops if isinstance(op, _ConvBR)]
+            grouped = (len(convs) > 1 and all(op._geometry() == 3 and op.use_bn and op.relu for _k, op in convs)
+                       and states[j].dtype == torch.float32)
+            if grouped:
+                params = [p for _k, op in convs for p in (op.conv.weight, op.bn.weight, op.bn.bias)]
+                outs = dict(zip([k for k, _op in convs], ag.ConvBRGroupFn.apply(states[j], tuple(op for _k, op in convs), *params)))
+            for k, op in out_ops:
+                pending[k].append(outs[k] if (grouped and isinstance(op, _ConvBR)) else op(states[j]))
         return torch.cat(states[-self.block_multiplier:], dim=1)
 
     def out_size(self, prev_size: Sequence[int]) -> Tuple[int, int, int]:

@@ -397,11 +397,12 @@ def bn_act_bwd_coeffs(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shi
     return out
 
 
-def bn_act_bwd_apply(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shift, relu: bool, c1, c2, c3) -> torch.Tensor:
-    """dx = g * c1 + x * c2 + c3 (per channel)."""
-    _need_gpu(dy, x, scale, shift, c1, c2, c3)
+def bn_act_bwd_apply(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shift, relu: bool, c1, c2, c3,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx = g * c1 + x * c2 + c3 (per channel); `out` may be a channel slice of a wider buffer."""
+    _need_gpu(dy, x, scale, shift, c1, c2, c3, out)
     B, C = x.shape[:2]
-    dx = torch.empty_like(x)
+    dx = out if out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
     check(load_library().ragmi_bn_act_bwd_apply(dy.data_ptr(), _planes(dy), dy_ch0, x.data_ptr(), _planes(x), scale.data_ptr(),
                                                 shift.data_ptr(), int(relu), c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), dx.data_ptr(),
                                                 _planes(dx), B, C, _vol(x), _stream()), "bn_act_bwd_apply")
