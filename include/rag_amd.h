@@ -312,6 +312,18 @@ int ragmi_conv2d_k3_strided_wgrad(const void* x, const void* g, void* dw, int B,
 /* adjoint of ragmi_disparity_regression_fwd: dprob[B,D,H,W] = dout[B,H,W] * d */
 int ragmi_disparity_regression_bwd(const void* dout, void* dprob, int B, int D, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Loss + evaluation metrics in one pass.  mask = 0 < gt < maxdisp (approaches/rag.py:210, 418).
+ * out[0] = masked smooth-L1 loss over the batch (rag.py:211, 419); out[1..5] = EPE, D1, Thres1, Thres2, Thres3 of
+ * utilstool/metrics.py:45-65, each the mean over the images that pass metrics.py:30's 10 % mask rule; out[6] = masked pixel
+ * count; out[7] = images kept.  est, gt: [B,H,W] fp32; acc: B*8 floats of scratch; out: 8 floats. */
+int ragmi_stereo_metrics_fwd(const void* disp_est, const void* disp_gt, int B, int H, int W, float maxdisp, void* acc, void* out,
+                             void* stream);
+
+/* gradient of out[0] w.r.t. disp_est: ddisp = gout[0] * [mask] * clamp(est - gt, -1, 1) / out[6] */
+int ragmi_masked_smooth_l1_bwd(const void* disp_est, const void* disp_gt, const void* out, const void* gout, void* ddisp,
+                               int B, int H, int W, float maxdisp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

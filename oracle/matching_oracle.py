@@ -342,3 +342,28 @@ def conv3d_explicit(x: np.ndarray, w: np.ndarray, padding: int) -> np.ndarray:
                 patch = xp[:, :, dz:dz + Do, dy:dy + Ho, dx:dx + Wo]
                 y += np.einsum("bcdhw,oc->bodhw", patch, w[:, :, dz, dy, dx])
     return y.astype(np.float32)
+
+
+# ---------------------------------------------------------------------- N3: loss + metrics of the eval loop
+def stereo_metrics(disp_est: torch.Tensor, disp_gt: torch.Tensor, maxdisp: float = 192.0) -> Dict[str, float]:
+    """Appr.eval's per-batch scalars, approaches/rag.py:418-430 with utilstool/metrics.py:21-65 restated:
+    mask = 0 < gt < maxdisp; loss = smooth-L1 over all masked pixels of the batch; EPE / D1 / Thres-tau are computed
+    per image and averaged over the images with mask.mean() / (gt > 0).mean() >= 0.1 (0 when none is kept).
+    PARITY UNPINNED for this function: utilstool.metrics imports torchvision (utilstool/experiment.py:7), which is not
+    installed here, so no fixture could be generated from the reference itself; it is a line-by-line restatement."""
+    mask = (disp_gt < maxdisp) & (disp_gt > 0)
+    out = {"loss": float(F.smooth_l1_loss(disp_est[mask], disp_gt[mask], reduction="mean"))}
+
+    def per_image(fn):
+        res = []
+        for b in range(disp_gt.shape[0]):
+            if mask[b].float().mean() / (disp_gt[b] > 0).float().mean() < 0.1:
+                continue
+            res.append(fn(disp_est[b][mask[b]], disp_gt[b][mask[b]]))
+        return float(torch.stack(res).mean()) if res else 0.0
+
+    out["EPE"] = per_image(lambda e, g: F.l1_loss(e, g, reduction="mean"))
+    out["D1"] = per_image(lambda e, g: (((g - e).abs() > 3) & ((g - e).abs() / g.abs() > 0.05)).float().mean())
+    for k, thr in (("Thres1", 1.0), ("Thres2", 2.0), ("Thres3", 3.0)):
+        out[k] = per_image(lambda e, g, thr=thr: ((g - e).abs() > thr).float().mean())
+    return out

@@ -10,6 +10,7 @@ ops raise if the library is missing.
 from ._lib import lib_path, load_library  # noqa: F401
 from . import ops  # noqa: F401
 from . import autograd  # noqa: F401
+from . import metrics  # noqa: F401
 from . import train  # noqa: F401
 from .modules import (  # noqa: F401
     ALL_CONV_GENOTYPE, ALL_SKIP_GENOTYPE, Cell_3d, ConvBR_3d, Disp, DisparityRegression, Genotype,

@@ -58,11 +58,14 @@ class GradBucket:
 
 
 def masked_smooth_l1(disp: torch.Tensor, gt: torch.Tensor, maxdisp: int) -> torch.Tensor:
-    """F.smooth_l1_loss(disp[mask], gt[mask]) with mask = 0 < gt < maxdisp (rag.py:210-211), written without the
-    boolean gather so the step does not synchronise the stream."""
-    mask = ((gt < maxdisp) & (gt > 0)).to(disp.dtype)
+    """F.smooth_l1_loss(disp[mask], gt[mask]) with mask = 0 < gt < maxdisp (rag.py:210-211) without the boolean gather
+    (no stream synchronisation): the fused HIP loss of rag_amd.metrics on the GPU."""
+    if disp.is_cuda:
+        from .metrics import masked_smooth_l1 as fused
+        return fused(disp, gt, maxdisp)
+    mask = ((gt < maxdisp) & (gt > 0)).to(disp.dtype)          # host-side twin (CPU tests of the step logic)
     per = F.smooth_l1_loss(disp, gt, reduction="none")
-    return (per * mask).sum() / mask.sum().clamp_min(1.0)
+    return (per * mask).sum() / mask.sum()
 
 
 def forward_backward(net, bucket: GradBucket, left, right, gt, *, task_arch=None, features: bool = False):

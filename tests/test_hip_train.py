@@ -385,3 +385,34 @@ def test_graphed_train_step_matches_eager(ra):
         assert abs(a - b) < 2e-3 * max(1.0, abs(a)), (l0, l1)
     for k in s0:
         close(s1[k].float(), s0[k].float(), 5e-3, k)
+
+
+# --------------------------------------------------------------------------- fused loss + metrics
+@pytest.mark.parametrize("B,H,W,maxdisp,case", [(2, 36, 48, 24, "plain"), (4, 192, 384, 192, "plain"), (3, 33, 47, 48, "skip"),
+                                                (1, 24, 24, 192, "sparse")])
+def test_stereo_metrics_vs_oracle(ra, B, H, W, maxdisp, case):
+    est = torch.rand((B, H, W), generator=gen(71)) * maxdisp
+    gt = torch.rand((B, H, W), generator=gen(72)) * maxdisp * 1.1 - 2.0          # some <= 0, some >= maxdisp
+    if case == "skip":                       # image 1: almost every positive gt is >= maxdisp -> dropped by the 10 % rule
+        gt[1] = maxdisp + 1.0
+        gt[1, :2, :5] = 3.0
+    if case == "sparse":                     # KITTI-like sparse ground truth
+        gt = torch.where(torch.rand((B, H, W), generator=gen(73)) < 0.7, torch.zeros(()), gt)
+    est = est + (gt - est) * 0.97            # errors around the 1-3 px thresholds
+    ref = O.stereo_metrics(est, gt, maxdisp)
+    got = ra.metrics.stereo_metrics(gpu(est), gpu(gt), maxdisp).floats()
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, got[k], v)
+
+
+def test_masked_smooth_l1_forward_backward(ra):
+    est = (torch.rand((2, 36, 48), generator=gen(74)) * 30).requires_grad_(True)
+    gt = torch.rand((2, 36, 48), generator=gen(75)) * 30
+    mask = (gt < 24) & (gt > 0)
+    ref = F.smooth_l1_loss(est[mask], gt[mask], reduction="mean")
+    (ref * 1.7).backward()
+    eg = gpu(est.detach()).requires_grad_(True)
+    loss = ra.metrics.masked_smooth_l1(eg, gpu(gt), 24)
+    (loss * 1.7).backward()
+    close(loss, ref, 1e-6)
+    close(eg.grad, est.grad, 1e-6)

@@ -153,3 +153,20 @@ def test_g6_train_step():
         assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
         checked += 1
     assert checked > 40
+
+
+def test_stereo_metrics_known_answer():
+    """Hand-computed case for the metrics restatement (utilstool/metrics.py:21-65 is not importable here: torchvision)."""
+    gt = torch.tensor([[[10.0, 20.0, 0.0, 200.0]], [[300.0, 250.0, 5.0, 0.0]]])          # B=2, H=1, W=4, maxdisp 192
+    est = torch.tensor([[[10.5, 24.0, 7.0, 100.0]], [[1.0, 2.0, 5.0, 9.0]]])
+    # image 0: mask = [1,1,0,0], gt>0 = [1,1,0,1] -> ratio 0.75 (kept); errors 0.5, 4.0 (4 > 3 px and 20 % > 5 %)
+    # image 1: mask = [0,0,1,0], gt>0 = [1,1,1,0] -> ratio 1/3 (kept); error 0
+    m = O.stereo_metrics(est, gt, 192)
+    assert abs(m["loss"] - (0.5 * 0.25 + 3.5 + 0.0) / 3) < 1e-6
+    assert abs(m["EPE"] - ((0.5 + 4.0) / 2 + 0.0) / 2) < 1e-6
+    assert abs(m["D1"] - (0.5 + 0.0) / 2) < 1e-6
+    assert abs(m["Thres1"] - 0.25) < 1e-6 and abs(m["Thres3"] - 0.25) < 1e-6
+    # 10 % rule: image with 1 of 20 positive gt pixels inside the mask is skipped
+    gt2 = torch.full((1, 1, 20), 500.0)
+    gt2[0, 0, 0] = 4.0
+    assert O.stereo_metrics(torch.zeros((1, 1, 20)), gt2, 192)["EPE"] == 0.0
