@@ -507,3 +507,46 @@ def test_bf16_matchingnet_epe_report(ra):
     e32, e16, e16_32 = O.epe(d32, ref), O.epe(d16, ref), O.epe(d16, d32)
     print(f"EPE fp32 vs oracle {e32:.3e}; bf16 vs oracle {e16:.3e}; bf16 vs fp32 build {e16_32:.3e} px (maxdisp 96)")
     assert d16.dtype == torch.float32 and torch.isfinite(d16).all() and e32 <= EPE_GATE and e16 < 5.0
+
+
+# --------------------------------------------------------------------------- grown model: checkpoint round trip + serving (N4)
+def test_multitask_serving_after_checkpoint_round_trip(ra, tmp_path):
+    from rag_amd import checkpoint as ck
+    mixed = np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]])
+    torch.manual_seed(5)
+    net = ra.Network(ra.ALL_CONV_GENOTYPE, DEV, maxdisp=48).to(DEV)
+    archis = [net.arch_init]
+    net.expand(1, ra.Genotype(mixed, None, mixed, None), DEV)
+    for k in (1, 5, 9, 12, 15):
+        net.p[k][-1] = 0.9
+    archis.append(net.select(1))
+    net = net.eval()
+    path = tmp_path / "checkpoint_task1.ckpt"
+    ck.save_checkpoint(path, net, archis, task=1)
+    net2, archis2 = ck.load_checkpoint(str(path), device=DEV)
+    serve = ck.MultiTaskStereo(net2, archis2)
+    left, right = gpu(torch.randn((1, 3, 48, 96), generator=gen(81))), gpu(torch.randn((1, 3, 48, 96), generator=gen(82)))
+    with torch.no_grad():
+        outs = [net(left, right, t, archis[t]) for t in (0, 1)]
+        served = [serve(left, right, t) for t in (0, 1)]
+    assert torch.equal(outs[0], served[0]) and torch.equal(outs[1], served[1])
+    assert not torch.equal(outs[0], outs[1])           # the two tasks really run different units
+
+
+# --------------------------------------------------------------------------- BASELINE configs[3] shape (480x960, D=192)
+def test_matchingnet_config4_shape_epe_and_shard_equivalence(ra):
+    """DrivingStereo eval pad 480x960, D=192 (features 160x320, cost depth 64): EPE vs the CPU oracle
+    on one pair, and a pair computed alone equals the same pair inside a batch (the multi-GPU split is a batch split)."""
+    rows = O.ALL_CONV
+    sd = O.random_matching_state_dict(rows, seed=9)
+    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=192)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    lf, rf = torch.randn((2, 12, 160, 320), generator=gen(91)), torch.randn((2, 12, 160, 320), generator=gen(92))
+    with torch.no_grad():
+        both = net(gpu(lf), gpu(rf))
+        alone = net(gpu(lf[1:]), gpu(rf[1:]))
+    assert torch.equal(both[1:], alone)
+    torch.set_num_threads(16)
+    ref = O.matching_net_forward(lf[:1], rf[:1], sd, rows, 192)
+    assert O.epe(both[:1].cpu(), ref) <= EPE_GATE

@@ -223,3 +223,57 @@ def test_oracle_rejects_shapes_the_reference_crashes_on():
     sd = O.random_matching_state_dict(rows)
     with pytest.raises(ValueError):     # h = 10 is not a multiple of 4 -> reference: UnboundLocalError at rag_model.py:360-366
         O.matching(torch.zeros(1, 24, 4, 10, 8), sd, rows)
+
+
+# ------------------------------------------------------------------ checkpoint round trip
+def _grown_network():
+    import rag_amd
+    from rag_amd.modules import Genotype
+    mixed = np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]])
+    torch.manual_seed(5)
+    net = rag_amd.Network(rag_amd.ALL_CONV_GENOTYPE, "cpu", maxdisp=48)
+    archis = [net.arch_init]
+    net.expand(1, Genotype(mixed, None, mixed, None), "cpu")
+    for k in (1, 5, 9, 12):                      # the candidate wins in four layers
+        net.p[k][-1] = 0.9
+    archis.append(net.select(1))
+    return net, archis
+
+
+def test_checkpoint_round_trip_rebuilds_grown_model(tmp_path):
+    from rag_amd import checkpoint as ck
+    net, archis = _grown_network()
+    path = tmp_path / "checkpoint_task1.ckpt"
+    ck.save_checkpoint(path, net, archis, task=1)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert {"task", "model", "optimizer"} <= set(raw)                      # the reference's keys (run.py:194) are intact
+    net2, archis2 = ck.load_checkpoint(str(path), device="cpu")
+    sd1, sd2 = net.state_dict(), net2.state_dict()
+    assert list(sd1) == list(sd2)
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+    assert archis2 == [{k: [int(v) for v in vs] for k, vs in a.items()} for a in archis]
+    assert net2.length == net.length and not net2.training
+    # grown cell units were rebuilt from THEIR genotype (identity ops at the same positions)
+    for name in ("cell_3d1", "cell_2d2"):
+        for u1, u2 in zip(net._units(name), net2._units(name)):
+            assert [type(o).__name__ for o in u1._ops] == [type(o).__name__ for o in u2._ops]
+    serve = ck.MultiTaskStereo(net2, archis2)
+    assert serve.n_tasks == 2
+    with pytest.raises(IndexError):
+        serve(None, None, 2)
+
+
+def test_reference_style_checkpoint_needs_genotypes_and_checks_them():
+    import rag_amd
+    from rag_amd import checkpoint as ck
+    net, archis = _grown_network()
+    ref_style = {"task": 1, "model": net.state_dict(), "optimizer": None}       # what run.py:194 writes
+    with pytest.raises(ValueError, match="no genotypes"):
+        ck.load_checkpoint(ref_style, device="cpu")
+    with pytest.raises(ValueError, match="wrong genotype"):                      # all-conv for every unit: the mixed units disagree
+        ck.load_checkpoint(ref_style, device="cpu", genotypes=rag_amd.ALL_CONV_GENOTYPE)
+    net2, archis2 = ck.load_checkpoint(ref_style, device="cpu", genotypes=ck.unit_genotypes(net), archis=archis)
+    assert list(net2.state_dict()) == list(net.state_dict()) and len(archis2) == 2
+    bad = [dict(archis[0], stem_3d0=[7])]
+    with pytest.raises(ValueError, match="archis"):
+        ck.load_checkpoint(ref_style, device="cpu", genotypes=ck.unit_genotypes(net), archis=bad)
