@@ -20,6 +20,8 @@ from .modules import (  # noqa: F401
 from .modules import Cell_2d, ConvBR_2d, OPS_2d, PRIMITIVES  # noqa: E402,F401
 from .network import Network  # noqa: E402,F401
 from . import checkpoint  # noqa: E402,F401
+from . import supernet  # noqa: E402,F401
+from .supernet import AutoFeature, AutoMatching, BasicNetwork  # noqa: E402,F401
 
 __all__ = [
     "Network", "Cell_2d", "ConvBR_2d",

@@ -269,6 +269,43 @@ def main():
     blob["keys_round2"] = sorted(net.state_dict().keys())
     save("g8_growth_api", blob=np.frombuffer(json.dumps(blob).encode(), dtype=np.uint8))
 
+    # ---- G9: the MdeNAS supernet (automl/mdenas_basicmodel.py BasicNetwork = AutoFeature + AutoMatching with one sampled
+    # op per edge, automl/build_model_{2d,3d}.py): eval forward and one training step (mdenas_search.py:164-173)
+    import automl.mdenas_basicmodel as mb
+    torch.manual_seed(91)
+    sup = mb.BasicNetwork(device="cpu")
+    randomize_bn(sup, torch.Generator().manual_seed(1091))
+    sup.maxdisp = 48
+    sup.disp = mb.Disp(48)
+    g = torch.Generator().manual_seed(92)
+    left = torch.randn((1, 3, 48, 96), generator=g)
+    right = torch.randn((1, 3, 48, 96), generator=g)
+    gt = torch.rand((1, 48, 96), generator=g) * 60
+    fea_ops = np.array([1, 0, 1, 1, 0, 1, 0, 1, 1])
+    mat_ops = np.array([0, 1, 1, 0, 1, 1, 1, 0, 1])
+    sd0 = sd_np(sup)
+    sup.eval()
+    with torch.no_grad():
+        disp_eval = sup(left, right, fea_ops, mat_ops)
+        disp_eval_conv = sup(left, right, np.ones(9, dtype=np.int64), np.ones(9, dtype=np.int64))
+    sup.train()
+    out = sup(left, right, fea_ops, mat_ops)
+    mask = (gt < 48) & (gt > 0)
+    loss = torch.nn.functional.smooth_l1_loss(out[mask], gt[mask], reduction="mean")
+    loss.backward()
+    arrays = {"left": left.numpy(), "right": right.numpy(), "gt": gt.numpy(), "fea_ops": fea_ops, "mat_ops": mat_ops,
+              "disp_eval": disp_eval.numpy(), "disp_eval_all_conv": disp_eval_conv.numpy(), "disp_train": out.detach().numpy(),
+              "loss": np.float64(loss.item()), "maxdisp": np.int64(48)}
+    arrays.update(sd0)
+    n = 0
+    for k_, p_ in sup.named_parameters():
+        if p_.grad is not None and (".stem" in k_ or ".last_" in k_ or ".cells.0." in k_ or "matching.cells.4." in k_ or "matching.cells.7." in k_):
+            arrays["grad::" + k_] = p_.grad.numpy()
+            n += 1
+    arrays["n_params_with_grad"] = np.int64(sum(1 for p_ in sup.parameters() if p_.grad is not None))
+    arrays["n_params"] = np.int64(sum(1 for _ in sup.parameters()))
+    save("g9_supernet", **arrays)
+
 
 if __name__ == "__main__":
     main()

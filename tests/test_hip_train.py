@@ -416,3 +416,42 @@ def test_masked_smooth_l1_forward_backward(ra):
     (loss * 1.7).backward()
     close(loss, ref, 1e-6)
     close(eg.grad, est.grad, 1e-6)
+
+
+# --------------------------------------------------------------------------- MdeNAS supernet
+def _supernet_from_golden(ra, g):
+    net = ra.BasicNetwork(device=DEV, maxdisp=int(g["maxdisp"]))
+    net.load_state_dict(split_sd(g), strict=True)
+    return net.to(DEV)
+
+
+def test_supernet_eval_forward_golden(ra):
+    """BasicNetwork.forward(left, right, fea_ops, mat_ops) in eval mode vs the reference's own supernet (g9)."""
+    g = load_golden("g9_supernet")
+    net = _supernet_from_golden(ra, g).eval()
+    left, right = gpu(g["left"]), gpu(g["right"])
+    with torch.no_grad():
+        disp = net(left, right, g["fea_ops"], g["mat_ops"])
+        disp_conv = net(left, right, np.ones(9, dtype=np.int64), np.ones(9, dtype=np.int64))
+    assert O.epe(disp.cpu(), torch.from_numpy(g["disp_eval"])) <= 1e-3
+    assert O.epe(disp_conv.cpu(), torch.from_numpy(g["disp_eval_all_conv"])) <= 1e-3
+
+
+def test_supernet_train_step_golden(ra):
+    """One search training step (mdenas_search.py:164-173): disp, loss and gradients vs the reference."""
+    g = load_golden("g9_supernet")
+    net = _supernet_from_golden(ra, g).train()
+    disp = net(gpu(g["left"]), gpu(g["right"]), g["fea_ops"], g["mat_ops"])
+    loss = _smooth_l1_step(disp, gpu(g["gt"]), int(g["maxdisp"]))
+    loss.backward()
+    close(disp, torch.from_numpy(g["disp_train"]), 5e-4, "disp")
+    assert abs(loss.item() - float(g["loss"])) < 2e-4 * max(1.0, float(g["loss"]))
+    named = dict(net.named_parameters())
+    n = 0
+    for k, ref in g.items():
+        if k.startswith("grad::"):
+            close(named[k[6:]].grad, torch.from_numpy(ref), 1e-3, k)
+            n += 1
+    assert n > 80
+    # ops that were not sampled get no gradient, like in the reference
+    assert sum(1 for p in net.parameters() if p.grad is not None) == int(g["n_params_with_grad"])

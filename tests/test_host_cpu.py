@@ -277,3 +277,23 @@ def test_reference_style_checkpoint_needs_genotypes_and_checks_them():
     bad = [dict(archis[0], stem_3d0=[7])]
     with pytest.raises(ValueError, match="archis"):
         ck.load_checkpoint(ref_style, device="cpu", genotypes=ck.unit_genotypes(net), archis=bad)
+
+
+# ------------------------------------------------------------------ MdeNAS supernet
+def test_supernet_state_dict_matches_reference_and_genotype_parse():
+    import rag_amd
+    g = load_golden("g9_supernet")
+    sd = split_sd(g)
+    net = rag_amd.BasicNetwork(device="cpu", maxdisp=48)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    assert sum(1 for _ in net.parameters()) == int(g["n_params"])
+    assert net.matching.cells[0]._ops[0] is None and net.matching.cells[0]._ops[1] is not None      # no s0 edge in the first cell
+    assert (net.num_edges, net.num_ops) == (9, 2) and net.p["normal"].shape == (9, 2)
+    # genotype(): per step the two edges with the largest non-identity probability, each with its argmax op
+    net.p["reduce"] = torch.tensor([[0.9, 0.1], [0.2, 0.8], [0.5, 0.5], [0.1, 0.9], [0.3, 0.7], [0.6, 0.4], [0.4, 0.6], [0.45, 0.55],
+                                    [0.2, 0.8]]).log()
+    rows = net.genotype().reduce.tolist()
+    assert rows == [[1, 1], [0, 0], [3, 1], [4, 1], [8, 1], [6, 1]]
+    twin = net.new()                             # mdenas_basicmodel.py:70-74: fresh weights, copied probabilities
+    assert torch.equal(twin.p["reduce"], net.p["reduce"]) and twin.p["reduce"] is not net.p["reduce"]
