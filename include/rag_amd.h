@@ -241,6 +241,23 @@ int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int d, int h, 
 int ragmi_disparity_regression_fwd(const void* prob, void* out, int B, int D, int H, int W,
                                    int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Cost volume + stem3d0 in one step, without materialising the cost volume (rag_model.py:375-383 followed by
+ * ConvBR_3d(2C, Cout, 3, 1, 1), rag_model.py:234/341).  The left half of the cost volume does not depend on the disparity
+ * plane and the right half depends on x - i only, so the 3-D convolution equals A[cls,tc][co,y,x] + B[cls,xr][co,y,x-i] with
+ * A / B two-dimensional convolutions of the feature maps with pre-summed weights (classes: z border, distance to the x = i
+ * diagonal, right border) — the same products, summed in another order.
+ *   ragmi_costvol_stem_prepare: weight [Cout, 2C, 3,3,3] fp32 -> `variants` (ragmi_costvol_stem_weights_elems floats)
+ *   ragmi_costvol_stem_fwd:     left/right [B,C,H,W] (dtype) -> y[B, Cout(+), D, H, W] = act(scale*(conv)+shift) (channels 0..Cout-1,
+ *                               batch stride y_bstride), optional fused consumer 1x1x1 tails as in ragmi_conv3d_k3_fwd_ex;
+ *                               `workspace`: ragmi_costvol_stem_workspace_elems floats.  C, Cout <= 16. */
+int64_t ragmi_costvol_stem_weights_elems(int C, int Cout);
+int ragmi_costvol_stem_prepare(const void* weight, void* variants, int C, int Cout, void* stream);
+int64_t ragmi_costvol_stem_workspace_elems(int B, int C, int Cout, int D, int H, int W);
+int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* variants, const void* scale, const void* shift, int relu,
+                           void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
+                           int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
+
 /* ragmi_conv3d_k3_pack with two options used by the training step: transpose != 0 packs the DATA-GRADIENT conv of a forward
  * weight (source [Cin][Cout][taps], taps flipped), Cout/Cin being those of the packed conv; planar2d != 0: the source is a 2-D
  * [.,.,3,3] weight living in the dz = 1 plane (Feature Net on depth-1 volumes). */

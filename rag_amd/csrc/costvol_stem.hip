@@ -1,0 +1,356 @@
+// Cost volume + first 3x3x3 ConvBR (stem3d0) without the cost volume.
+//
+// Reference: Network.forward builds cost[b, c, i, y, x] = L[b,c,y,x] and cost[b, C+c, i, y, x] = R[b,c,y,x-i] for
+// x >= i, zero elsewhere (src/models/rag_model.py:375-383) and feeds it to stem3d0 = ConvBR_3d(2C, Cout, 3, 1, 1)
+// (rag_model.py:234, 341; operations_3d.py:40-47).  The left half does not depend on the disparity plane i and the right
+// half depends on x - i only, so the convolution over (i, y, x) collapses:
+//
+//   pre[co, i, y, x] = sum_{c,dy,dx} L[c, y+dy, x+dx] * (sum over the admissible dz of wL[co,c,dz,dy,dx])
+//                    + sum_{c,dy,e } R[c, y+dy, (x-i)+e] * (sum over the admissible (dz,dx), dx-dz = e, of wR[co,c,dz,dy,dx])
+//
+// "admissible" = the tap lies inside the volume (0 <= i+dz < D, x+dx < W) and on the non-zero side of the cost volume
+// (x+dx >= i+dz).  Which taps are admissible depends only on a handful of classes of the output position:
+//   cls = [i == 0] + 2 [i == D-1]      (z border)          tc = clamp(x - i, -3, 2)   (distance to the x = i diagonal)
+//   xr  = [x == W-1]                   (right border, matters for the right half only)
+// so pre = A[cls, tc][co, y, x] + B[cls, xr][co, y, x - i] with A a 3x3 and B a 3x5 two-dimensional convolution of the
+// feature maps with pre-summed weights — EXACT (same products, summed in a different order), 15 + 6 small planes instead
+// of a 53 GFLOP 3-D convolution over a 327 MB tensor that is never materialised.  Three kernels:
+//   costvol_stem_weights : the pre-summed weight variants (once per weight version)
+//   costvol_stem_planes  : the variant planes (VALU, input tile + variant weights in LDS)
+//   costvol_stem_combine : out = act(scale * (A + B) + shift) (+ fused consumer 1x1x1 tails), HBM-write-bound
+#include "common.h"
+
+namespace ragmi {
+
+constexpr int CS_MAXC = 16;                 // feature channels C and output channels Cout supported by the register tiles
+constexpr int CS_NCLS = 4, CS_NTC = 5;      // z-border classes; tc = -2..2 (tc = -3 contributes nothing)
+
+// WA[cls][tcidx][c][dy][dx][co], WB[cls][xr][c][dy][e][co]  (co fastest: one broadcast LDS read feeds all outputs)
+__global__ __launch_bounds__(256) void costvol_stem_weights_kernel(const float* __restrict__ w, float* __restrict__ wa,
+                                                                   float* __restrict__ wb, int C, int Cout) {
+  const int na = CS_NCLS * CS_NTC * C * 9 * Cout, nb = CS_NCLS * 2 * C * 15 * Cout;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < na) {
+    int t = idx;
+    const int co = t % Cout; t /= Cout;
+    const int dx = t % 3 - 1; t /= 3;
+    const int dy = t % 3; t /= 3;
+    const int c = t % C; t /= C;
+    const int tc = t % CS_NTC - 2, cls = t / CS_NTC;
+    float s = 0.f;
+    for (int dz = -1; dz <= 1; ++dz) {
+      const bool ok = (dz >= 0 || !(cls & 1)) && (dz <= 0 || !(cls & 2)) && dz <= tc + dx;
+      if (ok) s += w[(((int64_t)co * 2 * C + c) * 3 + (dz + 1)) * 9 + dy * 3 + (dx + 1)];
+    }
+    wa[idx] = s;
+  } else if (idx < na + nb) {
+    int t = idx - na;
+    const int co = t % Cout; t /= Cout;
+    const int e = t % 5 - 2; t /= 5;
+    const int dy = t % 3; t /= 3;
+    const int c = t % C; t /= C;
+    const int xr = t % 2, cls = t / 2;
+    float s = 0.f;
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int dx = e + dz;
+      const bool ok = dx >= -1 && dx <= 1 && (dz >= 0 || !(cls & 1)) && (dz <= 0 || !(cls & 2)) && (dx < 1 || !xr);
+      if (ok) s += w[(((int64_t)co * 2 * C + C + c) * 3 + (dz + 1)) * 9 + dy * 3 + (dx + 1)];
+    }
+    wb[idx - na] = s;
+  }
+}
+
+// one set of planes: out[co][y][xi] = sum_{c,dy,k} src[c][y+dy-1][x0 + xi + k - kh] * w[c][dy][k][co]
+struct PlaneDesc {
+  int w_off;      // float offset of the variant's weights in the weight buffer
+  int out_off;    // float offset of the plane set in the workspace (per batch item: + b * ws_bstride)
+  int width;      // plane width (xi = 0..width-1)
+  int x0;         // source column of xi = 0
+  int right;      // 0: left features, 3 taps (kh = 1);  1: right features, 5 taps (kh = 2)
+};
+constexpr int CS_MAXDESC = 32;
+struct PlanesArgs {
+  const void* left;
+  const void* right;
+  const float* wts;
+  float* ws;
+  int64_t ws_bstride;
+  int C, Cout, H, W, ndesc;
+  PlaneDesc d[CS_MAXDESC];
+};
+constexpr int CS_TX = 64, CS_TY = 4, CS_PX = 4;     // workgroup tile; pixels per thread along x (weights read once per 4 pixels)
+constexpr int CS_RS = CS_TX + 5;                     // LDS row stride = 5 mod 32: the 16 x 4 lanes of a wave spread 2 per bank
+constexpr int CS_NT = (CS_TX / CS_PX) * CS_TY;       // threads per workgroup (one wave)
+static_assert(CS_RS % 32 == 5, "row stride must be 5 mod 32");
+// COUT4 = Cout / 4 when Cout is a multiple of 4 (weights read as float4 broadcasts), 0 = any Cout (scalar reads)
+template <class T, int COUT4>
+__global__ __launch_bounds__(CS_NT) void costvol_stem_planes_kernel(PlanesArgs a) {
+  constexpr int NCO = COUT4 ? COUT4 * 4 : CS_MAXC;
+  extern __shared__ __attribute__((aligned(16))) float cs_lds[];   // weights [C][3][ntap][Cout] | tile [C][TY+2][RS]
+  float* wl = cs_lds;
+  float* tile = cs_lds + ((a.C * 15 * a.Cout + 3) & ~3);
+  const PlaneDesc d = a.d[blockIdx.z % a.ndesc];
+  const int b = blockIdx.z / a.ndesc;
+  const int xb = blockIdx.x * CS_TX, yb = blockIdx.y * CS_TY;
+  if (xb >= d.width) return;                                      // uniform: descriptors have different widths
+  const int ntap = d.right ? 5 : 3, kh = d.right ? 2 : 1;
+  const T* src = static_cast<const T*>(d.right ? a.right : a.left) + (int64_t)b * a.C * a.H * a.W;
+  for (int e = threadIdx.x; e < a.C * (CS_TY + 2) * (CS_TX + 4); e += CS_NT) {
+    const int xx = e % (CS_TX + 4), yy = (e / (CS_TX + 4)) % (CS_TY + 2), c = e / ((CS_TX + 4) * (CS_TY + 2));
+    const int gy = yb + yy - 1, gx = d.x0 + xb + xx - kh;
+    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    tile[(c * (CS_TY + 2) + yy) * CS_RS + xx] = ok ? ld(src + ((int64_t)c * a.H + gy) * a.W + gx) : 0.f;
+  }
+  const int nw = a.C * 3 * ntap * a.Cout;
+  for (int e = threadIdx.x; e < nw; e += CS_NT) wl[e] = a.wts[d.w_off + e];
+  __syncthreads();
+  const int xx = (threadIdx.x % (CS_TX / CS_PX)) * CS_PX, yy = threadIdx.x / (CS_TX / CS_PX);
+  float acc[CS_PX][NCO];
+#pragma unroll
+  for (int p = 0; p < CS_PX; ++p)
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) acc[p][co] = 0.f;
+  auto body = [&](auto ntap_) {
+    constexpr int NT = decltype(ntap_)::value;
+    for (int c = 0; c < a.C; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        float v[CS_PX + NT - 1];
+#pragma unroll
+        for (int k = 0; k < CS_PX + NT - 1; ++k) v[k] = tile[(c * (CS_TY + 2) + yy + dy) * CS_RS + xx + k];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          const float* wr = wl + ((c * 3 + dy) * NT + k) * a.Cout;
+          if constexpr (COUT4 > 0) {
+#pragma unroll
+            for (int q = 0; q < COUT4; ++q) {
+              const float4 w4 = *reinterpret_cast<const float4*>(wr + 4 * q);
+#pragma unroll
+              for (int p = 0; p < CS_PX; ++p) {
+                acc[p][4 * q + 0] = fmaf(w4.x, v[p + k], acc[p][4 * q + 0]);
+                acc[p][4 * q + 1] = fmaf(w4.y, v[p + k], acc[p][4 * q + 1]);
+                acc[p][4 * q + 2] = fmaf(w4.z, v[p + k], acc[p][4 * q + 2]);
+                acc[p][4 * q + 3] = fmaf(w4.w, v[p + k], acc[p][4 * q + 3]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int co = 0; co < NCO; ++co)
+              if (co < a.Cout) {
+                const float wv = wr[co];
+#pragma unroll
+                for (int p = 0; p < CS_PX; ++p) acc[p][co] = fmaf(wv, v[p + k], acc[p][co]);
+              }
+          }
+        }
+      }
+  };
+  if (d.right) body(std::integral_constant<int, 5>{}); else body(std::integral_constant<int, 3>{});
+  const int y = yb + yy;
+  if (y >= a.H) return;
+  float* out = a.ws + b * a.ws_bstride + d.out_off + (int64_t)y * d.width + xb + xx;
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) {
+    if (co >= a.Cout) break;
+#pragma unroll
+    for (int p = 0; p < CS_PX; ++p)
+      if (xb + xx + p < d.width) out[(int64_t)co * a.H * d.width + p] = acc[p][co];
+  }
+}
+
+struct CombineArgs {
+  const float* ws;
+  int64_t ws_bstride;
+  const float* scale;
+  const float* shift;
+  void* y;
+  int64_t y_bstride;
+  int relu, Cout, D, H, W, wband, wb1, u1_0;
+  int off_afull[CS_NCLS], off_aband[CS_NCLS], off_b0[CS_NCLS], off_b1[CS_NCLS];   // float offsets of the plane sets
+  int ntail;
+  ragmi_tail_t tail[2];
+};
+template <class T>
+__global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a) {
+  __shared__ float par[2 * CS_MAXC + 2 * (4 * CS_MAXC + 8)];      // scale | shift | per tail: w[4][Cout] scale[4] shift[4]
+  for (int e = threadIdx.x; e < a.Cout; e += 256) {
+    par[e] = a.scale ? a.scale[e] : 1.f;
+    par[CS_MAXC + e] = a.shift ? a.shift[e] : 0.f;
+  }
+  for (int t = 0; t < a.ntail; ++t) {
+    float* p = par + 2 * CS_MAXC + t * (4 * CS_MAXC + 8);
+    const ragmi_tail_t& tl = a.tail[t];
+    for (int e = threadIdx.x; e < tl.cout * a.Cout; e += 256) p[e] = static_cast<const float*>(tl.weight)[e];
+    for (int e = threadIdx.x; e < tl.cout; e += 256) {
+      p[4 * CS_MAXC + e] = tl.scale ? static_cast<const float*>(tl.scale)[e] : 1.f;
+      p[4 * CS_MAXC + 4 + e] = tl.shift ? static_cast<const float*>(tl.shift)[e] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.W) return;
+  const int y = blockIdx.y % a.H, i = blockIdx.y / a.H, b = blockIdx.z;
+  const int cls = (i == 0 ? 1 : 0) + (i == a.D - 1 ? 2 : 0);
+  const int t = x - i, tc = min(max(t, -3), 2), xr = x == a.W - 1 ? 1 : 0;
+  const float* ws = a.ws + b * a.ws_bstride;
+  // A: full-width plane for tc = 2, band plane (columns 0..wband-1) for tc = -2..1, nothing for tc = -3
+  const float* pa = nullptr;
+  int64_t sa = 0;
+  if (tc == 2) { pa = ws + a.off_afull[cls] + (int64_t)y * a.W + x; sa = (int64_t)a.H * a.W; }
+  else if (tc > -3) { pa = ws + a.off_aband[cls] + (int64_t)(tc + 2) * a.Cout * a.H * a.wband + (int64_t)y * a.wband + x; sa = (int64_t)a.H * a.wband; }
+  // B: indexed by u = x - i (>= -2 to contribute); the right-border variant lives on u in [u1_0, W-1]
+  const float* pb = nullptr;
+  int64_t sb = 0;
+  if (t >= -2) {
+    if (xr) { pb = ws + a.off_b1[cls] + (int64_t)y * a.wb1 + (t - a.u1_0); sb = (int64_t)a.H * a.wb1; }
+    else { pb = ws + a.off_b0[cls] + (int64_t)y * (a.W + 2) + (t + 2); sb = (int64_t)a.H * (a.W + 2); }
+  }
+  float v[CS_MAXC];
+#pragma unroll
+  for (int co = 0; co < CS_MAXC; ++co) {
+    if (co < a.Cout) {
+      float s = (pa ? pa[co * sa] : 0.f) + (pb ? pb[co * sb] : 0.f);
+      s = fmaf(s, par[co], par[CS_MAXC + co]);
+      v[co] = a.relu ? fmaxf(s, 0.f) : s;
+    } else {
+      v[co] = 0.f;
+    }
+  }
+  const int64_t HW = (int64_t)a.H * a.W, DHW = HW * a.D, vox = (int64_t)i * HW + (int64_t)y * a.W + x;
+  T* py = static_cast<T*>(a.y) + b * a.y_bstride + vox;
+#pragma unroll
+  for (int co = 0; co < CS_MAXC; ++co)
+    if (co < a.Cout) st(py + co * DHW, v[co]);
+  for (int tl = 0; tl < a.ntail; ++tl) {
+    const float* p = par + 2 * CS_MAXC + tl * (4 * CS_MAXC + 8);
+    const ragmi_tail_t& td = a.tail[tl];
+    T* pt = static_cast<T*>(td.y) + b * td.y_bstride + (int64_t)td.y_ch0 * DHW + vox;
+    for (int k = 0; k < td.cout; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int co = 0; co < CS_MAXC; ++co)
+        if (co < a.Cout) s = fmaf(p[k * a.Cout + co], v[co], s);
+      s = fmaf(s, p[4 * CS_MAXC + k], p[4 * CS_MAXC + 4 + k]);
+      st(pt + k * DHW, td.relu ? fmaxf(s, 0.f) : s);
+    }
+  }
+}
+
+struct StemLayout {
+  int wband, wb1, u1_0;
+  int64_t na, nb;                 // weight variant sizes
+  int64_t off_afull[CS_NCLS], off_aband[CS_NCLS], off_b0[CS_NCLS], off_b1[CS_NCLS];
+  int64_t per_batch;              // workspace floats per batch item
+  bool used[CS_NCLS];
+};
+static void stem_layout(int C, int Cout, int D, int H, int W, StemLayout& l) {
+  l.wband = std::min(W, D + 1);                 // band columns x = i + tc <= D
+  l.u1_0 = std::max(W - D, -2);                 // right-border variant: u = W-1-i
+  l.wb1 = W - l.u1_0;
+  l.na = (int64_t)CS_NCLS * CS_NTC * C * 9 * Cout;
+  l.nb = (int64_t)CS_NCLS * 2 * C * 15 * Cout;
+  for (int c = 0; c < CS_NCLS; ++c) l.used[c] = false;
+  for (int i = 0; i < D; ++i) l.used[(i == 0 ? 1 : 0) + (i == D - 1 ? 2 : 0)] = true;
+  int64_t off = 0;
+  for (int c = 0; c < CS_NCLS; ++c) {
+    l.off_afull[c] = l.off_aband[c] = l.off_b0[c] = l.off_b1[c] = 0;
+    if (!l.used[c]) continue;
+    l.off_afull[c] = off; off += (int64_t)Cout * H * W;
+    l.off_aband[c] = off; off += (int64_t)4 * Cout * H * l.wband;
+    l.off_b0[c] = off; off += (int64_t)Cout * H * (W + 2);
+    l.off_b1[c] = off; off += (int64_t)Cout * H * l.wb1;
+  }
+  l.per_batch = off;
+}
+
+}  // namespace ragmi
+
+extern "C" int64_t ragmi_costvol_stem_weights_elems(int C, int Cout) {
+  if (C <= 0 || Cout <= 0) return 0;
+  return (int64_t)ragmi::CS_NCLS * (ragmi::CS_NTC * 9 + 2 * 15) * C * Cout;
+}
+
+extern "C" int ragmi_costvol_stem_prepare(const void* weight, void* variants, int C, int Cout, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(weight && variants, RAGMI_EINVAL, "costvol_stem_prepare: null pointer");
+  RAGMI_REQUIRE(C > 0 && Cout > 0 && C <= CS_MAXC && Cout <= CS_MAXC, RAGMI_EUNSUPPORTED,
+                "costvol_stem_prepare: C and Cout must be in 1..%d", CS_MAXC);
+  const int64_t na = (int64_t)CS_NCLS * CS_NTC * C * 9 * Cout, nb = (int64_t)CS_NCLS * 2 * C * 15 * Cout;
+  hipLaunchKernelGGL(costvol_stem_weights_kernel, dim3((unsigned)ceil_div(na + nb, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const float*)weight, (float*)variants, (float*)variants + na, C, Cout);
+  return check_launch("costvol_stem_prepare");
+}
+
+extern "C" int64_t ragmi_costvol_stem_workspace_elems(int B, int C, int Cout, int D, int H, int W) {
+  using namespace ragmi;
+  if (B <= 0 || C <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  StemLayout l;
+  stem_layout(C, Cout, D, H, W, l);
+  return l.per_batch * B;
+}
+
+extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* variants, const void* scale, const void* shift,
+                                      int relu, void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
+                                      int ntail, const ragmi_tail_t* tails, int dtype, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(left && right && variants && y && workspace, RAGMI_EINVAL, "costvol_stem: null pointer");
+  RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "costvol_stem: scale/shift must both be given or both NULL");
+  RAGMI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && B <= 65535, RAGMI_EINVAL, "costvol_stem: bad size");
+  RAGMI_REQUIRE(C > 0 && Cout > 0 && C <= CS_MAXC && Cout <= CS_MAXC, RAGMI_EUNSUPPORTED, "costvol_stem: C and Cout must be in 1..%d",
+                CS_MAXC);
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "costvol_stem: dtype %d not built", dtype);
+  RAGMI_REQUIRE(ntail >= 0 && ntail <= 2 && (ntail == 0 || tails), RAGMI_EINVAL, "costvol_stem: at most two tails");
+  StemLayout l;
+  stem_layout(C, Cout, D, H, W, l);
+  RAGMI_REQUIRE(l.per_batch < (1ll << 31), RAGMI_EUNSUPPORTED, "costvol_stem: planes too large for 32-bit offsets");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  PlanesArgs pa{};
+  pa.left = left; pa.right = right; pa.wts = (const float*)variants; pa.ws = (float*)workspace; pa.ws_bstride = l.per_batch;
+  pa.C = C; pa.Cout = Cout; pa.H = H; pa.W = W;
+  int n = 0, maxw = 0;
+  const int sa = C * 9 * Cout, sb = C * 15 * Cout;
+  for (int c = 0; c < CS_NCLS; ++c) {
+    if (!l.used[c]) continue;
+    pa.d[n++] = PlaneDesc{(c * CS_NTC + 4) * sa, (int)l.off_afull[c], W, 0, 0};                       // tc = 2
+    for (int k = 0; k < 4; ++k)                                                                       // tc = -2..1
+      pa.d[n++] = PlaneDesc{(c * CS_NTC + k) * sa, (int)(l.off_aband[c] + (int64_t)k * Cout * H * l.wband), l.wband, 0, 0};
+    pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 0) * sb, (int)l.off_b0[c], W + 2, -2, 1};
+    pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 1) * sb, (int)l.off_b1[c], l.wb1, l.u1_0, 1};
+  }
+  pa.ndesc = n;
+  for (int k = 0; k < n; ++k) maxw = std::max(maxw, pa.d[k].width);
+  RAGMI_REQUIRE((int64_t)n * B <= 65535, RAGMI_EUNSUPPORTED, "costvol_stem: batch too large for one launch");
+  const dim3 pgrid((unsigned)ceil_div(maxw, CS_TX), (unsigned)ceil_div(H, CS_TY), (unsigned)(n * B));
+  const size_t plds = sizeof(float) * (((size_t)C * 15 * Cout + 3) / 4 * 4 + (size_t)C * (CS_TY + 2) * CS_RS);
+#define RAGMI_CS_PLANES(TT)                                                                                             \
+  switch (Cout % 4 == 0 ? Cout / 4 : 0) {                                                                              \
+    case 1: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 1>), pgrid, dim3(CS_NT), plds, st, pa); break;          \
+    case 2: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 2>), pgrid, dim3(CS_NT), plds, st, pa); break;          \
+    case 3: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 3>), pgrid, dim3(CS_NT), plds, st, pa); break;          \
+    case 4: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 4>), pgrid, dim3(CS_NT), plds, st, pa); break;          \
+    default: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 0>), pgrid, dim3(CS_NT), plds, st, pa); break;         \
+  }
+  if (dtype == RAGMI_BF16) { RAGMI_CS_PLANES(bf16_t) } else { RAGMI_CS_PLANES(float) }
+#undef RAGMI_CS_PLANES
+
+  CombineArgs ca{};
+  ca.ws = (const float*)workspace; ca.ws_bstride = l.per_batch; ca.scale = (const float*)scale; ca.shift = (const float*)shift;
+  ca.y = y; ca.y_bstride = y_bstride; ca.relu = relu; ca.Cout = Cout; ca.D = D; ca.H = H; ca.W = W;
+  ca.wband = l.wband; ca.wb1 = l.wb1; ca.u1_0 = l.u1_0;
+  for (int c = 0; c < CS_NCLS; ++c) {
+    ca.off_afull[c] = (int)l.off_afull[c]; ca.off_aband[c] = (int)l.off_aband[c];
+    ca.off_b0[c] = (int)l.off_b0[c]; ca.off_b1[c] = (int)l.off_b1[c];
+  }
+  ca.ntail = ntail;
+  for (int t = 0; t < ntail; ++t) {
+    RAGMI_REQUIRE(tails[t].weight && tails[t].y && tails[t].cout >= 1 && tails[t].cout <= 4, RAGMI_EINVAL,
+                  "costvol_stem: tail %d needs weight, y and 1..4 output channels", t);
+    ca.tail[t] = tails[t];
+  }
+  RAGMI_REQUIRE((int64_t)D * H <= 65535, RAGMI_EUNSUPPORTED, "costvol_stem: D*H exceeds the grid limit");
+  const dim3 cgrid((unsigned)ceil_div(W, 256), (unsigned)(D * H), (unsigned)B);
+  if (dtype == RAGMI_BF16) hipLaunchKernelGGL(costvol_stem_combine_kernel<bf16_t>, cgrid, dim3(256), 0, st, ca);
+  else hipLaunchKernelGGL(costvol_stem_combine_kernel<float>, cgrid, dim3(256), 0, st, ca);
+  return check_launch("costvol_stem");
+}

@@ -136,6 +136,28 @@ class _ConvBR(nn.Module):
         y = ag.ConvBRFn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias, self)
         return y[:, :, 0] if squeeze else y
 
+    def costvol_fusable(self, C_fea: int) -> bool:
+        """This unit can consume (left_fea, right_fea) directly instead of the cost volume (ragmi_costvol_stem_fwd)."""
+        return (self.NDIM == 3 and self._geometry() == 3 and self.conv.in_channels == 2 * C_fea and C_fea <= 16
+                and self.conv.out_channels <= 16)
+
+    def costvol_variants(self) -> torch.Tensor:
+        """pre-summed weight variants of the fused cost-volume form, cached on the weight version."""
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = getattr(self, "_cv_cache", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, ops.costvol_stem_prepare(w.detach()))
+            self._cv_cache = hit
+        return hit[1]
+
+    def forward_costvol(self, left_fea, right_fea, maxdisp, tails=None) -> torch.Tensor:
+        """act(bn(conv(cost_volume(left_fea, right_fea)))) without materialising the cost volume (inference)."""
+        _wk, scale, shift = self.prepared()
+        return ops.costvol_stem(left_fea, right_fea, maxdisp, self.costvol_variants(), self.conv.out_channels, scale, shift,
+                                self.relu, tails=tails)
+
     def as_tail(self, out: torch.Tensor, out_ch0: int) -> "ops.Tail":
         """This 1x1(x1) ConvBR (<= 4 output channels) as a tail of the kernel that produces its input."""
         if self._geometry() != 1 or self.conv.out_channels > 4:
@@ -602,7 +624,9 @@ class MatchingNet(nn.Module):
         return Cell_3d(self._step, self._block_multiplier, pp, p, genotype, fm, du)
 
     # -- rag_model.py:325-366
-    def matching(self, x, task_arch, path=None):
+    def matching(self, x, task_arch, path=None, features=None):
+        """`features=(left_fea, right_fea)` with x=None: the cost volume is not built; stem3d0 consumes the feature maps
+        directly (ragmi_costvol_stem_fwd) — inference only, same result as matching(cost_volume(...))."""
         def unit(name):
             return task_arch[name][0] if task_arch is not None else None
 
@@ -614,31 +638,42 @@ class MatchingNet(nn.Module):
             elif path is not None:
                 arch_cell = path[i + 1]
             cells.append(cell[arch_cell])
-        last = self._run_chain(x, self.stem3d0[unit("stem_3d0")], self.stem3d1[unit("stem_3d1")], cells)
-        return self._head(x, last, unit("last_3_3d"), unit("last_6_3d"), unit("last_12_3d"))
+        last = self._run_chain(x, self.stem3d0[unit("stem_3d0")], self.stem3d1[unit("stem_3d1")], cells, features)
+        return self._head(self._vol_size(x, features), last, unit("last_3_3d"), unit("last_6_3d"), unit("last_12_3d"))
 
     # -- rag_model.py:663-685
-    def search_matching(self, x, selected_ops, t):
+    def search_matching(self, x, selected_ops, t, features=None):
         cells = [cell[selected_ops[i + 10]] for i, cell in enumerate(self.cells_3d)]
-        last = self._run_chain(x, self.stem3d0[selected_ops[8]], self.stem3d1[selected_ops[9]], cells)
-        return self._head(x, last, t, t, t)
+        last = self._run_chain(x, self.stem3d0[selected_ops[8]], self.stem3d1[selected_ops[9]], cells, features)
+        return self._head(self._vol_size(x, features), last, t, t, t)
 
-    def _run_chain(self, x, stem0, stem1, cells):
+    def _vol_size(self, x, features):
+        if x is not None:
+            return tuple(x.shape[2:])
+        return (int(self.maxdisp / 3),) + tuple(features[0].shape[2:])
+
+    def _run_chain(self, x, stem0, stem1, cells, features=None):
         """stem3d0 -> stem3d1 -> cells (rag_model.py:341-351) with cross-module fusion: the 1x1x1 pre_preprocess /
         preprocess conv of a cell that needs no resampling is computed in the epilogue of the kernel that PRODUCES its
         input (a "tail"), and a tensor consumed only by tails is never written to HBM.  Tensors: T[-2] = stem0 output,
         T[-1] = stem1 output, T[i] = output of cell i; cell i reads T[i-2] (prev_prev) and T[i-1] (prev)."""
-        if stem0.autograd_mode(x) or stem1.autograd_mode() or any(c.autograd_mode() for c in cells):
+        train = (stem0.autograd_mode(*(features if x is None else (x,))) or stem1.autograd_mode()
+                 or any(c.autograd_mode() for c in cells))
+        if x is None and (train or not stem0.costvol_fusable(features[0].shape[1])):
+            x = self.cost_volume(*features)
+        if train:
             out = (stem0(x),)                     # training: the reference's graph node by node (rag_model.py:341-351)
             out = (out[0], stem1(out[0]))
             for c in cells:
                 out = c(out[0], out[1])
             return out[-1]
         n = len(cells)
-        sizes = {-2: tuple(x.shape[2:]), -1: tuple(x.shape[2:])}
+        vol = self._vol_size(x, features)
+        sizes = {-2: vol, -1: vol}
         for i, c in enumerate(cells):
             sizes[i] = c.out_size(sizes[i - 1])
-        B, dev = x.shape[0], x.device
+        ref = x if x is not None else features[0]
+        B, dev, adt = ref.shape[0], ref.device, ref.dtype
 
         def fusable(i):
             """consumers of T[i] that can ride on its producer: [(cell index j, role 0 = pre_preprocess / 1 = preprocess)]"""
@@ -662,7 +697,7 @@ class MatchingNet(nn.Module):
             specs = []
             for (j, role) in fusable(i):
                 if j not in pre:
-                    pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=x.dtype)
+                    pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=adt)
                     has[j] = [False, False]
                 mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
                 specs.append((j, role, mod.as_tail(pre[j], cells[j].C_out if role == 1 else 0)))
@@ -679,7 +714,10 @@ class MatchingNet(nn.Module):
         T: Dict[int, Optional[torch.Tensor]] = {}
         # stem3d0: its output also feeds stem3d1 (3x3x3), so it is always materialised
         specs = tails_for(-2)
-        T[-2] = stem0(x, tails=[s[2] for s in specs] or None)
+        if x is None:
+            T[-2] = stem0.forward_costvol(features[0], features[1], self.maxdisp, tails=[s[2] for s in specs] or None)
+        else:
+            T[-2] = stem0(x, tails=[s[2] for s in specs] or None)
         settle(-2, specs, True, T[-2])
         # stem3d1
         specs = tails_for(-1)
@@ -697,8 +735,8 @@ class MatchingNet(nn.Module):
             T.pop(i - 2, None)
         return T[n - 1]
 
-    def _head(self, x, last_output, i3, i6, i12):
-        d, h, w = x.size()[2], x.size()[3], x.size()[4]
+    def _head(self, vol, last_output, i3, i6, i12):
+        d, h, w = vol
         if last_output.size()[3] == h:
             return self.last_3_3d[i3](last_output)
         heads = (self.last_3_3d[i3], self.last_6_3d[i6], self.last_12_3d[i12])
@@ -723,6 +761,9 @@ class MatchingNet(nn.Module):
     def forward(self, left_fea, right_fea, task_arch=None):
         if task_arch is None:
             task_arch = self.arch_init
-        cost = self.cost_volume(left_fea, right_fea)
-        cost = self.matching(cost, task_arch, None)
+        if left_fea.shape != right_fea.shape or left_fea.dim() != 4:
+            raise ValueError("MatchingNet: left/right features must both be [B, C, h, w]")
+        # the cost volume (rag_model.py:375-383) is folded into stem3d0 (ragmi_costvol_stem_fwd); matching(cost_volume(..))
+        # remains available and gives the same result
+        cost = self.matching(None, task_arch, None, features=(left_fea, right_fea))
         return self.disp(cost)

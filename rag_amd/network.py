@@ -140,14 +140,12 @@ class Network(MatchingNet):
 
     def forward(self, left, right, t, task_arch=None, path=None):   # rag_model.py:369-387
         lf, rf = self._features(left, right, lambda x: self.feature(x, task_arch, path))
-        cost = self.cost_volume(lf, rf)
-        cost = self.matching(cost, task_arch, path)
+        cost = self.matching(None, task_arch, path, features=(lf, rf))     # cost volume folded into stem3d0
         return self.disp(cost)
 
     def search_forward(self, left, right, t, selected_ops):        # rag_model.py:688-706
         lf, rf = self._features(left, right, lambda x: self.search_feature(x, selected_ops))
-        cost = self.cost_volume(lf, rf)
-        cost = self.search_matching(cost, selected_ops, t)
+        cost = self.search_matching(None, selected_ops, t, features=(lf, rf))
         return self.disp(cost)
 
     # ------------------------------------------------------------------ growth API

@@ -105,6 +105,44 @@ def costvol(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, out: 
     return out
 
 
+def costvol_stem_prepare(weight: torch.Tensor) -> torch.Tensor:
+    """Pre-summed weight variants of a ConvBR_3d(2C, Cout, 3, 1, 1) that consumes the cost volume (ragmi_costvol_stem_prepare)."""
+    _need_gpu(weight)
+    Cout, C2 = weight.shape[:2]
+    if tuple(weight.shape[2:]) != (3, 3, 3) or C2 % 2:
+        raise ValueError("costvol_stem_prepare: weight must be [Cout, 2C, 3, 3, 3]")
+    lib = load_library()
+    out = torch.empty((lib.ragmi_costvol_stem_weights_elems(C2 // 2, Cout),), device=weight.device, dtype=torch.float32)
+    check(lib.ragmi_costvol_stem_prepare(weight.detach().contiguous().data_ptr(), out.data_ptr(), C2 // 2, Cout, _stream()),
+          "costvol_stem_prepare")
+    return out
+
+
+def costvol_stem(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, variants: torch.Tensor, cout: int,
+                 scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool, out: Optional[torch.Tensor] = None,
+                 tails: Optional[Sequence[Tail]] = None) -> torch.Tensor:
+    """act(bn(conv3x3x3(cost_volume(left_fea, right_fea)))) without building the cost volume: ragmi_costvol_stem_fwd."""
+    _need_gpu(variants, scale, shift)
+    dt = _act(left_fea, right_fea, out, *[t.out for t in (tails or [])])
+    if left_fea.shape != right_fea.shape or left_fea.dim() != 4:
+        raise ValueError("costvol_stem: left/right features must both be [B, C, h, w]")
+    left_fea, right_fea = left_fea.contiguous(), right_fea.contiguous()
+    B, C, h, w = left_fea.shape
+    d = int(maxdisp / 3)
+    if out is None:
+        out = torch.empty((B, cout, d, h, w), device=left_fea.device, dtype=left_fea.dtype)
+    if tuple(out.shape[2:]) != (d, h, w) or out.shape[1] < cout or out.shape[0] != B:
+        raise ValueError("costvol_stem: out must be [B, >=Cout, maxdisp/3, h, w]")
+    lib = load_library()
+    ws = torch.empty((lib.ragmi_costvol_stem_workspace_elems(B, C, cout, d, h, w),), device=left_fea.device, dtype=torch.float32)
+    ntail, tarr = _tail_array(tails)
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(lib.ragmi_costvol_stem_fwd(left_fea.data_ptr(), right_fea.data_ptr(), variants.data_ptr(), p(scale), p(shift), int(relu),
+                                     out.data_ptr(), _planes(out), ws.data_ptr(), B, C, cout, d, h, w, ntail, tarr, dt, _stream()),
+          "costvol_stem")
+    return out
+
+
 def conv3d_k3_pack(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor:
     """Pre-pack an nn.Conv3d weight [Cout, Cin, 3, 3, 3] (or an nn.Conv2d weight [Cout, Cin, 3, 3], run as the dz = 1 plane of
     a 3x3x3 on depth-1 volumes) for conv3d_k3.  transpose=True packs the conv that computes the DATA GRADIENT of this weight's

@@ -550,3 +550,53 @@ def test_matchingnet_config4_shape_epe_and_shard_equivalence(ra):
     torch.set_num_threads(16)
     ref = O.matching_net_forward(lf[:1], rf[:1], sd, rows, 192)
     assert O.epe(both[:1].cpu(), ref) <= EPE_GATE
+
+
+# --------------------------------------------------------------------------- cost volume + stem3d0 without the cost volume
+@pytest.mark.parametrize("B,C,cout,h,w,maxdisp,bn,relu", [
+    (1, 12, 12, 8, 32, 24, True, True),        # D=8
+    (2, 12, 12, 5, 9, 48, True, True),         # w < D: every column is inside the diagonal band
+    (1, 12, 12, 6, 20, 3, True, True),         # D=1: one plane is both z borders
+    (1, 12, 12, 6, 20, 6, True, False),        # D=2
+    (2, 3, 5, 7, 13, 15, False, False),        # odd channel counts, no BN
+    (1, 12, 12, 16, 70, 48, True, True),       # wider than one 64-column tile
+    (1, 12, 12, 128, 416, 192, True, True),    # headline size
+])
+def test_costvol_stem_vs_oracle(ra, B, C, cout, h, w, maxdisp, bn, relu):
+    L, R = torch.randn((B, C, h, w), generator=gen(101)), torch.randn((B, C, h, w), generator=gen(102))
+    wt = torch.randn((cout, 2 * C, 3, 3, 3), generator=gen(103)) * 0.1
+    sd = {"conv.weight": wt, "bn.weight": torch.rand(cout, generator=gen(104)) + 0.5, "bn.bias": torch.randn(cout, generator=gen(105)) * 0.1,
+          "bn.running_mean": torch.randn(cout, generator=gen(106)) * 0.1, "bn.running_var": torch.rand(cout, generator=gen(107)) + 0.5}
+    torch.set_num_threads(16)
+    ref = O.conv_br_3d(O.cost_volume(L, R, maxdisp), sd, "", padding=1, bn=bn, relu=relu)
+    scale = shift = None
+    if bn:
+        scale = sd["bn.weight"] * torch.rsqrt(sd["bn.running_var"] + 1e-5)
+        shift = sd["bn.bias"] - sd["bn.running_mean"] * scale
+    var = ra.ops.costvol_stem_prepare(gpu(wt))
+    out = ra.ops.costvol_stem(gpu(L), gpu(R), maxdisp, var, cout, gpu(scale) if bn else None, gpu(shift) if bn else None, relu)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), **TOL)
+
+
+def test_costvol_stem_tails_and_bf16(ra):
+    B, C, h, w, maxdisp = 2, 12, 6, 40, 24
+    L, R = torch.randn((B, C, h, w), generator=gen(111)), torch.randn((B, C, h, w), generator=gen(112))
+    wt = torch.randn((12, 24, 3, 3, 3), generator=gen(113)) * 0.1
+    w1, w2 = torch.randn((4, 12), generator=gen(114)) * 0.3, torch.randn((3, 12), generator=gen(115)) * 0.3
+    s1, h1 = torch.rand(4, generator=gen(116)) + 0.5, torch.randn(4, generator=gen(117)) * 0.1
+    ref = F.relu(F.conv3d(O.cost_volume(L, R, maxdisp), wt, padding=1))
+    t1 = F.relu(torch.einsum("kc,bcdhw->bkdhw", w1, ref) * s1.view(1, -1, 1, 1, 1) + h1.view(1, -1, 1, 1, 1))
+    t2 = torch.einsum("kc,bcdhw->bkdhw", w2, ref)
+    var = ra.ops.costvol_stem_prepare(gpu(wt))
+    pre = torch.zeros((B, 8, maxdisp // 3, h, w), device=DEV)
+    tails = [ra.ops.Tail(gpu(w1), gpu(s1), gpu(h1), True, pre, 4), ra.ops.Tail(gpu(w2), None, None, False, pre, 0)]
+    out = ra.ops.costvol_stem(gpu(L), gpu(R), maxdisp, var, 12, None, None, True, tails=tails)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), **TOL)
+    np.testing.assert_allclose(pre[:, 4:8].cpu().numpy(), t1.numpy(), **TOL)
+    np.testing.assert_allclose(pre[:, 0:3].cpu().numpy(), t2.numpy(), **TOL)
+    # bf16 storage: features and output in bf16, planes and arithmetic in fp32
+    Lb, Rb = L.to(torch.bfloat16), R.to(torch.bfloat16)
+    refb = F.relu(F.conv3d(O.cost_volume(Lb.float(), Rb.float(), maxdisp), wt, padding=1))
+    outb = ra.ops.costvol_stem(gpu(Lb), gpu(Rb), maxdisp, var, 12, None, None, True)
+    assert outb.dtype == torch.bfloat16
+    np.testing.assert_allclose(outb.float().cpu().numpy(), refb.numpy(), rtol=1e-2, atol=1e-2)
