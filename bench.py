@@ -149,7 +149,7 @@ def timed_region(step, steps: int, warmup: int, dist=None, sync=lambda: None, de
     return dt
 
 
-def end_to_end(device, steps, seed=0):
+def end_to_end(device, steps, seed=0, use_graph=True):
     """(left, right) images -> disparity through rag_amd.Network: Feature Net + Matching Net, all HIP.
     Reported beside the headline Matching-Net metric ('separately reported, end-to-end')."""
     import rag_amd
@@ -171,13 +171,24 @@ def end_to_end(device, steps, seed=0):
         for _ in range(2):
             net(left, right, 0, net.arch_init)
         torch.cuda.synchronize()
+        graph = None
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                net(left, right, 0, net.arch_init)
+            graph.replay()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            net(left, right, 0, net.arch_init)
+            if graph is not None:
+                graph.replay()
+            else:
+                net(left, right, 0, net.arch_init)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(1.0 / dt, 3), "unit": "disparity maps/s", "ms_per_pair": round(dt * 1e3, 4),
-            "what": f"(left,right)[1,3,{H},{W}] -> disp, Feature Net + Matching Net on HIP, B=1 fp32"}
+            "what": f"(left,right)[1,3,{H},{W}] -> disp, Feature Net + Matching Net on HIP, B=1 fp32, "
+                    f"{'hipGraph' if use_graph else 'eager'}"}
 
 
 def randomize_bn(net, seed):
@@ -280,14 +291,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (configs[1]: 1)")
     ap.add_argument("--graph", type=int, default=None,
-                    help="1: replay the step as a captured hipGraph (default: 0 for inference, 1 for --train)")
+                    help="1 (default): replay the step as a captured hipGraph; 0: eager launches")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="activation storage: f32 (configs[1], default) or bf16 storage / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: time the data-parallel training step instead")
     args = ap.parse_args()
     if args.graph is None:
-        args.graph = 1 if args.train else 0
+        args.graph = 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -385,7 +396,7 @@ def main():
             epe = O.epe(out[:1].float().cpu(), ref)
             log(f"  EPE of the timed GPU path vs the CPU oracle on the same pair: {epe:.3e} px")
             cpu["epe_gpu_vs_cpu_px"] = epe
-        e2e = end_to_end(device, min(args.steps, 10)) if (n_gpus == 1 and args.dtype == "f32") else None
+        e2e = end_to_end(device, min(args.steps, 10), use_graph=bool(args.graph)) if (n_gpus == 1 and args.dtype == "f32") else None
         if e2e:
             log(f"  end-to-end (images -> disparity, Feature Net + Matching Net): {e2e['value']} maps/s ({e2e['ms_per_pair']} ms/pair)")
         ms = dt / args.steps * 1e3

@@ -78,7 +78,7 @@ struct PlanesArgs {
   int C, Cout, H, W, ndesc;
   PlaneDesc d[CS_MAXDESC];
 };
-constexpr int CS_TX = 64, CS_TY = 4, CS_PX = 4;     // workgroup tile; pixels per thread along x (weights read once per 4 pixels)
+constexpr int CS_TX = 64, CS_TY = 8, CS_PX = 4;     // workgroup tile; pixels per thread along x (weights read once per 4 pixels)
 constexpr int CS_RS = CS_TX + 5;                     // LDS row stride = 5 mod 32: the 16 x 4 lanes of a wave spread 2 per bank
 constexpr int CS_NT = (CS_TX / CS_PX) * CS_TY;       // threads per workgroup (one wave)
 static_assert(CS_RS % 32 == 5, "row stride must be 5 mod 32");

@@ -348,10 +348,22 @@ class _Cell(nn.Module):
             self._fused_cache[key] = hit
         return hit[1]
 
+    def _convbrs(self):
+        """the ConvBR units of this cell (cached: the module tree of a cell never changes after construction)."""
+        units = self.__dict__.get("_convbr_cache")
+        if units is None:
+            units = [m for m in self.modules() if isinstance(m, _ConvBR)]
+            self.__dict__["_convbr_cache"] = units
+        return units
+
     def autograd_mode(self, *inputs) -> bool:
-        if ag.needs_grad(*inputs, *self.parameters()):
-            return True
-        return any(m.use_bn and m.bn.training for m in self.modules() if isinstance(m, _ConvBR))
+        units = self._convbrs()
+        if torch.is_grad_enabled():
+            if any(t is not None and t.requires_grad for t in inputs):
+                return True
+            if any(m.conv.weight.requires_grad or m.bn.weight.requires_grad or m.bn.bias.requires_grad for m in units):
+                return True
+        return any(m.use_bn and m.bn.training for m in units)
 
     def forward(self, prev_prev_input, prev_input):
         run = self._run_autograd if self.autograd_mode(prev_prev_input, prev_input) else (lambda a, b: self._run(a, b)[0])

@@ -125,9 +125,17 @@ class Network(MatchingNet):
 
     def _training_graph(self, *inputs) -> bool:
         """True when the call must build the reference's autograd graph / use batch statistics (rag.py:155-219)."""
+        units = [m for m in self.modules() if isinstance(m, _ConvBR)] if self.training or torch.is_grad_enabled() else None
         if torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in self.parameters())):
             return True
-        return any(m.use_bn and m.bn.training for m in self.modules() if isinstance(m, _ConvBR))
+        if units is None:
+            # eval() on the root puts every unit in eval; a unit switched back to train() by hand is still honoured below
+            units = self.__dict__.get("_convbr_cache")
+            if units is None or self.__dict__.get("_convbr_count") != sum(len(self._units(n)) for n in self._p_layers()):
+                units = [m for m in self.modules() if isinstance(m, _ConvBR)]
+                self.__dict__["_convbr_cache"] = units
+                self.__dict__["_convbr_count"] = sum(len(self._units(n)) for n in self._p_layers())
+        return any(m.use_bn and m.bn.training for m in units)
 
     def _features(self, left, right, feature):
         if self._training_graph(left, right):
