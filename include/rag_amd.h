@@ -290,7 +290,7 @@ int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* scale, const 
 int ragmi_bn_act_bwd_coeffs(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
                             const void* scale, const void* shift, int relu, const void* mean, const void* invstd, int training,
                             int B, int C, int64_t DHW, void* workspace, void* c1, void* c2, void* c3, void* dgamma, void* dbeta,
-                            void* stream);
+                            int accumulate, void* stream);   /* dgamma / dbeta may be NULL; accumulate != 0: += */
 
 /* dx[b,c] = g * c1[c] + x * c2[c] + c3[c]   (train-mode BN backward is linear in g and x per channel; eval BN: c2 = c3 = 0) */
 int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
@@ -301,8 +301,10 @@ int ragmi_bn_act_bwd_apply(const void* dy, int64_t dy_bstride, int dy_ch0, const
  * workgroups write partial sums to `workspace`, ragmi_conv3d_k3_wgrad_workspace_elems(...) floats, and a second kernel adds them:
  * deterministic, dw needs no initialisation) */
 int64_t ragmi_conv3d_k3_wgrad_workspace_elems(int B, int Cin, int Cout, int D, int H, int W);
-int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw, void* workspace,
-                          int B, int Cin, int Cout, int D, int H, int W, void* stream);
+int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* const* dw_list, int n_dw,
+                          int accumulate, int planar2d, void* workspace, int B, int Cin, int Cout, int D, int H, int W, void* stream);
+/* dw_list: n_dw (1..8) destination tensors, each [Cout/n_dw, Cin, 3,3,3] (planar2d: [.., 3,3], the dz = 1 plane) — stacked
+ * sibling convolutions write every unit's gradient in place; accumulate != 0: dw += (gradient accumulation into .grad) */
 
 /* dw[co][ci] (+=) sum_{b,v} g[b, g_ch0+co, v] * x[b, ci, v]   — weight gradient of the 1x1x1 conv */
 int ragmi_conv3d_k1_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw,

@@ -74,12 +74,12 @@ SIGNATURES = {
     "ragmi_bn_act_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
                                  c_int, c_int, c_int64, c_void_p]),
     "ragmi_bn_act_bwd_coeffs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                        c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                        c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ragmi_bn_act_bwd_apply": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "ragmi_conv3d_k3_wgrad_workspace_elems": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "ragmi_conv3d_k3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                      c_int, c_void_p]),
+    "ragmi_conv3d_k3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_void_p,
+                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k1_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "ragmi_trilinear3d_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_costvol_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

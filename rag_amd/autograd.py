@@ -28,6 +28,14 @@ import torch
 from . import ops
 
 
+def _direct(p) -> "torch.Tensor | None":
+    """A parameter whose .grad is a persistent view of a flat gradient bucket (rag_amd.train.GradBucket): backward kernels
+    accumulate into it in place and autograd gets None for that input — no temporary and no AccumulateGrad add launch."""
+    if getattr(p, "_ragmi_direct", False) and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32:
+        return p.grad
+    return None
+
+
 def _dense(t: torch.Tensor) -> torch.Tensor:
     """Channel planes dense (a channel-slice view of a contiguous buffer qualifies); copy otherwise."""
     inner = 1
@@ -83,11 +91,12 @@ class ConvBRFn(torch.autograd.Function):
             else:
                 ops.conv3d_k1(draw, w.reshape(cout, cin).t().contiguous(), None, None, False, dx)
         if need_w:
+            tw = _direct(mod.conv.weight)
             if k == 3:
-                dw5 = ops.conv3d_k3_wgrad(x, draw, cout)
-                dw = (dw5[:, :, 1] if mod.NDIM == 2 else dw5).reshape(weight.shape)
+                dw = ops.conv3d_k3_wgrad(x, draw, cout, into=[tw] if tw is not None else None, planar2d=mod.NDIM == 2)
             else:
-                dw = ops.conv3d_k1_wgrad(x, draw, cout).reshape(weight.shape)
+                dw = ops.conv3d_k1_wgrad(x, draw, cout, into=tw)
+                dw = None if tw is not None else dw.reshape(weight.shape)
         return dx, dw, dgamma, dbeta, None
 
 
@@ -114,7 +123,8 @@ def _bn_forward(raw, n, gamma, beta, mod):
 
 
 def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, need_b, out=None):
-    """ReLU + BatchNorm adjoint: (gradient w.r.t. the raw conv output, dgamma, dbeta); `out`: destination channel slice."""
+    """ReLU + BatchNorm adjoint: (gradient w.r.t. the raw conv output, dgamma, dbeta); `out`: destination channel slice.
+    dgamma / dbeta come back as None when they were accumulated straight into bucket-backed .grad tensors."""
     if not (mod.use_bn or mod.relu):
         if out is not None:
             out.copy_(dy)
@@ -122,9 +132,13 @@ def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, 
         return dy, None, None
     dgamma = dbeta = None
     if mod.use_bn and (training or need_g or need_b):
-        co = ops.bn_act_bwd_coeffs(dy, 0, raw, scale, shift, mod.relu, mean, invstd, training)
+        tg, tb = (_direct(mod.bn.weight), _direct(mod.bn.bias)) if (need_g and need_b) else (None, None)
+        direct = tg is not None and tb is not None
+        co = ops.bn_act_bwd_coeffs(dy, 0, raw, scale, shift, mod.relu, mean, invstd, training,
+                                   dgamma_into=tg if direct else None, dbeta_into=tb if direct else None)
         c1, c2, c3 = co[0], co[1], co[2]
-        dgamma, dbeta = (co[3] if need_g else None), (co[4] if need_b else None)
+        if not direct:
+            dgamma, dbeta = (co[3] if need_g else None), (co[4] if need_b else None)
     else:
         c1 = scale
         c2 = c3 = torch.zeros_like(scale)
@@ -175,13 +189,17 @@ class ConvBRGroupFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ops.conv3d_k3(draw, ops.conv3d_k3_pack(wcat, transpose=True), x.shape[1], None, None, False, dx)
-        if any(ctx.needs_input_grad[2 + 3 * i] for i in range(n)):
-            dw = ops.conv3d_k3_wgrad(x, draw, n * C)
+        need_w = [ctx.needs_input_grad[2 + 3 * i] for i in range(n)]
+        if any(need_w):
             planar = mods[0].NDIM == 2
-            for i in range(n):
-                if ctx.needs_input_grad[2 + 3 * i]:
-                    part = dw[i * C:(i + 1) * C]
-                    grads[3 * i] = (part[:, :, 1] if planar else part).reshape(mods[i].conv.weight.shape)
+            targets = [_direct(m.conv.weight) for m in mods]
+            if all(need_w) and all(t is not None for t in targets) and n <= 8:
+                ops.conv3d_k3_wgrad(x, draw, n * C, into=targets, planar2d=planar)      # every unit's .grad in place
+            else:
+                dw = ops.conv3d_k3_wgrad(x, draw, n * C, planar2d=planar)
+                for i in range(n):
+                    if need_w[i]:
+                        grads[3 * i] = dw[i * C:(i + 1) * C]
         return (dx, None, *grads)
 
 
@@ -206,7 +224,11 @@ class StridedStemFn(torch.autograd.Function):
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         draw, dgamma, dbeta = _bn_backward(_dense(dy), raw, scale, shift, mean, invstd, ctx.mod, ctx.n, ctx.training, need_g, need_b)
         dx = ops.conv2d_k3_strided_dgrad(draw, weight, x.shape[2:], ctx.stride) if need_x else None
-        dw = ops.conv2d_k3_strided_wgrad(x, draw, ctx.stride) if need_w else None
+        dw = None
+        if need_w:
+            tw = _direct(ctx.mod.conv.weight)
+            dw = ops.conv2d_k3_strided_wgrad(x, draw, ctx.stride, into=tw)
+            dw = None if tw is not None else dw
         return dx, dw, dgamma, dbeta, None
 
 

@@ -160,7 +160,7 @@ struct BnCoeffArgs {
   float* c3;
   float* dgamma;
   float* dbeta;
-  int nparts, training;
+  int nparts, training, accumulate;
   double n;
 };
 __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(BnCoeffArgs a) {
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(BnCoeffArgs a) {
   if (threadIdx.x != 0) return;
   const double mean = a.mean[c], invstd = a.invstd[c], sc = a.scale[c];
   const double sgxh = invstd * (sgx - mean * sg);          // sum of g * xhat
-  a.dgamma[c] = (float)sgxh;
-  a.dbeta[c] = (float)sg;
+  if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + (float)sgxh;
+  if (a.dbeta) a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + (float)sg;
   a.c1[c] = (float)sc;
   if (a.training) {
     // dx = a (g - mean(g) - xhat mean(g xhat)), a = gamma * invstd: linear in g and x per channel
@@ -382,18 +382,29 @@ __global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
       }
 }
 
-// dw[co][ci][tap] = sum over the workgroups' partials: one wave per output element, lanes stride over the partials
-__global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nparts,
-                                                                     int Cin, int Cout, int CinP, int CoutP) {
+// dw[co][ci][tap] (+)= sum over the workgroups' partials: one wave per output element, lanes stride over the partials.
+// The Cout rows may be split over up to 8 destination tensors (stacked sibling convolutions write each unit's weight
+// gradient in place); planar: the destination is a 2-D [.,.,3,3] weight, only the dz = 1 plane (taps 9..17) is kept.
+struct WgradDst {
+  float* p[8];
+  int n, rows_per_dst, accumulate, planar;
+};
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part, WgradDst dst, int nparts, int Cin,
+                                                                     int Cout, int CinP, int CoutP) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= Cout * Cin * 27) return;
   const int tap = i % 27, ci = (i / 27) % Cin, co = i / (27 * Cin);
+  if (dst.planar && (tap < 9 || tap >= 18)) return;
   const int64_t stride = (int64_t)CoutP * CinP * 27, off = ((int64_t)co * CinP + ci) * 27 + tap;
   float s = 0.f;
   for (int p = lane; p < nparts; p += 64) s += part[p * stride + off];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) dw[i] = s;
+  if (lane == 0) {
+    const int k = co / dst.rows_per_dst, r = co % dst.rows_per_dst;
+    float* d = dst.p[k] + (dst.planar ? ((int64_t)r * Cin + ci) * 9 + (tap - 9) : ((int64_t)r * Cin + ci) * 27 + tap);
+    *d = dst.accumulate ? *d + s : s;
+  }
 }
 
 // dw[co][ci] += sum_v g[co][v] * x[ci][v]   (1x1x1 conv).  A workgroup owns a 4 (co) x 12 (ci) block of dw and a slab of
@@ -716,9 +727,9 @@ extern "C" int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* sc
 extern "C" int ragmi_bn_act_bwd_coeffs(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride,
                                       const void* scale, const void* shift, int relu, const void* mean, const void* invstd, int training,
                                       int B, int C, int64_t DHW, void* workspace, void* c1, void* c2, void* c3, void* dgamma, void* dbeta,
-                                      void* stream) {
+                                      int accumulate, void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(dy && x && scale && shift && mean && invstd && workspace && c1 && c2 && c3 && dgamma && dbeta, RAGMI_EINVAL,
+  RAGMI_REQUIRE(dy && x && scale && shift && mean && invstd && workspace && c1 && c2 && c3, RAGMI_EINVAL,
                 "bn_act_bwd_coeffs: null pointer");
   RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act_bwd_coeffs: bad size");
   const unsigned gx = reduce_blocks(B, C, DHW);
@@ -727,7 +738,7 @@ extern "C" int ragmi_bn_act_bwd_coeffs(const void* dy, int64_t dy_bstride, int d
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(gx, C, B), dim3(256), 0, st, (const float*)dy, dy_bstride, dy_ch0, (const float*)x,
                      x_bstride, (const float*)scale, (const float*)shift, relu, DHW, (float*)workspace, nparts);
   BnCoeffArgs a{(const float*)workspace, (const float*)mean, (const float*)invstd, (const float*)scale, (float*)c1, (float*)c2, (float*)c3,
-                (float*)dgamma, (float*)dbeta, nparts, training ? 1 : 0, (double)B * (double)DHW};
+                (float*)dgamma, (float*)dbeta, nparts, training ? 1 : 0, accumulate ? 1 : 0, (double)B * (double)DHW};
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, st, a);
   return check_launch("bn_act_bwd_coeffs");
 }
@@ -787,11 +798,19 @@ extern "C" int64_t ragmi_conv3d_k3_wgrad_workspace_elems(int B, int Cin, int Cou
   return (int64_t)p.gx * (p.gz * p.cg * 4) * (p.gy * 4) * 27;
 }
 
-extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* dw,
-                                     void* workspace, int B, int Cin, int Cout, int D, int H, int W, void* stream) {
+extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const void* g, int64_t g_bstride, int g_ch0, void* const* dw_list,
+                                     int n_dw, int accumulate, int planar2d, void* workspace, int B, int Cin, int Cout, int D, int H,
+                                     int W, void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(x && g && dw && workspace, RAGMI_EINVAL, "conv3d_k3_wgrad: null pointer");
+  RAGMI_REQUIRE(x && g && dw_list && workspace, RAGMI_EINVAL, "conv3d_k3_wgrad: null pointer");
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, RAGMI_EINVAL, "conv3d_k3_wgrad: bad size");
+  RAGMI_REQUIRE(n_dw >= 1 && n_dw <= 8 && Cout % n_dw == 0, RAGMI_EINVAL, "conv3d_k3_wgrad: 1..8 destinations that split Cout evenly");
+  WgradDst dst{};
+  for (int k = 0; k < n_dw; ++k) {
+    RAGMI_REQUIRE(dw_list[k], RAGMI_EINVAL, "conv3d_k3_wgrad: null destination");
+    dst.p[k] = static_cast<float*>(dw_list[k]);
+  }
+  dst.n = n_dw; dst.rows_per_dst = Cout / n_dw; dst.accumulate = accumulate ? 1 : 0; dst.planar = planar2d ? 1 : 0;
   WgradPlan p;
   const int rc = wgrad_plan(B, Cin, Cout, D, H, W, p);
   if (rc != RAGMI_OK) return rc;
@@ -813,8 +832,8 @@ extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const voi
   }
 #undef RAGMI_WGRAD_LAUNCH
   const int total = Cout * Cin * 27;
-  hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, (const float*)workspace,
-                     (float*)dw, p.gx, Cin, Cout, p.gy * 4, p.gz * p.cg * 4);
+  hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, (const float*)workspace, dst,
+                     p.gx, Cin, Cout, p.gy * 4, p.gz * p.cg * 4);
   return check_launch("conv3d_k3_wgrad");
 }
 

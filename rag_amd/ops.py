@@ -420,17 +420,23 @@ def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool
     return out
 
 
-def bn_act_bwd_coeffs(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shift, relu: bool, mean, invstd, training: bool):
+def bn_act_bwd_coeffs(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shift, relu: bool, mean, invstd, training: bool,
+                      dgamma_into: Optional[torch.Tensor] = None, dbeta_into: Optional[torch.Tensor] = None):
     """Reduction half of the ReLU+BN adjoint: returns the [5, C] tensor (c1, c2, c3, dgamma, dbeta) with
-    dx = g*c1 + x*c2 + c3, g = dy * [x*scale+shift > 0] (ragmi_bn_act_bwd_coeffs)."""
-    _need_gpu(dy, x, scale, shift, mean, invstd)
+    dx = g*c1 + x*c2 + c3, g = dy * [x*scale+shift > 0] (ragmi_bn_act_bwd_coeffs).  `dgamma_into` / `dbeta_into`: accumulate the
+    parameter gradients straight into these tensors (a parameter's .grad) instead of rows 3 / 4."""
+    _need_gpu(dy, x, scale, shift, mean, invstd, dgamma_into, dbeta_into)
     B, C = x.shape[:2]
     lib = load_library()
     ws = torch.empty((lib.ragmi_bn_workspace_elems(B, C, _vol(x)),), device=x.device, dtype=torch.float32)
     out = torch.empty((5, C), device=x.device, dtype=torch.float32)
+    direct = dgamma_into is not None or dbeta_into is not None
+    if direct and (dgamma_into is None or dbeta_into is None):
+        raise ValueError("bn_act_bwd_coeffs: pass both dgamma_into and dbeta_into, or neither")
+    dg, db = (dgamma_into, dbeta_into) if direct else (out[3], out[4])
     check(lib.ragmi_bn_act_bwd_coeffs(dy.data_ptr(), _planes(dy), dy_ch0, x.data_ptr(), _planes(x), scale.data_ptr(), shift.data_ptr(),
                                       int(relu), mean.data_ptr(), invstd.data_ptr(), int(training), B, C, _vol(x), ws.data_ptr(),
-                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(),
+                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), dg.data_ptr(), db.data_ptr(), int(direct),
                                       _stream()), "bn_act_bwd_coeffs")
     return out
 
@@ -447,26 +453,39 @@ def bn_act_bwd_apply(dy: torch.Tensor, dy_ch0: int, x: torch.Tensor, scale, shif
     return dx
 
 
-def conv3d_k3_wgrad(x: torch.Tensor, g: torch.Tensor, cout: int, g_ch0: int = 0) -> torch.Tensor:
-    """dW[cout, Cin, 3, 3, 3] of a 3x3x3 / pad 1 conv from its input x and output gradient g."""
-    _need_gpu(x, g)
+def conv3d_k3_wgrad(x: torch.Tensor, g: torch.Tensor, cout: int, g_ch0: int = 0, into: Optional[Sequence[torch.Tensor]] = None,
+                    planar2d: bool = False):
+    """dW of a 3x3x3 / pad 1 conv from its input x and output gradient g.  Default: returns a fresh [cout, Cin, 3, 3, 3].
+    `into`: 1..8 tensors (each [cout/n, Cin, 3,3,3], or [.., 3,3] with planar2d) the gradient is ACCUMULATED into in place
+    (parameters' .grad, one per stacked sibling conv); returns None."""
+    _need_gpu(x, g, *(into or []))
     B, Cin, D, H, W = x.shape
     lib = load_library()
     n = lib.ragmi_conv3d_k3_wgrad_workspace_elems(B, Cin, cout, D, H, W)
     if n < 0:
         check(-2, "conv3d_k3_wgrad_workspace_elems")
     ws = torch.empty((n,), device=x.device, dtype=torch.float32)
-    dw = torch.empty((cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
-    check(lib.ragmi_conv3d_k3_wgrad(x.data_ptr(), _planes(x), g.data_ptr(), _planes(g), g_ch0, dw.data_ptr(), ws.data_ptr(), B, Cin, cout,
-                                    D, H, W, _stream()), "conv3d_k3_wgrad")
+    if into is None:
+        dw = torch.empty((cout, Cin, 3, 3) if planar2d else (cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
+        dsts, acc = [dw], 0
+    else:
+        want = (cout // len(into), Cin, 3, 3) if planar2d else (cout // len(into), Cin, 3, 3, 3)
+        if any(tuple(t.shape) != want or not t.is_contiguous() for t in into):
+            raise ValueError(f"conv3d_k3_wgrad: every destination must be a contiguous {want} tensor")
+        dw, dsts, acc = None, list(into), 1
+    arr = (ctypes.c_void_p * len(dsts))(*[t.data_ptr() for t in dsts])
+    check(lib.ragmi_conv3d_k3_wgrad(x.data_ptr(), _planes(x), g.data_ptr(), _planes(g), g_ch0, arr, len(dsts), acc, int(planar2d),
+                                    ws.data_ptr(), B, Cin, cout, D, H, W, _stream()), "conv3d_k3_wgrad")
     return dw
 
 
-def conv3d_k1_wgrad(x: torch.Tensor, g: torch.Tensor, cout: int, g_ch0: int = 0) -> torch.Tensor:
-    """dW[cout, Cin] of a 1x1x1 conv."""
-    _need_gpu(x, g)
+def conv3d_k1_wgrad(x: torch.Tensor, g: torch.Tensor, cout: int, g_ch0: int = 0, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW[cout, Cin] of a 1x1x1 conv; `into`: accumulate into this contiguous tensor of cout*Cin elements instead."""
+    _need_gpu(x, g, into)
     B, Cin = x.shape[:2]
-    dw = torch.zeros((cout, Cin), device=x.device, dtype=torch.float32)
+    if into is not None and (into.numel() != cout * Cin or not into.is_contiguous()):
+        raise ValueError("conv3d_k1_wgrad: destination must be contiguous with cout*Cin elements")
+    dw = into if into is not None else torch.zeros((cout, Cin), device=x.device, dtype=torch.float32)
     check(load_library().ragmi_conv3d_k1_wgrad(x.data_ptr(), _planes(x), g.data_ptr(), _planes(g), g_ch0, dw.data_ptr(), B, Cin, cout,
                                                _vol(x), _stream()), "conv3d_k1_wgrad")
     return dw
@@ -522,13 +541,15 @@ def conv2d_k3_strided_dgrad(g: torch.Tensor, weight: torch.Tensor, in_hw: Sequen
     return dx
 
 
-def conv2d_k3_strided_wgrad(x: torch.Tensor, g: torch.Tensor, stride: int) -> torch.Tensor:
-    """weight gradient [Cout,Cin,3,3] of the strided 2-D stem conv."""
-    _need_gpu(x, g)
+def conv2d_k3_strided_wgrad(x: torch.Tensor, g: torch.Tensor, stride: int, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """weight gradient [Cout,Cin,3,3] of the strided 2-D stem conv; `into`: accumulate into this tensor instead."""
+    _need_gpu(x, g, into)
     x, g = x.contiguous(), g.contiguous()
     B, Cin, H, W = x.shape
     Cout = g.shape[1]
-    dw = torch.zeros((Cout, Cin, 3, 3), device=x.device, dtype=torch.float32)
+    if into is not None and (tuple(into.shape) != (Cout, Cin, 3, 3) or not into.is_contiguous()):
+        raise ValueError("conv2d_k3_strided_wgrad: destination must be a contiguous [Cout, Cin, 3, 3] tensor")
+    dw = into if into is not None else torch.zeros((Cout, Cin, 3, 3), device=x.device, dtype=torch.float32)
     check(load_library().ragmi_conv2d_k3_strided_wgrad(x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, Cin, Cout, H, W, int(stride),
                                                        _stream()), "conv2d_k3_strided_wgrad")
     return dw

@@ -29,6 +29,7 @@ class GradBucket:
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p._ragmi_direct = True          # rag_amd.autograd accumulates into these views in place (no AccumulateGrad adds)
             off += p.numel()
 
     def zero(self) -> None:
