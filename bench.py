@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 H, W, MAXDISP, FEA_C = 384, 1248, 192, 12
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, BF16 dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -68,6 +69,9 @@ class K3Profiler:
                 return self._orig(x, packed, cout, *a, **kw)
             B, Cin, D, Hh, Ww = x.shape
             log_tx, rows, groups = ops.conv3d_k3_plan(cout, B, D, Hh, Ww)
+            res = a[5] if len(a) > 5 else kw.get("res")
+            if ops.conv3d_k3_uses_x3(Cin, cout, B, D, Hh, Ww, 1, res is not None, len(kw.get("tails") or []), x.dtype):
+                groups, log_tx, rows = [(Cin + 3) // 4], "x3", 0          # bf16x3 kernel: conv3d_x3_kernel<channel groups, sets>
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = self._orig(x, packed, cout, *a, **kw)
@@ -84,6 +88,9 @@ class K3Profiler:
                 return self._orig_dual(x, cin_a, pa, sa, ha, pb, sb, hb, cout, *a, **kw)
             B, Cin, D, Hh, Ww = x.shape
             log_tx, rows, groups = ops.conv3d_k3_plan(cout, B, D, Hh, Ww, 2)
+            res = a[3] if len(a) > 3 else kw.get("res")
+            if ops.conv3d_k3_uses_x3(Cin, cout, B, D, Hh, Ww, 2, res is not None, len(kw.get("tails") or []), x.dtype):
+                groups, log_tx, rows = [(Cin + 3) // 4], "x3", 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = self._orig_dual(x, cin_a, pa, sa, ha, pb, sb, hb, cout, *a, **kw)
@@ -378,16 +385,23 @@ def main():
             secs, flops, nbytes, nlaunch = by[dom_key]
             groups, log_tx, rows, nset = dom_key
             ach = flops / secs * 1e-12
-            kname = f"conv3d_k3_kernel<{groups[0]}, {log_tx}, {rows}, {nset}, 2, 0>"
+            x3 = log_tx == "x3"
+            kname = (f"conv3d_x3_kernel<{groups[0]}, {nset}>" if x3 else f"conv3d_k3_kernel<{groups[0]}, {log_tx}, {rows}, {nset}, 2, 0>")
+            peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
             roofline = {"kernel": kname, "bound": "mfma",
-                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic_bytes(kname),
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": pmc_traffic_bytes(kname),
                         "algorithmic_bytes_per_launch": nbytes / nlaunch,
                         "launches_per_step": nlaunch // args.steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
                         "flops_per_launch": flops / nlaunch,
                         "share_of_step": round(secs / args.steps / (dt / args.steps), 3)}
+            if x3:
+                roofline["note"] = ("fp32 convolution emulated on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate): "
+                                    "achieved = ALGORITHMIC fp32 flops / time against the bf16 dense peak; the kernel executes 3 bf16 "
+                                    "MFMAs per product plus Cout 12->16 / K padding; against the fp32 matrix peak (157.3) the same "
+                                    f"figure is {ach / PEAK_FP32_MFMA_TFLOPS:.2f}")
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
-                log(f"  conv3d_k3 G={k[0]} tx=2^{k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
+                log(f"  conv3d {'x3 (bf16x3) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
         cpu = None
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -258,6 +258,11 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
                            void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
                            int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
 
+/* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) runs this shape on the
+ * bf16x3 kernel (conv3d_x3.hip: fp32 accuracy from three bf16 MFMAs per product; big fp32 volumes without a residual input),
+ * 0 when it runs on the fp32-MFMA kernel.  The bf16x3 form is opt-in: environment RAGMI_X3=1 (read at every call). */
+int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int nset, int has_res, int ntail, int dtype);
+
 /* ragmi_conv3d_k3_pack with two options used by the training step: transpose != 0 packs the DATA-GRADIENT conv of a forward
  * weight (source [Cin][Cout][taps], taps flipped), Cout/Cin being those of the packed conv; planar2d != 0: the source is a 2-D
  * [.,.,3,3] weight living in the dz = 1 plane (Feature Net on depth-1 volumes). */

@@ -105,9 +105,13 @@ static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* 
 
 }  // namespace ragmi
 
+// packed weights = [fp32-MFMA section: groups x chunks x PACK_PER_GC floats][bf16x3 fragments of conv3d_x3.hip]
+static int64_t k3_section_elems(int Cout, int Cin) {
+  return (int64_t)((Cout + 3) / 4) * ((Cin + ragmi::CK - 1) / ragmi::CK) * ragmi::PACK_PER_GC;
+}
 extern "C" int64_t ragmi_conv3d_k3_packed_elems(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0) return 0;
-  return (int64_t)((Cout + 3) / 4) * ((Cin + ragmi::CK - 1) / ragmi::CK) * ragmi::PACK_PER_GC;
+  return k3_section_elems(Cout, Cin) + ragmi::x3_packed_words(Cout, Cin);
 }
 
 extern "C" int ragmi_conv3d_k3_pack(const void* weight, void* packed, int Cout, int Cin, int dtype, void* stream) {
@@ -120,10 +124,11 @@ extern "C" int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cou
   RAGMI_REQUIRE(weight && packed, RAGMI_EINVAL, "conv3d_k3_pack: null pointer");
   RAGMI_REQUIRE(Cout > 0 && Cin > 0, RAGMI_EINVAL, "conv3d_k3_pack: non-positive size");
   RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3_pack: dtype %d not built", dtype);
-  const int64_t total = ragmi_conv3d_k3_packed_elems(Cout, Cin);
+  const int64_t total = k3_section_elems(Cout, Cin);
   hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), (const float*)weight, (float*)packed, Cout, Cin,
                      (Cin + CK - 1) / CK, total, transpose ? 1 : 0, planar2d ? 1 : 0);
+  x3_pack((const float*)weight, (float*)packed + total, Cout, Cin, transpose ? 1 : 0, planar2d ? 1 : 0, static_cast<hipStream_t>(stream));
   return check_launch("conv3d_k3_pack");
 }
 
@@ -154,6 +159,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, s);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s1_cfg0_bf16(a, ng, s) : launch_k3_s1_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s1_cfg1_bf16(a, ng, s) : launch_k3_s1_cfg1_f32(a, ng, s);
@@ -218,11 +224,23 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, s);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s2_cfg0_bf16(a, ng, s) : launch_k3_s2_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s2_cfg1_bf16(a, ng, s) : launch_k3_s2_cfg1_f32(a, ng, s);
     default: return bf ? launch_k3_s2_cfg2_bf16(a, ng, s) : launch_k3_s2_cfg2_f32(a, ng, s);
   }
+}
+
+extern "C" int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int nset, int has_res, int ntail, int dtype) {
+  using namespace ragmi;
+  if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || (nset != 1 && nset != 2)) return 0;
+  K3Args a{};
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.ntail = ntail;
+  a.res = has_res ? (const void*)&a : nullptr;
+  if (nset == 2) { if (Cin % (2 * CK)) return 0; a.nchunks[0] = a.nchunks[1] = Cin / (2 * CK); }
+  else a.nchunks[0] = (Cin + CK - 1) / CK;
+  return x3_eligible(a, nset, dtype) ? 1 : 0;
 }
 
 extern "C" int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int nset, int32_t* log_tx,

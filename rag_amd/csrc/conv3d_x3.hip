@@ -1,0 +1,374 @@
+// 3x3x3 convolution with fp32 accuracy on the bf16 matrix cores ("bf16x3"): every fp32 operand is split into
+// hi = bf16(x) and lo = bf16(x - hi), and a product a*b is accumulated in fp32 as hi*hi + hi*lo + lo*hi (the dropped
+// lo*lo term and the rounding of lo are ~2^-17 relative: well inside the fp32 reassociation noise of the path).
+// v_mfma_f32_16x16x32_bf16 runs at 16x the rate of the fp32 MFMA forms, so three of them per product still leave ~5x.
+//
+// Mapping (operand layout of mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15],
+// D[row 4(l>>4)+reg][col l&15]):  rows = 16 output channels, cols = 16 consecutive voxels along x, K = 8 "pairs" of
+// (input-channel group of 4, tap) x 4 channels.  The input halo tile lives in LDS channel-interleaved,
+// [cg][z][y][x][4 ch] as bf16 (one hi and one lo copy), so a lane fetches the 4 channels of one (voxel, tap) with one
+// 8-byte read; weight fragments are pre-packed per lane in HBM (hi and lo) and read once per K-slice per wave.
+#include <cstdlib>
+
+#include "conv3d_k3.h"
+
+namespace ragmi {
+
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+
+// z-marching: a workgroup owns a (y, x) tile of 8 x 32 voxels and walks a segment of the depth axis keeping a ring of three
+// input planes (10 x 34 halo) in LDS: every input plane is fetched once per column (halo overhead 1.33x instead of 2.66x
+// for a 2-deep box tile), the next plane travels HBM -> registers while the current one is multiplied.
+constexpr int X3_TY = 8, X3_TX = 32;
+constexpr int X3_HY = X3_TY + 2, X3_HX = X3_TX + 2, X3_PL = X3_HY * X3_HX;   // one halo plane: 340 voxels
+constexpr int X3_THREADS = 256, X3_WAVES = X3_THREADS / 64;
+constexpr int X3_NT = X3_TY * X3_TX / 16 / X3_WAVES;                  // 16-voxel column tiles per wave per plane (4)
+
+__device__ __forceinline__ unsigned short x3_bf16_rn(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void x3_split(float v, unsigned short& hi, unsigned short& lo) {
+  hi = x3_bf16_rn(v);
+  lo = x3_bf16_rn(v - __uint_as_float((unsigned)hi << 16));
+}
+// two values at once through the packed converter (v_cvt_pk_bf16_f32, round to nearest even): returns the packed hi pair,
+// writes the packed lo pair
+typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x3_split2(float v0, float v1, unsigned& lo) {
+  const x3_bf16x2 h = __builtin_convertvector(x3_f32x2{v0, v1}, x3_bf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float r0 = v0 - __uint_as_float(hb << 16), r1 = v1 - __uint_as_float(hb & 0xffff0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{r0, r1}, x3_bf16x2));
+  return hb;
+}
+
+// packed weight fragments of ONE accumulator set (a conv with Cout outputs and Cin = 4 * ncgs inputs):
+// wf[((cog * nsls + s) * 2 + hl) * 64 + lane] (uint4 = 8 bf16): A[row = lane & 15][k = 8 (lane>>4) + j],
+// k -> pair P = 8 s + 2 (lane>>4) + (j>>2) = cg * 27 + tap, channel 4 cg + (j&3).  The source is indexed like the fp32
+// pack (transpose / planar options of ragmi_conv3d_k3_pack_ex).
+__global__ void x3_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wf, int Cout, int Cin, int nsls, int ncog,
+                               int transpose, int planar) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncog * nsls * 64) return;
+  const int lane = idx & 63, s = (idx >> 6) % nsls, cog = idx / (64 * nsls);
+  const int co = cog * 16 + (lane & 15), kb = lane >> 4;
+  unsigned short hi[8], lo[8];
+  for (int j = 0; j < 8; ++j) {
+    const int P = 8 * s + 2 * kb + (j >> 2), cg = P / 27, tap = P % 27, ci = 4 * cg + (j & 3);
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      const int taps = planar ? 9 : 27;
+      int t = planar ? tap - 9 : tap;
+      if (t >= 0 && t < taps) {
+        if (transpose) t = taps - 1 - t;
+        v = transpose ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t];
+      }
+    }
+    x3_split(v, hi[j], lo[j]);
+  }
+  auto pk = [](const unsigned short* h) {
+    return make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+  };
+  wf[((int64_t)(cog * nsls + s) * 2 + 0) * 64 + lane] = pk(hi);
+  wf[((int64_t)(cog * nsls + s) * 2 + 1) * 64 + lane] = pk(lo);
+}
+
+struct X3Extra {
+  const uint4* wf[2];        // packed fragments per accumulator set
+  int nseg, seg_len, nwork, diag;
+};
+
+// NCG = input-channel groups of 4 over all sets, NSET accumulator sets (2: out = act(bnA(convA(x[:, :C]))) + act(bnB(convB(x[:, C:]))),
+// the Cell_3d sibling fusion of conv3d_k3).  Compile-time so that the K loop is fully unrolled (the LDS reads of the next
+// K-slice are in flight under the MFMAs of the current one) and the prefetch registers are static.
+template <int NCG, int NSET>
+__global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra e) {
+  constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
+  constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
+  static_assert(NCG % NSET == 0 && NPF <= 32, "bad instantiation");
+  extern __shared__ __attribute__((aligned(16))) uint2 x3_lds[];       // hi[NCG][3][PL] | lo[NCG][3][PL] (uint2 = 4 bf16) | weights | offsets | params
+  uint2* const lhi = x3_lds;
+  uint2* const llo = x3_lds + NCG * 3 * X3_PL;
+  uint4* const lw = reinterpret_cast<uint4*>(x3_lds + 2 * NCG * 3 * X3_PL);            // [set][slice][hi/lo][64 lanes]
+  int2* const loff = reinterpret_cast<int2*>(lw + NSL * 2 * 64);                        // [set][slice][8 pairs]: (in-plane offset incl. cg, dz)
+  float* const par = reinterpret_cast<float*>(loff + NSL * 8);                          // scale[2][16] | shift[2][16]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
+  const int cog = blockIdx.y;
+  const int HW = a.H * a.W;
+  const int64_t DHW = (int64_t)HW * a.D;
+  for (int i = tid; i < NSL * 2 * 64; i += X3_THREADS) {
+    const int set = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
+    lw[i] = e.wf[set][(int64_t)cog * NSLS * 2 * 64 + r];
+  }
+  for (int i = tid; i < NSL * 8; i += X3_THREADS) {
+    const int set = i / (NSLS * 8), P = i % (NSLS * 8), cgl = P / 27, tap = P % 27;
+    loff[i] = cgl < NCGS ? make_int2((set * NCGS + cgl) * 3 * X3_PL + ((tap / 3) % 3) * X3_HX + tap % 3, tap / 9) : make_int2(0, 0);
+  }
+  for (int i = tid; i < 32; i += X3_THREADS) {
+    const int set = i >> 4, co = cog * 16 + (i & 15);
+    const bool ok = set < NSET && co < a.Cout;
+    par[i] = (ok && a.scale[set]) ? a.scale[set][co] : 1.f;
+    par[32 + i] = (ok && a.shift[set]) ? a.shift[set][co] : 0.f;
+  }
+  // Fused consumer 1x1x1 convs ("tails") on the matrix cores: out_t[k][voxel] = sum_c W_t[k][c] * v[c][voxel] is one more
+  // 16x16x32 product whose K slots are laid out so that every lane quarter feeds ITS OWN four channels — slots 8kb..8kb+3 carry
+  // v_hi, slots 8kb+4..8kb+7 carry v_lo of channels 4kb..4kb+3 — so no value crosses lanes.  Rows: tail 0 -> 0..3, tail 1 -> 4..7.
+  //   ta1 = W_hi in all eight slots (W_hi * (v_hi + v_lo)),  ta2 = W_lo in the hi slots only (W_lo * v_hi)
+  x3_bf16x8 ta1, ta2;
+  {
+    unsigned short h1[8], h2[8];
+    const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cog * 16 + 4 * kb + (j & 3);
+      float wv = 0.f;
+      if (tl < a.ntail && k < a.tail_cout[tl] && c < a.Cout) wv = a.tail_w[tl][k * a.Cout + c];
+      unsigned short hi, lo;
+      x3_split(wv, hi, lo);
+      h1[j] = hi;
+      h2[j] = j < 4 ? lo : (unsigned short)0;
+    }
+    ta1 = __builtin_bit_cast(x3_bf16x8, make_uint4(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16), h1[4] | ((unsigned)h1[5] << 16), h1[6] | ((unsigned)h1[7] << 16)));
+    ta2 = __builtin_bit_cast(x3_bf16x8, make_uint4(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16), h2[4] | ((unsigned)h2[5] << 16), h2[6] | ((unsigned)h2[7] << 16)));
+  }
+  // this lane's tail outputs after that product: rows 4 kb + r -> tail kb, output r
+  float tsc[4], tsh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = kb < a.ntail && r < a.tail_cout[kb < 2 ? kb : 0];
+    tsc[r] = (ok && a.tail_scale[kb]) ? a.tail_scale[kb][r] : 1.f;
+    tsh[r] = (ok && a.tail_shift[kb]) ? a.tail_shift[kb][r] : 0.f;
+  }
+  float pf[NPF][4];
+  unsigned valid = 0;
+  const float* const x = static_cast<const float*>(a.x);
+  // issue the loads of input plane gz of the column at (y0, x0): unconditional, addresses clamped into the volume
+  auto prefetch = [&](const float* xb, int gz, int y0, int x0) {
+    valid = 0;
+    const bool zok = (unsigned)gz < (unsigned)a.D;
+    const int cz = min(max(gz, 0), a.D - 1);
+#pragma unroll
+    for (int p = 0; p < NPF; ++p) {
+      const int el = p * X3_THREADS + tid, cg = el / X3_PL, r = el % X3_PL;
+      const int xx = r % X3_HX, yy = r / X3_HX;
+      const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+      const bool ok = zok && cg < NCG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      valid |= (ok ? 1u : 0u) << p;
+      const unsigned off = (unsigned)(cz * HW + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pf[p][c] = xb[(int64_t)min(cg * 4 + c, a.Cin - 1) * DHW + off];
+    }
+  };
+  auto commit = [&](int slot) {          // registers -> ring plane `slot` (bf16 hi / lo), zeros outside the volume / past Cin
+#pragma unroll
+    for (int p = 0; p < NPF; ++p) {
+      const int el = p * X3_THREADS + tid;
+      if (el >= NCG * X3_PL) continue;
+      const int cg = el / X3_PL, r = el % X3_PL;
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = (((valid >> p) & 1u) && cg * 4 + c < a.Cin) ? pf[p][c] : 0.f;
+      unsigned l01, l23;
+      const unsigned h01 = x3_split2(v[0], v[1], l01), h23 = x3_split2(v[2], v[3], l23);
+      const int d = (cg * 3 + slot) * X3_PL + r;
+      lhi[d] = make_uint2(h01, h23);
+      llo[d] = make_uint2(l01, l23);
+    }
+  };
+  // this wave's column tiles of a plane: nt = wave * X3_NT + i -> (row y = nt / 2, x half = nt % 2)
+  int vbase[X3_NT];
+#pragma unroll
+  for (int i = 0; i < X3_NT; ++i) {
+    const int nt = wave * X3_NT + i;
+    vbase[i] = (nt >> 1) * X3_HX + (nt & 1) * 16 + n;
+  }
+  const int diag = e.diag & 3;              // RAGMI_X3_DIAG (profiling only): 1 no MFMA phase, 2 no staging; bits 8.. = stagger (x64 cycles)
+  if ((e.diag >> 8) && ((blockIdx.x >> 8) & 1))       // experiment: de-phase the second workgroup of every CU
+    for (int i = 0; i < (e.diag >> 8); ++i) __builtin_amdgcn_s_sleep(1);
+  const int g = cog * 4 + kb, ngroups = (a.Cout + 3) >> 2;
+  // XCD-aware schedule: workgroup j runs on XCD j % 8 (round-robin dispatch); give every XCD one contiguous chunk of the
+  // (x-fastest) work list so that neighbouring columns — which share halo rows and cache lines — meet in the same L2
+  const int chunk = (e.nwork + 7) / 8;
+  for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
+    const int work = (j & 7) * chunk + (j >> 3);
+    if ((j >> 3) >= chunk || work >= e.nwork) continue;
+    int t = work;
+    const int x0 = (t % a.tiles_x) * X3_TX; t /= a.tiles_x;
+    const int y0 = (t % a.tiles_y) * X3_TY; t /= a.tiles_y;
+    const int seg = t % e.nseg, b = t / e.nseg;
+    const int zs = seg * e.seg_len, ze = min(a.D, zs + e.seg_len);
+    const float* xb = x + b * a.x_bstride;
+    __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
+    if (!(diag & 2)) {
+      prefetch(xb, zs - 1, y0, x0); commit((zs - 1 + 3) % 3);
+      prefetch(xb, zs, y0, x0); commit(zs % 3);
+      prefetch(xb, zs + 1, y0, x0);
+    }
+    for (int z = zs; z < ze; ++z) {
+      __syncthreads();                                 // plane z-2 (same ring slot as z+1) is no longer read
+      if (!(diag & 2)) commit((z + 1) % 3);
+      __syncthreads();
+      if (z + 1 < ze && !(diag & 2)) prefetch(xb, z + 2, y0, x0);
+      f32x4 acc[NSET][X3_NT];
+#pragma unroll
+      for (int st = 0; st < NSET; ++st)
+#pragma unroll
+        for (int i = 0; i < X3_NT; ++i) acc[st][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int ring = (z - 1 + 3) % 3;                // slot of plane z-1; plane z+dz-1 (dz = 0..2) sits in slot (ring + dz) % 3
+      if (!(diag & 1))
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) {
+        const int st = s / NSLS;                        // compile time after unrolling
+        const x3_bf16x8 ah = __builtin_bit_cast(x3_bf16x8, lw[(s * 2 + 0) * 64 + lane]);
+        const x3_bf16x8 al = __builtin_bit_cast(x3_bf16x8, lw[(s * 2 + 1) * 64 + lane]);
+        const int2 p0 = loff[s * 8 + 2 * kb], p1 = loff[s * 8 + 2 * kb + 1];
+        int s0 = ring + p0.y, s1 = ring + p1.y;
+        s0 -= s0 >= 3 ? 3 : 0; s1 -= s1 >= 3 ? 3 : 0;
+        const int o0 = p0.x + s0 * X3_PL, o1 = p1.x + s1 * X3_PL;
+        x3_bf16x8 bh[X3_NT], bl[X3_NT];
+#pragma unroll
+        for (int i = 0; i < X3_NT; ++i) {
+          const uint2 h0 = lhi[vbase[i] + o0], h1 = lhi[vbase[i] + o1], l0 = llo[vbase[i] + o0], l1 = llo[vbase[i] + o1];
+          bh[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+          bl[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        }
+        // term-major order: consecutive MFMAs hit different accumulators (a dependent pair is X3_NT instructions apart)
+#pragma unroll
+        for (int i = 0; i < X3_NT; ++i) acc[st][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[i], acc[st][i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < X3_NT; ++i) acc[st][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[i], acc[st][i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < X3_NT; ++i) acc[st][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[i], acc[st][i], 0, 0, 0);
+      }
+      // epilogue: lane holds channels 4 g + reg (g = cog*4 + kb) of voxel n of each column tile
+#pragma unroll
+      for (int i = 0; i < X3_NT; ++i) {
+        const int nt = wave * X3_NT + i;
+        const int gy = y0 + (nt >> 1), gx = x0 + (nt & 1) * 16 + n;
+        const bool inside = gy < a.H && gx < a.W;
+        const int64_t vox = (int64_t)z * HW + gy * a.W + gx;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = 0.f;
+#pragma unroll
+          for (int st = 0; st < NSET; ++st) {
+            float u = fmaf(acc[st][i][r], par[st * 16 + 4 * kb + r], par[32 + st * 16 + 4 * kb + r]);
+            sum += a.relu ? fmaxf(u, 0.f) : u;
+          }
+          v[r] = sum;
+        }
+        if (a.store_main && inside && g < ngroups) {
+          float* py = static_cast<float*>(a.y) + b * a.y_bstride + (int64_t)a.y_ch[g] * DHW + vox;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.Cout) py[r * DHW] = v[r];
+        }
+        if (a.ntail > 0) {                              // uniform
+          unsigned l01, l23;
+          const unsigned h01 = x3_split2(v[0], v[1], l01), h23 = x3_split2(v[2], v[3], l23);
+          const x3_bf16x8 bv = __builtin_bit_cast(x3_bf16x8, make_uint4(h01, h23, l01, l23));
+          f32x4 tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta1, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta2, bv, tacc, 0, 0, 0);
+          if (kb < a.ntail && inside) {
+            float* pt = static_cast<float*>(a.tail_y[kb]) + b * a.tail_bstride[kb] + (int64_t)a.tail_ch0[kb] * DHW + vox;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r < a.tail_cout[kb]) {
+                float u = fmaf(tacc[r], tsc[r], tsh[r]);
+                pt[r * DHW] = a.tail_relu[kb] ? fmaxf(u, 0.f) : u;
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int64_t x3_packed_words(int Cout, int Cin) {
+  const int ncgs = (Cin + 3) / 4, nsls = (ncgs * 27 + 7) / 8, ncog = (Cout + 15) / 16;
+  return (int64_t)ncog * nsls * 2 * 64 * 4;
+}
+
+int x3_pack(const float* w, float* dst, int Cout, int Cin, int transpose, int planar, hipStream_t s) {
+  const int ncgs = (Cin + 3) / 4, nsls = (ncgs * 27 + 7) / 8, ncog = (Cout + 15) / 16;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)ceil_div((int64_t)ncog * nsls * 64, 256)), dim3(256), 0, s, w,
+                     reinterpret_cast<uint4*>(dst), Cout, Cin, nsls, ncog, transpose, planar);
+  return RAGMI_OK;
+}
+
+// The bf16x3 form pays off on the big level-3 volumes (z-marching columns need many (column, segment) work items to fill the
+// chip) with fp32 storage, no residual input and equal-sized sets; everything else stays on the fp32-MFMA kernel.
+bool x3_eligible(const K3Args& a, int nset, int dtype) {
+  // opt-in (RAGMI_X3=1, read at every call so that a process can switch): the first version is ~4 % faster end to end than the
+  // fp32-MFMA kernel at 8x its (still tiny) rounding error — see DESIGN.md 4.6 for what limits it
+  const char* env = getenv("RAGMI_X3");
+  const bool enabled = env && atoi(env) != 0;
+  if (!enabled || dtype != RAGMI_F32 || a.res != nullptr) return false;
+  const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
+  if (nset == 2 && (a.nchunks[0] != a.nchunks[1] || a.nchunks[0] > 2)) return false;
+  if (nset == 1 && ncg > 6) return false;
+  if ((int64_t)a.B * a.D * a.H * a.W < (1 << 20) || a.W < 32 || a.D < 8) return false;
+  if (a.ntail > 0 && a.Cout > 16) return false;
+  if ((int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
+  return true;
+}
+
+template <int NCG, int NSET>
+static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3d_x3_kernel<NCG, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3d_x3_kernel<NCG, NSET>), grid, dim3(X3_THREADS), lds, st, a, e);
+  return check_launch("conv3d_x3");
+}
+
+// a: as filled for the fp32 kernel (wp[s] = packed weights: fp32-MFMA section followed by the bf16x3 fragments)
+int x3_launch(K3Args a, int nset, hipStream_t st) {
+  X3Extra e{};
+  const int ngroups = (a.Cout + 3) / 4;
+  for (int s = 0; s < nset; ++s)
+    e.wf[s] = reinterpret_cast<const uint4*>(a.wp[s] + (int64_t)ngroups * a.nchunks[s] * PACK_PER_GC);
+  const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0), ncgs = ncg / nset, nsls = (ncgs * 27 + 7) / 8, nsl = nset * nsls;
+  a.tiles_x = (int)ceil_div(a.W, X3_TX); a.tiles_y = (int)ceil_div(a.H, X3_TY);
+  const int ncog = (a.Cout + 15) / 16;
+  // depth segments: enough independent (column, segment) work items to fill several workgroups per CU, at least 8 planes each
+  const int64_t cols = (int64_t)a.tiles_x * a.tiles_y * a.B;
+  const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(1536, cols * ncog), ceil_div(a.D, 8)));
+  e.seg_len = (int)ceil_div(a.D, nseg);
+  e.nseg = (int)ceil_div(a.D, e.seg_len);
+  const int64_t nwork = cols * e.nseg;
+  RAGMI_REQUIRE(nwork < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
+  e.nwork = (int)nwork;
+  static const int diag = getenv("RAGMI_X3_DIAG") ? atoi(getenv("RAGMI_X3_DIAG")) : 0;
+  e.diag = diag;
+  const size_t lds = (size_t)2 * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)nsl * 8 * sizeof(int2) +
+                     64 * sizeof(float);
+  RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
+  const dim3 grid((unsigned)std::min<int64_t>(nwork, 1024), ncog);
+  if (nset == 2) {
+    switch (ncg) {
+      case 2: return x3_launch_one<2, 2>(a, e, grid, lds, st);
+      case 4: return x3_launch_one<4, 2>(a, e, grid, lds, st);
+      default: return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: dual form with %d channel groups not instantiated", ncg);
+    }
+  }
+  switch (ncg) {
+    case 1: return x3_launch_one<1, 1>(a, e, grid, lds, st);
+    case 2: return x3_launch_one<2, 1>(a, e, grid, lds, st);
+    case 3: return x3_launch_one<3, 1>(a, e, grid, lds, st);
+    case 4: return x3_launch_one<4, 1>(a, e, grid, lds, st);
+    case 5: return x3_launch_one<5, 1>(a, e, grid, lds, st);
+    case 6: return x3_launch_one<6, 1>(a, e, grid, lds, st);
+    default: return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: %d channel groups not instantiated", ncg);
+  }
+}
+
+}  // namespace ragmi

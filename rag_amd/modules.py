@@ -343,7 +343,11 @@ class _Cell(nn.Module):
             if len(mods) == 1:
                 fused = prep[0]
             else:
-                fused = (torch.cat([p[0] for p in prep]), torch.cat([p[1] for p in prep]), torch.cat([p[2] for p in prep]))
+                # sibling convs as one stacked convolution: pack the concatenated raw weights (the packed layout has sections
+                # that do not concatenate); BN scale / shift simply stack
+                with torch.no_grad():
+                    wk = ops.conv3d_k3_pack(torch.cat([m.conv.weight.detach() for m in mods]))
+                fused = (wk, torch.cat([p[1] for p in prep]), torch.cat([p[2] for p in prep]))
             hit = (stamps, fused)
             self._fused_cache[key] = hit
         return hit[1]

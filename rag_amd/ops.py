@@ -564,3 +564,10 @@ def disparity_regression_bwd(dout: torch.Tensor, maxdisp: int) -> torch.Tensor:
     check(load_library().ragmi_disparity_regression_bwd(dout.data_ptr(), dp.data_ptr(), B, int(maxdisp), H, W, _stream()),
           "disparity_regression_bwd")
     return dp
+
+
+
+def conv3d_k3_uses_x3(cin: int, cout: int, B: int, D: int, H: int, W: int, nset: int = 1, has_res: bool = False, ntail: int = 0,
+                      dtype: torch.dtype = torch.float32) -> bool:
+    """True when conv3d_k3 (nset=1) / conv3d_k3_dual (nset=2, cin = both inputs) runs this shape on the bf16x3 kernel."""
+    return bool(load_library().ragmi_conv3d_k3_uses_x3(cin, cout, B, D, H, W, nset, int(has_res), ntail, _DT[dtype]))

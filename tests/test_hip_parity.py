@@ -232,7 +232,7 @@ def test_conv3d_linearity_full_size(ra):
         ra.ops.conv3d_k3(x, packed, 12, None, None, False, o)
         outs.append(o)
     err = (outs[2] - (2.5 * outs[0] + outs[1])).abs().max().item()
-    assert err < 1e-4, err
+    assert err < 3e-4, err      # level-3 volumes run on the bf16x3 kernel: ~5e-6 relative per output (fp32 MFMA: ~6e-7)
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(12, 4, (2, 4, 6, 8)), (48, 24, (1, 4, 8, 26)), (24, 12, (1, 3, 5, 7)),
@@ -600,3 +600,52 @@ def test_costvol_stem_tails_and_bf16(ra):
     outb = ra.ops.costvol_stem(gpu(Lb), gpu(Rb), maxdisp, var, 12, None, None, True)
     assert outb.dtype == torch.bfloat16
     np.testing.assert_allclose(outb.float().cpu().numpy(), refb.numpy(), rtol=1e-2, atol=1e-2)
+
+
+# --------------------------------------------------------------------------- opt-in bf16x3 convolution (conv3d_x3.hip, RAGMI_X3=1)
+@pytest.fixture
+def x3_on():
+    import os
+    old = os.environ.get("RAGMI_X3")
+    os.environ["RAGMI_X3"] = "1"
+    yield
+    if old is None:
+        del os.environ["RAGMI_X3"]
+    else:
+        os.environ["RAGMI_X3"] = old
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(12, 12, (1, 16, 40, 70)), (4, 12, (2, 9, 33, 65)), (24, 12, (1, 8, 17, 250)), (3, 5, (1, 9, 30, 45)),
+                                            (8, 24, (1, 10, 24, 64)), (16, 48, (1, 8, 16, 96))])
+def test_x3_conv_vs_oracle(ra, x3_on, cin, cout, shape):
+    """fp32 accuracy from three bf16 MFMAs per product: same entry point, shapes big enough to take the bf16x3 kernel."""
+    B, D, H, W = shape
+    vox = B * D * H * W
+    scale_up = max(1, -(-(1 << 20) // vox))           # the dispatcher wants >= 2^20 voxels: tile the batch
+    x = torch.randn((B, cin, D, H, W), generator=gen(121)).repeat(scale_up, 1, 1, 1, 1)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen(122)) * 0.1
+    sc, sh = torch.rand(cout, generator=gen(123)) + 0.5, torch.randn(cout, generator=gen(124)) * 0.1
+    assert ra.ops.conv3d_k3_uses_x3(cin, cout, x.shape[0], D, H, W)
+    out = torch.empty((x.shape[0], cout, D, H, W), device=DEV)
+    ra.ops.conv3d_k3(gpu(x), ra.ops.conv3d_k3_pack(gpu(w)), cout, gpu(sc), gpu(sh), True, out)
+    ref = F.relu(F.conv3d(x[:B], w, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    np.testing.assert_allclose(out[:B].cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+    assert torch.equal(out[:B], out[-B:])
+
+
+def test_x3_dual_tails_and_headline_epe(ra, x3_on):
+    """The level-3 launches of the headline forward (stem3d1 with fused tails and no main store, dual cells) on the bf16x3
+    kernel: EPE vs the CPU oracle stays within the gate (measured 1.2e-4 px; fp32-MFMA path 1.5e-5 px)."""
+    rows = O.ALL_CONV
+    sd = O.random_matching_state_dict(rows, seed=0)
+    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=192)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    lf, rf = torch.randn((1, 12, 128, 416), generator=gen(131)), torch.randn((1, 12, 128, 416), generator=gen(132))
+    assert ra.ops.conv3d_k3_uses_x3(8, 12, 1, 64, 128, 416, nset=2, ntail=2)
+    with torch.no_grad():
+        disp = net(gpu(lf), gpu(rf)).cpu()
+    torch.set_num_threads(16)
+    ref = O.matching_net_forward(lf, rf, sd, rows, 192)
+    epe = O.epe(disp, ref)
+    assert epe <= EPE_GATE, epe
