@@ -125,6 +125,23 @@ def pmc_traffic_bytes(kernel_name: str):
         return None
 
 
+def try_capture(fn):
+    """Capture fn() into a hipGraph; (graph, result) or (None, None) if the capture is refused.  Thread-local error mode:
+    other threads of the process (RCCL's watchdog polls events) must not invalidate the capture.  A failed capture
+    leaves the bench on eager launches instead of killing the run."""
+    graph = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            out = fn()
+        graph.replay()
+        torch.cuda.synchronize()
+        return graph, out
+    except Exception as exc:  # noqa: BLE001
+        log(f"bench: hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
+        torch.cuda.synchronize()
+        return None, None
+
+
 def shard_range(n_items: int, world: int, rank: int):
     """Contiguous [lo, hi) slice of `n_items` independent stereo pairs owned by `rank` (GPU g gets pairs
     [g*B/N, (g+1)*B/N)); sizes differ by at most one."""
@@ -180,11 +197,8 @@ def end_to_end(device, steps, seed=0, use_graph=True):
         torch.cuda.synchronize()
         graph = None
         if use_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                net(left, right, 0, net.arch_init)
-            graph.replay()
-            torch.cuda.synchronize()
+            graph, _ = try_capture(lambda: net(left, right, 0, net.arch_init))
+            use_graph = graph is not None
         t0 = time.perf_counter()
         for _ in range(steps):
             if graph is not None:
@@ -230,7 +244,13 @@ def train_bench(args, device, dist, rank, n_gpus):
     right = torch.randn((B, 3, TRAIN_H, TRAIN_W), generator=g).to(device)
     gt = (torch.rand((B, TRAIN_H, TRAIN_W), generator=g) * 200).to(device)
     losses = []
-    graphed = GraphedTrainStep(net, opt, bucket, left, right, gt, clip=5.0, dist=dist) if args.graph else None
+    graphed = None
+    if args.graph:
+        try:
+            graphed = GraphedTrainStep(net, opt, bucket, left, right, gt, clip=5.0, dist=dist)
+        except Exception as exc:  # noqa: BLE001
+            log(f"bench: hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); eager launches")
+            torch.cuda.synchronize()
 
     def step():
         if graphed is not None:
@@ -350,11 +370,9 @@ def main():
 
     graph = None
     if args.graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = step()
-        graph.replay()
-        torch.cuda.synchronize()
+        graph, captured = try_capture(step)
+        if graph is not None:
+            out = captured
 
     holder = {}
 

@@ -113,7 +113,7 @@ class GraphedTrainStep:
                 exchange_and_update(optimizer, bucket, clip=clip, dist=dist)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not trip it
             self.loss = forward_backward(net, bucket, self.left, self.right, self.gt, **kw)
 
     def __call__(self, left=None, right=None, gt=None):
