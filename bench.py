@@ -113,10 +113,10 @@ class K3Profiler:
 
 
 def pmc_traffic_bytes(kernel_name: str):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (profiles/r01g_pmc_summary.json:
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (profiles/r01j_pmc_summary.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same bench command).  gfx950 correction per
     MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B -> doubled; WRITE_SIZE is exact.  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01g_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r01j_pmc_summary.json")
     try:
         with open(path) as f:
             rec = json.load(f).get(kernel_name)
@@ -437,7 +437,9 @@ def main():
             "value": round(n_gpus * B * args.steps / dt, 3), "unit": "disparity maps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate", "data": "synthetic",
+            "dtype": ("f32 (level-3 3x3x3 convolutions: fp32 operands split into bf16 hi+lo on the bf16 matrix cores, fp32 accumulate)"
+                      if (args.dtype == "f32" and os.environ.get("RAGMI_X3", "1") != "0") else
+                      "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate"), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
                        "global_batch": n_gpus * B, "sharding": "batch split, no collective",

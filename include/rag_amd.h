@@ -260,7 +260,7 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
 
 /* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) runs this shape on the
  * bf16x3 kernel (conv3d_x3.hip: fp32 accuracy from three bf16 MFMAs per product; big fp32 volumes without a residual input),
- * 0 when it runs on the fp32-MFMA kernel.  The bf16x3 form is opt-in: environment RAGMI_X3=1 (read at every call). */
+ * 0 when it runs on the fp32-MFMA kernel.  Environment RAGMI_X3=0 (read at every call) disables the bf16x3 form. */
 int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int nset, int has_res, int ntail, int dtype);
 
 /* ragmi_conv3d_k3_pack with two options used by the training step: transpose != 0 packs the DATA-GRADIENT conv of a forward

@@ -185,9 +185,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
     const int nt = wave * X3_NT + i;
     vbase[i] = (nt >> 1) * X3_HX + (nt & 1) * 16 + n;
   }
-  const int diag = e.diag & 3;              // RAGMI_X3_DIAG (profiling only): 1 no MFMA phase, 2 no staging; bits 8.. = stagger (x64 cycles)
-  if ((e.diag >> 8) && ((blockIdx.x >> 8) & 1))       // experiment: de-phase the second workgroup of every CU
-    for (int i = 0; i < (e.diag >> 8); ++i) __builtin_amdgcn_s_sleep(1);
   const int g = cog * 4 + kb, ngroups = (a.Cout + 3) >> 2;
   // XCD-aware schedule: workgroup j runs on XCD j % 8 (round-robin dispatch); give every XCD one contiguous chunk of the
   // (x-fastest) work list so that neighbouring columns — which share halo rows and cache lines — meet in the same L2
@@ -202,23 +199,23 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
     const int zs = seg * e.seg_len, ze = min(a.D, zs + e.seg_len);
     const float* xb = x + b * a.x_bstride;
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
-    if (!(diag & 2)) {
-      prefetch(xb, zs - 1, y0, x0); commit((zs - 1 + 3) % 3);
-      prefetch(xb, zs, y0, x0); commit(zs % 3);
-      prefetch(xb, zs + 1, y0, x0);
-    }
+    prefetch(xb, zs - 1, y0, x0); commit((zs - 1 + 3) % 3);
+    prefetch(xb, zs, y0, x0); commit(zs % 3);
+    prefetch(xb, zs + 1, y0, x0);
     for (int z = zs; z < ze; ++z) {
       __syncthreads();                                 // plane z-2 (same ring slot as z+1) is no longer read
-      if (!(diag & 2)) commit((z + 1) % 3);
+      commit((z + 1) % 3);
       __syncthreads();
-      if (z + 1 < ze && !(diag & 2)) prefetch(xb, z + 2, y0, x0);
+      // unconditional (also past the segment end: the addresses are clamped): the loads stay straight-line code ahead of the
+      // MFMA block, a branch here made the compiler drain them (s_waitcnt vmcnt(0)) before the first LDS read
+      prefetch(xb, z + 2, y0, x0);
+      __builtin_amdgcn_sched_barrier(0);               // ...and the scheduler must not sink them below the MFMAs either
       f32x4 acc[NSET][X3_NT];
 #pragma unroll
       for (int st = 0; st < NSET; ++st)
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) acc[st][i] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int ring = (z - 1 + 3) % 3;                // slot of plane z-1; plane z+dz-1 (dz = 0..2) sits in slot (ring + dz) % 3
-      if (!(diag & 1))
 #pragma unroll
       for (int s = 0; s < NSL; ++s) {
         const int st = s / NSLS;                        // compile time after unrolling
@@ -304,10 +301,10 @@ int x3_pack(const float* w, float* dst, int Cout, int Cin, int transpose, int pl
 // The bf16x3 form pays off on the big level-3 volumes (z-marching columns need many (column, segment) work items to fill the
 // chip) with fp32 storage, no residual input and equal-sized sets; everything else stays on the fp32-MFMA kernel.
 bool x3_eligible(const K3Args& a, int nset, int dtype) {
-  // opt-in (RAGMI_X3=1, read at every call so that a process can switch): the first version is ~4 % faster end to end than the
-  // fp32-MFMA kernel at 8x its (still tiny) rounding error — see DESIGN.md 4.6 for what limits it
+  // on by default; RAGMI_X3=0 (read at every call, so a process can switch) keeps everything on the fp32-MFMA kernel.
+  // End to end it is ~8 % faster at 8x the (still tiny) rounding error — DESIGN.md 4.6 says what limits it
   const char* env = getenv("RAGMI_X3");
-  const bool enabled = env && atoi(env) != 0;
+  const bool enabled = !(env && atoi(env) == 0);
   if (!enabled || dtype != RAGMI_F32 || a.res != nullptr) return false;
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
   if (nset == 2 && (a.nchunks[0] != a.nchunks[1] || a.nchunks[0] > 2)) return false;
@@ -347,8 +344,7 @@ int x3_launch(K3Args a, int nset, hipStream_t st) {
   const int64_t nwork = cols * e.nseg;
   RAGMI_REQUIRE(nwork < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
-  static const int diag = getenv("RAGMI_X3_DIAG") ? atoi(getenv("RAGMI_X3_DIAG")) : 0;
-  e.diag = diag;
+  e.diag = 0;
   const size_t lds = (size_t)2 * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)nsl * 8 * sizeof(int2) +
                      64 * sizeof(float);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");

@@ -602,7 +602,7 @@ def test_costvol_stem_tails_and_bf16(ra):
     np.testing.assert_allclose(outb.float().cpu().numpy(), refb.numpy(), rtol=1e-2, atol=1e-2)
 
 
-# --------------------------------------------------------------------------- opt-in bf16x3 convolution (conv3d_x3.hip, RAGMI_X3=1)
+# --------------------------------------------------------------------------- bf16x3 convolution (conv3d_x3.hip; RAGMI_X3=0 disables it)
 @pytest.fixture
 def x3_on():
     import os
@@ -649,3 +649,25 @@ def test_x3_dual_tails_and_headline_epe(ra, x3_on):
     ref = O.matching_net_forward(lf, rf, sd, rows, 192)
     epe = O.epe(disp, ref)
     assert epe <= EPE_GATE, epe
+
+
+def test_x3_switch_off_restores_fp32_mfma_path(ra):
+    """RAGMI_X3=0 is honoured at every call: same entry point, fp32-MFMA kernel, results within the fp32 tolerance of the bf16x3 ones."""
+    import os
+    x = torch.randn((1, 12, 64, 128, 130), generator=gen(141))
+    w = torch.randn((12, 12, 3, 3, 3), generator=gen(142)) * 0.1
+    pk, xg = ra.ops.conv3d_k3_pack(gpu(w)), gpu(x)
+    outs = {}
+    old = os.environ.get("RAGMI_X3")
+    try:
+        for flag in ("1", "0"):
+            os.environ["RAGMI_X3"] = flag
+            assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 128, 130) == (flag == "1")
+            outs[flag] = ra.ops.conv3d_k3(xg, pk, 12, None, None, False, torch.empty((1, 12, 64, 128, 130), device=DEV))
+    finally:
+        if old is None:
+            os.environ.pop("RAGMI_X3", None)
+        else:
+            os.environ["RAGMI_X3"] = old
+    assert not torch.equal(outs["0"], outs["1"])
+    np.testing.assert_allclose(outs["1"].cpu().numpy(), outs["0"].cpu().numpy(), rtol=1e-4, atol=1e-4)

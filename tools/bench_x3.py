@@ -10,7 +10,7 @@ import rag_amd  # noqa: E402
 
 dev = "cuda:0"
 ops = rag_amd.ops
-print("RAGMI_X3 =", os.environ.get("RAGMI_X3", "0 (default)"))
+print("RAGMI_X3 =", os.environ.get("RAGMI_X3", "1 (default)"))
 for cin, cout, shape in [(12, 12, (1, 16, 40, 70)), (4, 12, (2, 9, 33, 65)), (12, 12, (1, 64, 128, 416)), (4, 12, (1, 64, 128, 416)),
                          (24, 12, (1, 64, 128, 416)), (12, 12, (4, 64, 64, 128))]:
     g = torch.Generator().manual_seed(1)
