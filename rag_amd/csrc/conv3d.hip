@@ -159,7 +159,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
-  if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, s);
+  if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, dtype, s);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s1_cfg0_bf16(a, ng, s) : launch_k3_s1_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s1_cfg1_bf16(a, ng, s) : launch_k3_s1_cfg1_f32(a, ng, s);
@@ -224,7 +224,7 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
-  if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, s);
+  if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, dtype, s);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s2_cfg0_bf16(a, ng, s) : launch_k3_s2_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s2_cfg1_bf16(a, ng, s) : launch_k3_s2_cfg1_f32(a, ng, s);

@@ -556,7 +556,7 @@ RAGMI_K3_DECL(s2_cfg2);
 int64_t x3_packed_words(int Cout, int Cin);
 int x3_pack(const float* w, float* dst, int Cout, int Cin, int transpose, int planar, hipStream_t s);
 bool x3_eligible(const K3Args& a, int nset, int dtype);
-int x3_launch(K3Args a, int nset, hipStream_t st);
+int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
 int launch_k3_valu_f32(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights
 int launch_k3_valu_bf16(const K3Args& a, int cfg, hipStream_t s);
 

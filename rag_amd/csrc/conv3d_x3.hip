@@ -84,15 +84,18 @@ struct X3Extra {
 // NCG = input-channel groups of 4 over all sets, NSET accumulator sets (2: out = act(bnA(convA(x[:, :C]))) + act(bnB(convB(x[:, C:]))),
 // the Cell_3d sibling fusion of conv3d_k3).  Compile-time so that the K loop is fully unrolled (the LDS reads of the next
 // K-slice are in flight under the MFMAs of the current one) and the prefetch registers are static.
-template <int NCG, int NSET>
+// T = activation storage: float (three MFMAs per product) or bf16_t (the activations ARE bf16: no lo copy, two MFMAs per
+// product — weight hi and lo — and half the LDS operand traffic)
+template <class T, int NCG, int NSET>
 __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra e) {
+  constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
   static_assert(NCG % NSET == 0 && NPF <= 32, "bad instantiation");
   extern __shared__ __attribute__((aligned(16))) uint2 x3_lds[];       // hi[NCG][3][PL] | lo[NCG][3][PL] (uint2 = 4 bf16) | weights | offsets | params
   uint2* const lhi = x3_lds;
-  uint2* const llo = x3_lds + NCG * 3 * X3_PL;
-  uint4* const lw = reinterpret_cast<uint4*>(x3_lds + 2 * NCG * 3 * X3_PL);            // [set][slice][hi/lo][64 lanes]
+  uint2* const llo = x3_lds + NCG * 3 * X3_PL;                                          // absent for bf16 storage
+  uint4* const lw = reinterpret_cast<uint4*>(x3_lds + (BF ? 1 : 2) * NCG * 3 * X3_PL);  // [set][slice][hi/lo][64 lanes]
   int2* const loff = reinterpret_cast<int2*>(lw + NSL * 2 * 64);                        // [set][slice][8 pairs]: (in-plane offset incl. cg, dz)
   float* const par = reinterpret_cast<float*>(loff + NSL * 8);                          // scale[2][16] | shift[2][16]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
@@ -144,9 +147,9 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
   }
   float pf[NPF][4];
   unsigned valid = 0;
-  const float* const x = static_cast<const float*>(a.x);
+  const T* const x = static_cast<const T*>(a.x);
   // issue the loads of input plane gz of the column at (y0, x0): unconditional, addresses clamped into the volume
-  auto prefetch = [&](const float* xb, int gz, int y0, int x0) {
+  auto prefetch = [&](const T* xb, int gz, int y0, int x0) {
     valid = 0;
     const bool zok = (unsigned)gz < (unsigned)a.D;
     const int cz = min(max(gz, 0), a.D - 1);
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
       valid |= (ok ? 1u : 0u) << p;
       const unsigned off = (unsigned)(cz * HW + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pf[p][c] = xb[(int64_t)min(cg * 4 + c, a.Cin - 1) * DHW + off];
+      for (int c = 0; c < 4; ++c) pf[p][c] = ld(xb + (int64_t)min(cg * 4 + c, a.Cin - 1) * DHW + off);
     }
   };
   auto commit = [&](int slot) {          // registers -> ring plane `slot` (bf16 hi / lo), zeros outside the volume / past Cin
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
       const unsigned h01 = x3_split2(v[0], v[1], l01), h23 = x3_split2(v[2], v[3], l23);
       const int d = (cg * 3 + slot) * X3_PL + r;
       lhi[d] = make_uint2(h01, h23);
-      llo[d] = make_uint2(l01, l23);
+      if constexpr (!BF) llo[d] = make_uint2(l01, l23);
     }
   };
   // this wave's column tiles of a plane: nt = wave * X3_NT + i -> (row y = nt / 2, x half = nt % 2)
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
     const int y0 = (t % a.tiles_y) * X3_TY; t /= a.tiles_y;
     const int seg = t % e.nseg, b = t / e.nseg;
     const int zs = seg * e.seg_len, ze = min(a.D, zs + e.seg_len);
-    const float* xb = x + b * a.x_bstride;
+    const T* xb = x + b * a.x_bstride;
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
     prefetch(xb, zs - 1, y0, x0); commit((zs - 1 + 3) % 3);
     prefetch(xb, zs, y0, x0); commit(zs % 3);
@@ -228,13 +231,17 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
         x3_bf16x8 bh[X3_NT], bl[X3_NT];
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) {
-          const uint2 h0 = lhi[vbase[i] + o0], h1 = lhi[vbase[i] + o1], l0 = llo[vbase[i] + o0], l1 = llo[vbase[i] + o1];
+          const uint2 h0 = lhi[vbase[i] + o0], h1 = lhi[vbase[i] + o1];
           bh[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-          bl[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+          if constexpr (!BF) {
+            const uint2 l0 = llo[vbase[i] + o0], l1 = llo[vbase[i] + o1];
+            bl[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+          }
         }
         // term-major order: consecutive MFMAs hit different accumulators (a dependent pair is X3_NT instructions apart)
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) acc[st][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[i], acc[st][i], 0, 0, 0);
+        if constexpr (!BF)
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) acc[st][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[i], acc[st][i], 0, 0, 0);
 #pragma unroll
@@ -259,10 +266,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
           v[r] = sum;
         }
         if (a.store_main && inside && g < ngroups) {
-          float* py = static_cast<float*>(a.y) + b * a.y_bstride + (int64_t)a.y_ch[g] * DHW + vox;
+          T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)a.y_ch[g] * DHW + vox;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (4 * g + r < a.Cout) py[r * DHW] = v[r];
+            if (4 * g + r < a.Cout) st(py + r * DHW, v[r]);
         }
         if (a.ntail > 0) {                              // uniform
           unsigned l01, l23;
@@ -271,12 +278,12 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
           f32x4 tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta1, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta2, bv, tacc, 0, 0, 0);
           if (kb < a.ntail && inside) {
-            float* pt = static_cast<float*>(a.tail_y[kb]) + b * a.tail_bstride[kb] + (int64_t)a.tail_ch0[kb] * DHW + vox;
+            T* pt = static_cast<T*>(a.tail_y[kb]) + b * a.tail_bstride[kb] + (int64_t)a.tail_ch0[kb] * DHW + vox;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (r < a.tail_cout[kb]) {
                 float u = fmaf(tacc[r], tsc[r], tsh[r]);
-                pt[r * DHW] = a.tail_relu[kb] ? fmaxf(u, 0.f) : u;
+                st(pt + r * DHW, a.tail_relu[kb] ? fmaxf(u, 0.f) : u);
               }
           }
         }
@@ -305,30 +312,35 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
   // End to end it is ~8 % faster at 8x the (still tiny) rounding error — DESIGN.md 4.6 says what limits it
   const char* env = getenv("RAGMI_X3");
   const bool enabled = !(env && atoi(env) == 0);
-  if (!enabled || dtype != RAGMI_F32 || a.res != nullptr) return false;
+  if (!enabled || !dtype_ok(dtype) || a.res != nullptr) return false;
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
   if (nset == 2 && (a.nchunks[0] != a.nchunks[1] || a.nchunks[0] > 2)) return false;
   if (nset == 1 && ncg > 6) return false;
-  if ((int64_t)a.B * a.D * a.H * a.W < (1 << 20) || a.W < 32 || a.D < 8) return false;
+  static const int64_t minvox = getenv("RAGMI_X3_MINVOX") ? atoll(getenv("RAGMI_X3_MINVOX")) : (1 << 18);
+  if ((int64_t)a.B * a.D * a.H * a.W < minvox || a.W < 32 || a.D < 8) return false;
   if (a.ntail > 0 && a.Cout > 16) return false;
   if ((int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
   return true;
 }
 
-template <int NCG, int NSET>
-static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
+template <class T, int NCG, int NSET>
+static int x3_launch_typed(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3d_x3_kernel<NCG, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3d_x3_kernel<T, NCG, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3d_x3_kernel<NCG, NSET>), grid, dim3(X3_THREADS), lds, st, a, e);
+  hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET>), grid, dim3(X3_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3");
+}
+template <int NCG, int NSET>
+static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
+  return e.diag ? x3_launch_typed<bf16_t, NCG, NSET>(a, e, grid, lds, st) : x3_launch_typed<float, NCG, NSET>(a, e, grid, lds, st);
 }
 
 // a: as filled for the fp32 kernel (wp[s] = packed weights: fp32-MFMA section followed by the bf16x3 fragments)
-int x3_launch(K3Args a, int nset, hipStream_t st) {
+int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   X3Extra e{};
   const int ngroups = (a.Cout + 3) / 4;
   for (int s = 0; s < nset; ++s)
@@ -344,8 +356,8 @@ int x3_launch(K3Args a, int nset, hipStream_t st) {
   const int64_t nwork = cols * e.nseg;
   RAGMI_REQUIRE(nwork < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
-  e.diag = 0;
-  const size_t lds = (size_t)2 * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)nsl * 8 * sizeof(int2) +
+  e.diag = dtype == RAGMI_BF16 ? 1 : 0;          // storage type selector
+  const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)nsl * 8 * sizeof(int2) +
                      64 * sizeof(float);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
   const dim3 grid((unsigned)std::min<int64_t>(nwork, 1024), ncog);

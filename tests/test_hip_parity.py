@@ -621,7 +621,7 @@ def test_x3_conv_vs_oracle(ra, x3_on, cin, cout, shape):
     """fp32 accuracy from three bf16 MFMAs per product: same entry point, shapes big enough to take the bf16x3 kernel."""
     B, D, H, W = shape
     vox = B * D * H * W
-    scale_up = max(1, -(-(1 << 20) // vox))           # the dispatcher wants >= 2^20 voxels: tile the batch
+    scale_up = max(1, -(-(1 << 18) // vox))           # the dispatcher wants >= 2^18 voxels: tile the batch
     x = torch.randn((B, cin, D, H, W), generator=gen(121)).repeat(scale_up, 1, 1, 1, 1)
     w = torch.randn((cout, cin, 3, 3, 3), generator=gen(122)) * 0.1
     sc, sh = torch.rand(cout, generator=gen(123)) + 0.5, torch.randn(cout, generator=gen(124)) * 0.1
@@ -671,3 +671,17 @@ def test_x3_switch_off_restores_fp32_mfma_path(ra):
             os.environ["RAGMI_X3"] = old
     assert not torch.equal(outs["0"], outs["1"])
     np.testing.assert_allclose(outs["1"].cpu().numpy(), outs["0"].cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_x3_bf16_storage(ra):
+    """bf16 activation storage on the bf16x3 kernel: the activations are exact bf16 operands, only the weights are split (2 MFMAs)."""
+    B, cin, cout, D, H, W = 2, 12, 12, 32, 128, 130
+    x = torch.randn((B, cin, D, H, W), generator=gen(151)).to(torch.bfloat16)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen(152)) * 0.1
+    assert ra.ops.conv3d_k3_uses_x3(cin, cout, B, D, H, W, dtype=torch.bfloat16)
+    out = torch.empty((B, cout, D, H, W), device=DEV, dtype=torch.bfloat16)
+    ra.ops.conv3d_k3(gpu(x), ra.ops.conv3d_k3_pack(gpu(w)), cout, None, None, True, out)
+    ref = F.relu(F.conv3d(x[:1, :, :8].float(), w, padding=1))
+    got = out[:1, :, :8].float().cpu()
+    # interior planes only (the reference slab has its own z border at plane 7)
+    np.testing.assert_allclose(got[:, :, :7].numpy(), ref[:, :, :7].numpy(), rtol=1e-2, atol=1e-2)
