@@ -87,7 +87,7 @@ struct X3Extra {
 // T = activation storage: float (three MFMAs per product) or bf16_t (the activations ARE bf16: no lo copy, two MFMAs per
 // product — weight hi and lo — and half the LDS operand traffic)
 template <class T, int NCG, int NSET>
-__global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra e) {
+__global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 2 : 1)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
@@ -189,6 +189,13 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
     vbase[i] = (nt >> 1) * X3_HX + (nt & 1) * 16 + n;
   }
   const int g = cog * 4 + kb, ngroups = (a.Cout + 3) >> 2;
+  // per-lane destinations, read ONCE: indexing the kernel-argument arrays with a lane-dependent index inside the loop is a
+  // vector memory load per use, and its s_waitcnt vmcnt drains the prefetch that is supposed to fly under the MFMAs
+  const int my_ych = g < ngroups ? a.y_ch[g < RAGMI_MAX_GROUPS ? g : 0] : 0;
+  const int tsel = kb & 1;
+  T* const my_tail = static_cast<T*>(a.tail_y[tsel]);
+  const int64_t my_tail_bstride = a.tail_bstride[tsel];
+  const int my_tail_ch0 = a.tail_ch0[tsel], my_tail_cout = kb < a.ntail ? a.tail_cout[tsel] : 0, my_tail_relu = a.tail_relu[tsel];
   // XCD-aware schedule: workgroup j runs on XCD j % 8 (round-robin dispatch); give every XCD one contiguous chunk of the
   // (x-fastest) work list so that neighbouring columns — which share halo rows and cache lines — meet in the same L2
   const int chunk = (e.nwork + 7) / 8;
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
           v[r] = sum;
         }
         if (a.store_main && inside && g < ngroups) {
-          T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)a.y_ch[g] * DHW + vox;
+          T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)my_ych * DHW + vox;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (4 * g + r < a.Cout) st(py + r * DHW, v[r]);
@@ -277,13 +284,13 @@ __global__ __launch_bounds__(X3_THREADS) void conv3d_x3_kernel(K3Args a, X3Extra
           const x3_bf16x8 bv = __builtin_bit_cast(x3_bf16x8, make_uint4(h01, h23, l01, l23));
           f32x4 tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta1, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta2, bv, tacc, 0, 0, 0);
-          if (kb < a.ntail && inside) {
-            T* pt = static_cast<T*>(a.tail_y[kb]) + b * a.tail_bstride[kb] + (int64_t)a.tail_ch0[kb] * DHW + vox;
+          if (my_tail_cout > 0 && inside) {
+            T* pt = my_tail + b * my_tail_bstride + (int64_t)my_tail_ch0 * DHW + vox;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (r < a.tail_cout[kb]) {
+              if (r < my_tail_cout) {
                 float u = fmaf(tacc[r], tsc[r], tsh[r]);
-                st(pt + r * DHW, a.tail_relu[kb] ? fmaxf(u, 0.f) : u);
+                st(pt + r * DHW, my_tail_relu ? fmaxf(u, 0.f) : u);
               }
           }
         }
