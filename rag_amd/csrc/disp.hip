@@ -19,6 +19,13 @@ struct DispArgs {
 
 template <class T>
 __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
+  extern __shared__ float4 ztab[];                 // [maxdisp]
+  for (int dd = threadIdx.x; dd < a.maxdisp; dd += 256) {
+    const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
+    const bool same = lz.i1 == lz.i0;
+    ztab[dd] = make_float4((float)lz.i0, lz.w0, same ? 0.f : lz.w1, same ? lz.w1 : 0.f);
+  }
+  __syncthreads();
   const int64_t npix = (int64_t)a.Ho * a.Wo;
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= npix) return;
@@ -43,18 +50,20 @@ __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
   //   m' = max(m, t); s = s*2^((m-m')k) + 2^((t-m')k); differences are formed BEFORE scaling by k=log2(e)
   //   so large |cost| does not lose the bits that matter near the maximum.
   constexpr float K = 1.4426950408889634f;
+  // The fine-disparity taps (i0, i1 == i0, w0, w1) are the same for every pixel: one table per workgroup in LDS instead
+  // of ~12 VALU instructions of index arithmetic per fine sample per pixel (the kernel is VALU-bound).
   int cz = 0;
   float b0 = plane(0), b1 = plane(a.d > 1 ? 1 : 0);
   float m = -INFINITY, s = 0.f, ws = 0.f;
   for (int dd = 0; dd < a.maxdisp; ++dd) {
-    const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
-    while (lz.i0 > cz) {   // rarely more than one step (only when down-sampling the disparity axis)
+    const float4 tb = ztab[dd];                    // (i0, w0, w1 if i1 != i0 else 0, w1 if i1 == i0 else 0)
+    const int i0 = (int)tb.x;
+    while (i0 > cz) {   // rarely more than one step (only when down-sampling the disparity axis)
       ++cz;
       b0 = b1;
       b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1);
     }
-    const float v1 = lz.i1 == lz.i0 ? b0 : b1;
-    const float t = -(lz.w0 * b0 + lz.w1 * v1);
+    const float t = -fmaf(tb.y + tb.w, b0, tb.z * b1);
     const float mn = fmaxf(m, t);
     const float r = __builtin_amdgcn_exp2f((m - mn) * K);   // 2^(-inf) = 0 on the first sample
     const float e = __builtin_amdgcn_exp2f((t - mn) * K);
@@ -92,8 +101,10 @@ extern "C" int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int
   DispArgs a{cost, (float*)out, d, h, w, maxdisp, Ho, Wo,
              lin_scale(d, maxdisp, 0), lin_scale(h, Ho, 0), lin_scale(w, Wo, 0)};
   dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), B);
-  if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_kernel<bf16_t>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  else hipLaunchKernelGGL(disp_softargmin_kernel<float>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  const size_t lds = (size_t)maxdisp * sizeof(float4);
+  RAGMI_REQUIRE(lds <= 64 * 1024, RAGMI_EUNSUPPORTED, "disp_softargmin: maxdisp %d exceeds the tap table (4096)", maxdisp);
+  if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_kernel<bf16_t>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(disp_softargmin_kernel<float>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
   return check_launch("disp_softargmin");
 }
 
