@@ -80,13 +80,14 @@ struct PlanesArgs {
 };
 constexpr int CS_TX = 64, CS_TY = 8, CS_PX = 4;     // workgroup tile; pixels per thread along x (weights read once per 4 pixels)
 constexpr int CS_RS = CS_TX + 5;                     // LDS row stride = 5 mod 32: the 16 x 4 lanes of a wave spread 2 per bank
-constexpr int CS_NT = (CS_TX / CS_PX) * CS_TY;       // threads per workgroup (one wave)
+constexpr int CS_NT = (CS_TX / CS_PX) * CS_TY;       // threads per workgroup
+constexpr int CS_CC = 4;                             // input channels staged in LDS at a time
 static_assert(CS_RS % 32 == 5, "row stride must be 5 mod 32");
 // COUT4 = Cout / 4 when Cout is a multiple of 4 (weights read as float4 broadcasts), 0 = any Cout (scalar reads)
 template <class T, int COUT4>
 __global__ __launch_bounds__(CS_NT) void costvol_stem_planes_kernel(PlanesArgs a) {
   constexpr int NCO = COUT4 ? COUT4 * 4 : CS_MAXC;
-  extern __shared__ __attribute__((aligned(16))) float cs_lds[];   // weights [C][3][ntap][Cout] | tile [C][TY+2][RS]
+  extern __shared__ __attribute__((aligned(16))) float cs_lds[];   // weights [C][3][ntap][Cout] | tile [CS_CC][TY+2][RS]
   float* wl = cs_lds;
   float* tile = cs_lds + ((a.C * 15 * a.Cout + 3) & ~3);
   const PlaneDesc d = a.d[blockIdx.z % a.ndesc];
@@ -95,55 +96,63 @@ __global__ __launch_bounds__(CS_NT) void costvol_stem_planes_kernel(PlanesArgs a
   if (xb >= d.width) return;                                      // uniform: descriptors have different widths
   const int ntap = d.right ? 5 : 3, kh = d.right ? 2 : 1;
   const T* src = static_cast<const T*>(d.right ? a.right : a.left) + (int64_t)b * a.C * a.H * a.W;
-  for (int e = threadIdx.x; e < a.C * (CS_TY + 2) * (CS_TX + 4); e += CS_NT) {
-    const int xx = e % (CS_TX + 4), yy = (e / (CS_TX + 4)) % (CS_TY + 2), c = e / ((CS_TX + 4) * (CS_TY + 2));
-    const int gy = yb + yy - 1, gx = d.x0 + xb + xx - kh;
-    const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    tile[(c * (CS_TY + 2) + yy) * CS_RS + xx] = ok ? ld(src + ((int64_t)c * a.H + gy) * a.W + gx) : 0.f;
-  }
   const int nw = a.C * 3 * ntap * a.Cout;
   for (int e = threadIdx.x; e < nw; e += CS_NT) wl[e] = a.wts[d.w_off + e];
-  __syncthreads();
   const int xx = (threadIdx.x % (CS_TX / CS_PX)) * CS_PX, yy = threadIdx.x / (CS_TX / CS_PX);
   float acc[CS_PX][NCO];
 #pragma unroll
   for (int p = 0; p < CS_PX; ++p)
 #pragma unroll
     for (int co = 0; co < NCO; ++co) acc[p][co] = 0.f;
+  // input channels go through LDS CS_CC at a time: a small tile keeps many workgroups resident (the loop body is a chain
+  // of LDS reads feeding FMAs, so occupancy is what hides its latency)
   auto body = [&](auto ntap_) {
     constexpr int NT = decltype(ntap_)::value;
-    for (int c = 0; c < a.C; ++c)
+    for (int c0 = 0; c0 < a.C; c0 += CS_CC) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < CS_CC * (CS_TY + 2) * (CS_TX + 4); e += CS_NT) {
+        const int tx = e % (CS_TX + 4), ty = (e / (CS_TX + 4)) % (CS_TY + 2), cl = e / ((CS_TX + 4) * (CS_TY + 2));
+        const int gy = yb + ty - 1, gx = d.x0 + xb + tx - kh, c = c0 + cl;
+        const bool ok = c < a.C && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        tile[(cl * (CS_TY + 2) + ty) * CS_RS + tx] = ok ? ld(src + ((int64_t)c * a.H + gy) * a.W + gx) : 0.f;
+      }
+      __syncthreads();
+      const int nc = min(CS_CC, a.C - c0);
+      for (int cl = 0; cl < nc; ++cl) {
+        const int c = c0 + cl;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        float v[CS_PX + NT - 1];
+        for (int dy = 0; dy < 3; ++dy) {
+          float v[CS_PX + NT - 1];
 #pragma unroll
-        for (int k = 0; k < CS_PX + NT - 1; ++k) v[k] = tile[(c * (CS_TY + 2) + yy + dy) * CS_RS + xx + k];
+          for (int k = 0; k < CS_PX + NT - 1; ++k) v[k] = tile[(cl * (CS_TY + 2) + yy + dy) * CS_RS + xx + k];
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-          const float* wr = wl + ((c * 3 + dy) * NT + k) * a.Cout;
-          if constexpr (COUT4 > 0) {
+          for (int k = 0; k < NT; ++k) {
+            const float* wr = wl + ((c * 3 + dy) * NT + k) * a.Cout;
+            if constexpr (COUT4 > 0) {
 #pragma unroll
-            for (int q = 0; q < COUT4; ++q) {
-              const float4 w4 = *reinterpret_cast<const float4*>(wr + 4 * q);
+              for (int q = 0; q < COUT4; ++q) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wr + 4 * q);
 #pragma unroll
-              for (int p = 0; p < CS_PX; ++p) {
-                acc[p][4 * q + 0] = fmaf(w4.x, v[p + k], acc[p][4 * q + 0]);
-                acc[p][4 * q + 1] = fmaf(w4.y, v[p + k], acc[p][4 * q + 1]);
-                acc[p][4 * q + 2] = fmaf(w4.z, v[p + k], acc[p][4 * q + 2]);
-                acc[p][4 * q + 3] = fmaf(w4.w, v[p + k], acc[p][4 * q + 3]);
+                for (int p = 0; p < CS_PX; ++p) {
+                  acc[p][4 * q + 0] = fmaf(w4.x, v[p + k], acc[p][4 * q + 0]);
+                  acc[p][4 * q + 1] = fmaf(w4.y, v[p + k], acc[p][4 * q + 1]);
+                  acc[p][4 * q + 2] = fmaf(w4.z, v[p + k], acc[p][4 * q + 2]);
+                  acc[p][4 * q + 3] = fmaf(w4.w, v[p + k], acc[p][4 * q + 3]);
+                }
               }
+            } else {
+#pragma unroll
+              for (int co = 0; co < NCO; ++co)
+                if (co < a.Cout) {
+                  const float wv = wr[co];
+#pragma unroll
+                  for (int p = 0; p < CS_PX; ++p) acc[p][co] = fmaf(wv, v[p + k], acc[p][co]);
+                }
             }
-          } else {
-#pragma unroll
-            for (int co = 0; co < NCO; ++co)
-              if (co < a.Cout) {
-                const float wv = wr[co];
-#pragma unroll
-                for (int p = 0; p < CS_PX; ++p) acc[p][co] = fmaf(wv, v[p + k], acc[p][co]);
-              }
           }
         }
       }
+    }
   };
   if (d.right) body(std::integral_constant<int, 5>{}); else body(std::integral_constant<int, 3>{});
   const int y = yb + yy;
@@ -322,7 +331,7 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
   for (int k = 0; k < n; ++k) maxw = std::max(maxw, pa.d[k].width);
   RAGMI_REQUIRE((int64_t)n * B <= 65535, RAGMI_EUNSUPPORTED, "costvol_stem: batch too large for one launch");
   const dim3 pgrid((unsigned)ceil_div(maxw, CS_TX), (unsigned)ceil_div(H, CS_TY), (unsigned)(n * B));
-  const size_t plds = sizeof(float) * (((size_t)C * 15 * Cout + 3) / 4 * 4 + (size_t)C * (CS_TY + 2) * CS_RS);
+  const size_t plds = sizeof(float) * (((size_t)C * 15 * Cout + 3) / 4 * 4 + (size_t)CS_CC * (CS_TY + 2) * CS_RS);
 #define RAGMI_CS_PLANES(TT)                                                                                             \
   switch (Cout % 4 == 0 ? Cout / 4 : 0) {                                                                              \
     case 1: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 1>), pgrid, dim3(CS_NT), plds, st, pa); break;          \
