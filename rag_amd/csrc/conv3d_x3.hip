@@ -78,7 +78,7 @@ __global__ void x3_pack_kernel(const float* __restrict__ w, uint4* __restrict__ 
 
 struct X3Extra {
   const uint4* wf[2];        // packed fragments per accumulator set
-  int nseg, seg_len, nwork, diag;
+  int nseg, seg_len, nwork, bf16;   // bf16 != 0: bf16 activation storage (kernel instantiation selector)
 };
 
 // NCG = input-channel groups of 4 over all sets, NSET accumulator sets (2: out = act(bnA(convA(x[:, :C]))) + act(bnB(convB(x[:, C:]))),
@@ -343,7 +343,7 @@ static int x3_launch_typed(const K3Args& a, const X3Extra& e, dim3 grid, size_t 
 }
 template <int NCG, int NSET>
 static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
-  return e.diag ? x3_launch_typed<bf16_t, NCG, NSET>(a, e, grid, lds, st) : x3_launch_typed<float, NCG, NSET>(a, e, grid, lds, st);
+  return e.bf16 ? x3_launch_typed<bf16_t, NCG, NSET>(a, e, grid, lds, st) : x3_launch_typed<float, NCG, NSET>(a, e, grid, lds, st);
 }
 
 // a: as filled for the fp32 kernel (wp[s] = packed weights: fp32-MFMA section followed by the bf16x3 fragments)
@@ -363,7 +363,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   const int64_t nwork = cols * e.nseg;
   RAGMI_REQUIRE(nwork < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
-  e.diag = dtype == RAGMI_BF16 ? 1 : 0;          // storage type selector
+  e.bf16 = dtype == RAGMI_BF16 ? 1 : 0;
   const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)nsl * 8 * sizeof(int2) +
                      64 * sizeof(float);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
