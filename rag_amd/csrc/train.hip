@@ -338,15 +338,16 @@ __global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
     }
   };
 
-  const int diag = a.diag;                             // RAGMI_WGRAD_DIAG (profiling only): 2 no MFMA, 4 no loads
   int tile = blockIdx.x;
-  if (tile < a.ntiles && !(diag & 4)) prefetch(tile);
+  if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();                                   // the previous tile's LDS reads are done
     commit((tile % a.tiles_x) * WG_TX);
     __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles && !(diag & 4)) prefetch(tile + gridDim.x);
-    if (diag & 2) continue;
+    // unconditional (past the end it re-reads the last tile; never committed) and pinned: a branch around the prefetch makes the
+    // compiler drain it before the first LDS read, and without the barrier the scheduler sinks it below the MFMA loop
+    prefetch(min(tile + (int)gridDim.x, a.ntiles - 1));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 2
     for (int s = 0; s < WG_NV / 16; ++s) {
       const int v = s * 16 + blk;                      // this block's voxel of the step: 16 consecutive x
