@@ -429,13 +429,16 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     if (nchunk == nch) { nchunk = 0; nt += tstep; }
     const bool has_next = nt < tend;
     if (has_next && nt != t) nxt = decode_tc(nt);
-    if (has_next && !diag_nostage) prefetch(nxt, nchunk);   // global loads stay in flight under the MFMA phase below
+    // weights that come from global memory are requested BEFORE the halo prefetch: vector memory returns in order, so waiting
+    // for them must not have to wait for the prefetch that is meant to stay in flight under the MFMA phase
+    if (VCO == 0 && !diag_nomfma && nch > 1 && !a.w_in_lds) load_weights(chunk);
+    if (has_next && !diag_nostage) prefetch(nxt, nchunk);
 
     if (diag_nomfma) {
     } else if constexpr (VCO > 0) {
       valu_block(chunk);
     } else {
-      if (nch > 1 || a.w_in_lds) load_weights(chunk);   // from LDS: visible after the barrier above
+      if (a.w_in_lds) load_weights(chunk);   // from LDS: visible after the barrier above
       if (NSET == 2 && chunk >= nch0) mfma_block(std::integral_constant<int, NSET - 1>{});
       else mfma_block(std::integral_constant<int, 0>{});
     }
@@ -496,12 +499,16 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   if (diag_nostore) a.relu |= (diag_nostore << 8);   // DIAG: 1 no stores, 2 no MFMA block, 4 no staging
   static const int policy = [] { const char* e = getenv("RAGMI_K3_WLDS"); return e ? atoi(e) : 2; }();
   const int nstages = a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0);
-  a.w_in_lds = (VCO == 0 && policy != 0 && wbytes <= (size_t)K3_MAX_WLDS_BYTES && (policy == 1 || nstages > 1)) ? 1 : 0;
+  // budget: 36 KB next to the big tiles, or whatever still leaves two workgroups per CU (small tiles of the deep levels: their
+  // 48-output weights are ~57 KB; read from global per stage they sit in the vmcnt queue BEHIND the halo prefetch, so waiting
+  // for them drains the prefetch that should fly under the MFMAs)
+  const size_t wbudget = std::max<size_t>(K3_MAX_WLDS_BYTES, tile_bytes < 78 * 1024 ? 78 * 1024 - tile_bytes : 0);
+  a.w_in_lds = (VCO == 0 && policy != 0 && wbytes <= wbudget && (policy == 1 || nstages > 1)) ? 1 : 0;
   const size_t lds = tile_bytes + (VCO > 0 ? (size_t)a.Cout * a.Cin * 27 * sizeof(float) : (a.w_in_lds ? wbytes : 0));
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(tile_bytes + K3_MAX_WLDS_BYTES));
+                              (int)std::max<size_t>(tile_bytes + K3_MAX_WLDS_BYTES, 80 * 1024));
     attr_set = true;
   }
   // occupancy depends on the dynamic LDS size: cache per size (a handful of distinct sizes per instantiation)
