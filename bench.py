@@ -323,9 +323,16 @@ def main():
                     help="activation storage: f32 (configs[1], default) or bf16 storage / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: time the data-parallel training step instead")
+    ap.add_argument("--hw", default=None, help="HxW of the stereo pairs, multiples of 12 (default 384x1248 = configs[1]; configs[3]: "
+                                               "480x960 with --batch 8)")
     args = ap.parse_args()
     if args.graph is None:
         args.graph = 1
+    global H, W
+    if args.hw:
+        H, W = (int(v) for v in args.hw.lower().split("x"))
+        if H % 12 or W % 12:
+            ap.error("--hw: H and W must be multiples of 12 (rag_model.py:317-323)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -433,14 +440,14 @@ def main():
             log(f"  end-to-end (images -> disparity, Feature Net + Matching Net): {e2e['value']} maps/s ({e2e['ms_per_pair']} ms/pair)")
         ms = dt / args.steps * 1e3
         line = {
-            "metric": "disparity maps/sec at 384x1248 D=192 (Matching-Net forward)",
+            "metric": f"disparity maps/sec at {H}x{W} D=192 (Matching-Net forward)",
             "value": round(n_gpus * B * args.steps / dt, 3), "unit": "disparity maps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (level-3 3x3x3 convolutions: fp32 operands split into bf16 hi+lo on the bf16 matrix cores, fp32 accumulate)"
                       if (args.dtype == "f32" and os.environ.get("RAGMI_X3", "1") != "0") else
                       "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate"), "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "
+            "config": {"workload": f"BASELINE configs[{3 if (H, W) == (480, 960) else 1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
                        "global_batch": n_gpus * B, "sharding": "batch split, no collective",
                        "launch": "hipGraph" if graph is not None else "eager"},
