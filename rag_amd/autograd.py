@@ -69,8 +69,7 @@ class ConvBRFn(torch.autograd.Function):
         else:
             ops.conv3d_k1(x, w.reshape(cout, -1), None, None, False, raw)
         n = B * _vol(x)
-        scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
-        y = ops.bn_act(raw, scale, shift, mod.relu) if (mod.use_bn or mod.relu) else raw
+        y, scale, shift, mean, invstd, training = _bn_forward_act(raw, n, gamma, beta, mod)
         ctx.mod, ctx.k, ctx.n, ctx.training = mod, k, n, training
         ctx.save_for_backward(x, weight, raw, scale, shift, mean, invstd)
         return y
@@ -122,6 +121,23 @@ def _bn_forward(raw, n, gamma, beta, mod):
     return scale, shift, mean, invstd, False
 
 
+def _bn_forward_act(raw, n, gamma, beta, mod):
+    """BatchNorm + ReLU of a ConvBR forward: (y, scale, shift, mean, invstd, training).  Train mode is two launches
+    (ragmi_bn_train_act_fwd: statistics, then finalize + running-stat update + affine + ReLU in one kernel)."""
+    bn = mod.bn
+    if mod.use_bn and bn.training:
+        if bn.momentum is None:
+            raise NotImplementedError("rag_amd: BatchNorm momentum=None (cumulative average) is not built; the reference uses 0.1")
+        track = bn.track_running_stats and bn.running_mean is not None
+        y, st = ops.bn_train_act(raw, gamma.detach(), beta.detach(), bn.running_mean if track else None,
+                                 bn.running_var if track else None, bn.num_batches_tracked if track else None, bn.momentum, bn.eps,
+                                 mod.relu)
+        return y, st[2], st[3], st[0], st[1], True
+    scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
+    y = ops.bn_act(raw, scale, shift, mod.relu) if (mod.use_bn or mod.relu) else raw
+    return y, scale, shift, mean, invstd, training
+
+
 def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, need_b, out=None):
     """ReLU + BatchNorm adjoint: (gradient w.r.t. the raw conv output, dgamma, dbeta); `out`: destination channel slice.
     dgamma / dbeta come back as None when they were accumulated straight into bucket-backed .grad tensors."""
@@ -134,11 +150,11 @@ def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, 
     if mod.use_bn and (training or need_g or need_b):
         tg, tb = (_direct(mod.bn.weight), _direct(mod.bn.bias)) if (need_g and need_b) else (None, None)
         direct = tg is not None and tb is not None
-        co = ops.bn_act_bwd_coeffs(dy, 0, raw, scale, shift, mod.relu, mean, invstd, training,
-                                   dgamma_into=tg if direct else None, dbeta_into=tb if direct else None)
-        c1, c2, c3 = co[0], co[1], co[2]
+        dx, dg, db = ops.bn_act_bwd(dy, raw, scale, shift, mod.relu, mean, invstd, training, out=out,
+                                    dgamma_into=tg if direct else None, dbeta_into=tb if direct else None)
         if not direct:
-            dgamma, dbeta = (co[3] if need_g else None), (co[4] if need_b else None)
+            dgamma, dbeta = (dg if need_g else None), (db if need_b else None)
+        return dx, dgamma, dbeta
     else:
         c1 = scale
         c2 = c3 = torch.zeros_like(scale)
@@ -164,8 +180,8 @@ class ConvBRGroupFn(torch.autograd.Function):
         ctx.training = []
         for i, m in enumerate(mods):
             r = raw[:, i * C:(i + 1) * C]
-            scale, shift, mean, invstd, training = _bn_forward(r, nvox, params[3 * i + 1], params[3 * i + 2], m)
-            outs.append(ops.bn_act(r, scale, shift, m.relu))
+            y, scale, shift, mean, invstd, training = _bn_forward_act(r, nvox, params[3 * i + 1], params[3 * i + 2], m)
+            outs.append(y)
             saved += [scale, shift, mean, invstd]
             ctx.training.append(training)
         ctx.mods, ctx.n = mods, nvox
@@ -212,8 +228,7 @@ class StridedStemFn(torch.autograd.Function):
         stride = mod.conv.stride[0]
         raw = ops.conv2d_k3_strided(x, weight.detach(), None, None, False, stride)
         n = raw.shape[0] * _vol(raw)
-        scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
-        y = ops.bn_act(raw, scale, shift, mod.relu) if (mod.use_bn or mod.relu) else raw
+        y, scale, shift, mean, invstd, training = _bn_forward_act(raw, n, gamma, beta, mod)
         ctx.mod, ctx.n, ctx.training, ctx.stride = mod, n, training, stride
         ctx.save_for_backward(x, weight, raw, scale, shift, mean, invstd)
         return y

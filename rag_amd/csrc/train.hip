@@ -184,6 +184,104 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(BnCoeffArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused second halves: every workgroup re-derives its channel's coefficients from the (<= 256) partials — a couple of
+// microseconds of redundant work per workgroup — instead of a separate one-workgroup-per-channel launch in between:
+// train-mode BatchNorm + ReLU forward = bn_stats + bn_finalize_act, its adjoint = bn_act_bwd_reduce + bn_coeffs_apply.
+struct BnFinActArgs {
+  BnFinalizeArgs f;
+  const float* x;
+  float* y;
+  int64_t x_bstride, y_bstride, dhw;
+  int y_ch0, relu;
+};
+__global__ __launch_bounds__(256) void bn_finalize_act_kernel(BnFinActArgs a) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  double s, q;
+  block_pair_sum(a.f.part, a.f.nparts, c, s, q);
+  const double mean = s / a.f.n;
+  double var = q / a.f.n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)a.f.eps));
+  const float sc = a.f.gamma[c] * invstd, sh = a.f.beta[c] - (float)mean * sc;
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    a.f.mean[c] = (float)mean;
+    a.f.invstd[c] = invstd;
+    a.f.scale[c] = sc;
+    a.f.shift[c] = sh;
+    if (a.f.running_mean) {
+      const float m = a.f.momentum;
+      a.f.running_mean[c] = (1.f - m) * a.f.running_mean[c] + m * (float)mean;
+      a.f.running_var[c] = (1.f - m) * a.f.running_var[c] + m * (float)(var * (a.f.n / (a.f.n > 1.0 ? a.f.n - 1.0 : 1.0)));
+      if (c == 0 && a.f.num_batches_tracked) *a.f.num_batches_tracked += 1;
+    }
+  }
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= a.dhw) return;
+  const float* px = a.x + b * a.x_bstride + (int64_t)c * a.dhw;
+  float* py = a.y + b * a.y_bstride + (int64_t)(a.y_ch0 + c) * a.dhw;
+  auto one = [&](float xv) {
+    const float v = fmaf(xv, sc, sh);
+    return a.relu ? fmaxf(v, 0.f) : v;
+  };
+  if ((a.dhw & 3) == 0 && (((reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(py)) & 15) == 0)) {
+    const float4 xv = *reinterpret_cast<const float4*>(px + i0);
+    *reinterpret_cast<float4*>(py + i0) = make_float4(one(xv.x), one(xv.y), one(xv.z), one(xv.w));
+  } else {
+    for (int k = 0; k < 4 && i0 + k < a.dhw; ++k) py[i0 + k] = one(px[i0 + k]);
+  }
+}
+
+struct BnCoeffApplyArgs {
+  const float* part;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  float* dgamma;
+  float* dbeta;
+  const float* dy;
+  const float* x;
+  float* dx;
+  int64_t dy_bstride, x_bstride, dx_bstride, dhw;
+  int nparts, training, accumulate, relu, dy_ch0;
+  double n;
+};
+__global__ __launch_bounds__(256) void bn_coeffs_apply_kernel(BnCoeffApplyArgs a) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  double sg, sgx;
+  block_pair_sum(a.part, a.nparts, c, sg, sgx);
+  const double mean = a.mean[c], invstd = a.invstd[c], scd = a.scale[c];
+  const double sgxh = invstd * (sgx - mean * sg);          // sum of g * xhat
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + (float)sgxh;
+    if (a.dbeta) a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + (float)sg;
+  }
+  float k1 = (float)scd, k2 = 0.f, k3 = 0.f;
+  if (a.training) {
+    const double mg = sg / a.n, mgxh = sgxh / a.n;
+    k2 = (float)(-scd * invstd * mgxh);
+    k3 = (float)(scd * (invstd * mean * mgxh - mg));
+  }
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= a.dhw) return;
+  const float* px = a.x + b * a.x_bstride + (int64_t)c * a.dhw;
+  const float* pg = a.dy + b * a.dy_bstride + (int64_t)(a.dy_ch0 + c) * a.dhw;
+  float* po = a.dx + b * a.dx_bstride + (int64_t)c * a.dhw;
+  const float sc = a.scale[c], sh = a.shift[c];
+  auto one = [&](float g, float xv) {
+    if (a.relu && fmaf(xv, sc, sh) <= 0.f) g = 0.f;
+    return fmaf(g, k1, fmaf(xv, k2, k3));
+  };
+  const uintptr_t al = reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(pg) | reinterpret_cast<uintptr_t>(po);
+  if ((a.dhw & 3) == 0 && (al & 15) == 0) {
+    const float4 g4 = *reinterpret_cast<const float4*>(pg + i0), x4 = *reinterpret_cast<const float4*>(px + i0);
+    *reinterpret_cast<float4*>(po + i0) = make_float4(one(g4.x, x4.x), one(g4.y, x4.y), one(g4.z, x4.z), one(g4.w, x4.w));
+  } else {
+    for (int k = 0; k < 4 && i0 + k < a.dhw; ++k) po[i0 + k] = one(pg[i0 + k], px[i0 + k]);
+  }
+}
+
 // dx[b, c] = g * c1[c] + x * c2[c] + c3[c]   (train-mode BN backward is linear in g and x per channel; eval: c2 = c3 = 0)
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ dy, int64_t dy_bstride, int dy_ch0,
                                                                const float* __restrict__ x, int64_t x_bstride,
@@ -685,7 +783,8 @@ __global__ __launch_bounds__(256) void disparity_regression_bwd_kernel(const flo
 namespace ragmi {
 static unsigned reduce_blocks(int B, int C, int64_t DHW) {
   const int64_t want = ceil_div(4096, (int64_t)B * C);
-  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, ceil_div(DHW, 1024)), 256));
+  // <= 256 partials per channel (gx * B): the fused second halves re-reduce them in every workgroup
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, ceil_div(DHW, 1024)), std::max(1, 256 / B)));
 }
 }  // namespace ragmi
 
@@ -711,6 +810,49 @@ extern "C" int ragmi_bn_train_stats_fwd(const void* x, int64_t x_bstride, int B,
                    (double)B * (double)DHW, eps, momentum};
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, a);
   return check_launch("bn_train_stats");
+}
+
+extern "C" int ragmi_bn_train_act_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, const void* gamma, const void* beta,
+                                      void* running_mean, void* running_var, void* num_batches_tracked, float momentum, float eps,
+                                      int relu, void* workspace, void* mean, void* invstd, void* scale, void* shift, void* y,
+                                      int64_t y_bstride, int y_ch0, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && gamma && beta && workspace && mean && invstd && scale && shift && y, RAGMI_EINVAL, "bn_train_act: null pointer");
+  RAGMI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), RAGMI_EINVAL, "bn_train_act: running_mean/var go together");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_train_act: bad size");
+  RAGMI_REQUIRE(momentum >= 0.f && momentum <= 1.f, RAGMI_EUNSUPPORTED, "bn_train_act: momentum must be in [0,1] (cumulative average not built)");
+  const unsigned gx = reduce_blocks(B, C, DHW);
+  const int nparts = (int)(gx * B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, C, B), dim3(256), 0, st, (const float*)x, x_bstride, DHW, (float*)workspace, nparts);
+  BnFinActArgs a{};
+  a.f = BnFinalizeArgs{(const float*)workspace, (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var,
+                       (long long*)num_batches_tracked, (float*)mean, (float*)invstd, (float*)scale, (float*)shift, nparts,
+                       (double)B * (double)DHW, eps, momentum};
+  a.x = (const float*)x; a.y = (float*)y; a.x_bstride = x_bstride; a.y_bstride = y_bstride; a.dhw = DHW; a.y_ch0 = y_ch0; a.relu = relu;
+  hipLaunchKernelGGL(bn_finalize_act_kernel, dim3((unsigned)ceil_div(DHW, 1024), C, B), dim3(256), 0, st, a);
+  return check_launch("bn_train_act");
+}
+
+extern "C" int ragmi_bn_act_bwd(const void* dy, int64_t dy_bstride, int dy_ch0, const void* x, int64_t x_bstride, const void* scale,
+                                const void* shift, int relu, const void* mean, const void* invstd, int training, int B, int C,
+                                int64_t DHW, void* workspace, void* dx, int64_t dx_bstride, void* dgamma, void* dbeta, int accumulate,
+                                void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(dy && x && scale && shift && mean && invstd && workspace && dx, RAGMI_EINVAL, "bn_act_bwd: null pointer");
+  RAGMI_REQUIRE(B > 0 && C > 0 && DHW > 0 && B <= 65535 && C <= 65535, RAGMI_EINVAL, "bn_act_bwd: bad size");
+  const unsigned gx = reduce_blocks(B, C, DHW);
+  const int nparts = (int)(gx * B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(gx, C, B), dim3(256), 0, st, (const float*)dy, dy_bstride, dy_ch0, (const float*)x,
+                     x_bstride, (const float*)scale, (const float*)shift, relu, DHW, (float*)workspace, nparts);
+  BnCoeffApplyArgs a{};
+  a.part = (const float*)workspace; a.mean = (const float*)mean; a.invstd = (const float*)invstd; a.scale = (const float*)scale;
+  a.shift = (const float*)shift; a.dgamma = (float*)dgamma; a.dbeta = (float*)dbeta; a.dy = (const float*)dy; a.x = (const float*)x;
+  a.dx = (float*)dx; a.dy_bstride = dy_bstride; a.x_bstride = x_bstride; a.dx_bstride = dx_bstride; a.dhw = DHW; a.nparts = nparts;
+  a.training = training ? 1 : 0; a.accumulate = accumulate ? 1 : 0; a.relu = relu; a.dy_ch0 = dy_ch0; a.n = (double)B * (double)DHW;
+  hipLaunchKernelGGL(bn_coeffs_apply_kernel, dim3((unsigned)ceil_div(DHW, 1024), C, B), dim3(256), 0, st, a);
+  return check_launch("bn_act_bwd");
 }
 
 extern "C" int ragmi_bn_act_fwd(const void* x, int64_t x_bstride, const void* scale, const void* shift, int relu, const void* res,

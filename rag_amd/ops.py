@@ -407,6 +407,44 @@ def bn_train_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, run
     return out
 
 
+def bn_train_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
+                 running_var: Optional[torch.Tensor], num_batches_tracked: Optional[torch.Tensor], momentum: float, eps: float, relu: bool):
+    """Train-mode BatchNorm + ReLU of the raw conv output x as two launches (ragmi_bn_train_act_fwd): returns (y, stats) with
+    stats the [4, C] tensor (mean, invstd, scale, shift); the running statistics are updated in place."""
+    _need_gpu(x, gamma, beta, running_mean, running_var)
+    B, C = x.shape[:2]
+    lib = load_library()
+    ws = torch.empty((lib.ragmi_bn_workspace_elems(B, C, _vol(x)),), device=x.device, dtype=torch.float32)
+    st = torch.empty((4, C), device=x.device, dtype=torch.float32)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise RuntimeError("bn_train_act: num_batches_tracked must be int64")
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(lib.ragmi_bn_train_act_fwd(x.data_ptr(), _planes(x), B, C, _vol(x), gamma.data_ptr(), beta.data_ptr(), p(running_mean),
+                                     p(running_var), p(num_batches_tracked), float(momentum), float(eps), int(relu), ws.data_ptr(),
+                                     st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), y.data_ptr(), _planes(y), 0,
+                                     _stream()), "bn_train_act")
+    return y, st
+
+
+def bn_act_bwd(dy: torch.Tensor, x: torch.Tensor, scale, shift, relu: bool, mean, invstd, training: bool,
+               out: Optional[torch.Tensor] = None, dgamma_into: Optional[torch.Tensor] = None, dbeta_into: Optional[torch.Tensor] = None):
+    """ReLU + BatchNorm adjoint as two launches (ragmi_bn_act_bwd): returns (dx, dgamma, dbeta); with `dgamma_into` / `dbeta_into`
+    the parameter gradients are accumulated into those tensors and None is returned for them."""
+    _need_gpu(dy, x, scale, shift, mean, invstd, out, dgamma_into, dbeta_into)
+    B, C = x.shape[:2]
+    lib = load_library()
+    ws = torch.empty((lib.ragmi_bn_workspace_elems(B, C, _vol(x)),), device=x.device, dtype=torch.float32)
+    dx = out if out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    direct = dgamma_into is not None and dbeta_into is not None
+    gb = None if direct else torch.empty((2, C), device=x.device, dtype=torch.float32)
+    dg, db = (dgamma_into, dbeta_into) if direct else (gb[0], gb[1])
+    check(lib.ragmi_bn_act_bwd(dy.data_ptr(), _planes(dy), 0, x.data_ptr(), _planes(x), scale.data_ptr(), shift.data_ptr(), int(relu),
+                               mean.data_ptr(), invstd.data_ptr(), int(training), B, C, _vol(x), ws.data_ptr(), dx.data_ptr(), _planes(dx),
+                               dg.data_ptr(), db.data_ptr(), int(direct), _stream()), "bn_act_bwd")
+    return dx, (None if direct else gb[0]), (None if direct else gb[1])
+
+
 def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool, out: Optional[torch.Tensor] = None,
            out_ch0: int = 0, res: Optional[torch.Tensor] = None, res_ch0: int = 0) -> torch.Tensor:
     """out[:, ch0:ch0+C] = act(x * scale + shift) (+ res[:, res_ch0:+C])."""

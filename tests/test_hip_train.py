@@ -64,6 +64,36 @@ def test_bn_train_stats_and_affine(ra, shape):
     close(y, F.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)), 1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 6, 9, 13), (1, 4, 12, 24, 32), (3, 2, 1, 7, 5)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bn_fused_forward_and_adjoint(ra, shape, relu):
+    """ragmi_bn_train_act_fwd / ragmi_bn_act_bwd (two launches each) against torch's train-mode batch_norm + relu and its autograd."""
+    C = shape[1]
+    x = (torch.randn(shape, generator=gen(1)) * 2 + 0.5).requires_grad_(True)
+    gm = (torch.rand(C, generator=gen(2)) + 0.5).requires_grad_(True)
+    bt = torch.randn(C, generator=gen(3)).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=gen(4)), torch.rand(C, generator=gen(5)) + 0.5
+    rm_g, rv_g, nbt = gpu(rm), gpu(rv), torch.zeros((), dtype=torch.int64, device=DEV)
+    y, st = ra.ops.bn_train_act(gpu(x.detach()), gpu(gm.detach()), gpu(bt.detach()), rm_g, rv_g, nbt, 0.1, 1e-5, relu)
+    yr = F.batch_norm(x, rm, rv, gm, bt, training=True, momentum=0.1, eps=1e-5)
+    yr = F.relu(yr) if relu else yr
+    close(y, yr.detach(), 1e-5, "y")
+    close(rm_g, rm, 1e-5, "running_mean")
+    close(rv_g, rv, 1e-5, "running_var")
+    assert int(nbt) == 1
+    dy = torch.randn(shape, generator=gen(6))
+    yr.backward(dy)
+    dx, dg, db = ra.ops.bn_act_bwd(gpu(dy), gpu(x.detach()), st[2], st[3], relu, st[0], st[1], True)
+    close(dx, x.grad, 2e-5, "dx")
+    close(dg, gm.grad, 2e-5, "dgamma")
+    close(db, bt.grad, 2e-5, "dbeta")
+    # accumulate-into form adds to what is there
+    tg, tb = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    ra.ops.bn_act_bwd(gpu(dy), gpu(x.detach()), st[2], st[3], relu, st[0], st[1], True, dgamma_into=tg, dbeta_into=tb)
+    close(tg - 1, gm.grad, 2e-5, "dgamma +=")
+    close(tb - 1, bt.grad, 2e-5, "dbeta +=")
+
+
 def _convbr_case(ra, cin, cout, k, bn, relu, bn_training, shape, seed, ndim=3, train_params=True):
     """(module on the GPU, x, torch-CPU reference function)"""
     cls = ra.ConvBR_3d if ndim == 3 else ra.ConvBR_2d
