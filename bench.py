@@ -231,14 +231,14 @@ def train_bench(args, device, dist, rank, n_gpus):
     Matching Net -> Disp -> masked smooth-L1 -> backward -> flat-bucket gradient all-reduce (RCCL) -> clip -> SGD,
     forward and backward on the HIP kernels (rag_amd.autograd).  All units trainable (task 0 of the growth loop)."""
     import rag_amd
-    from rag_amd.train import GradBucket, GraphedTrainStep, make_optimizer, train_step
+    from rag_amd.train import GradBucket, GraphedTrainStep, exchange_and_update, make_optimizer, train_step
     B = args.batch if args.batch > 1 else TRAIN_B
     torch.manual_seed(0)                                   # identical replicas
     net = rag_amd.Network(rag_amd.ALL_CONV_GENOTYPE, device, maxdisp=MAXDISP)
     randomize_bn(net, 1)
     net = net.to(device).train()
     bucket = GradBucket(net.parameters())
-    opt = make_optimizer(net.parameters())
+    opt = make_optimizer(net.parameters(), bucket=bucket)
     g = torch.Generator().manual_seed(1234 + rank)         # each replica its own shard of the global batch
     left = torch.randn((B, 3, TRAIN_H, TRAIN_W), generator=g).to(device)
     right = torch.randn((B, 3, TRAIN_H, TRAIN_W), generator=g).to(device)
@@ -271,9 +271,7 @@ def train_bench(args, device, dist, rank, n_gpus):
     bucket.zero()
     loss.backward()
     ev[2].record()
-    bucket.all_reduce_mean(dist)
-    bucket.clip_(5.0)
-    opt.step()
+    exchange_and_update(opt, bucket, clip=5.0, dist=dist)
     ev[3].record()
     torch.cuda.synchronize()
     phases = {"forward_ms": round(ev[0].elapsed_time(ev[1]), 3), "backward_ms": round(ev[1].elapsed_time(ev[2]), 3),
@@ -351,6 +349,8 @@ def main():
         n_gpus = 1
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    # everything (eager launches, hipGraph replays, timing events) on ONE explicit stream rather than the legacy null stream
+    torch.cuda.set_stream(torch.cuda.Stream(device))
 
     import rag_amd
     rag_amd.load_library()          # fail loudly if the HIP extension is missing

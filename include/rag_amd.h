@@ -361,6 +361,15 @@ int ragmi_stereo_metrics_fwd(const void* disp_est, const void* disp_gt, int B, i
 int ragmi_masked_smooth_l1_bwd(const void* disp_est, const void* disp_gt, const void* out, const void* gout, void* ddisp,
                                int B, int H, int W, float maxdisp, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * clip_grad_norm_(max_norm) + torch.optim.SGD(lr, momentum, weight_decay).step() over flat fp32 buffers of n elements
+ * (approaches/rag.py:64-70, 215-216) as two launches: g *= min(1, max_norm/(||g||+1e-6)) (max_norm <= 0: no clipping);
+ * d = g + weight_decay*p; buf = first_step ? d : momentum*buf + d; p -= lr*buf.  norm_out (may be NULL) receives ||g|| before
+ * clipping; workspace: ragmi_sgd_workspace_bytes() bytes of device scratch. */
+int64_t ragmi_sgd_workspace_bytes(void);
+int ragmi_sgd_clip_step(void* param, void* grad, void* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                        float max_norm, int first_step, void* workspace, void* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,7 +143,7 @@ def _bn_backward(dy, raw, scale, shift, mean, invstd, mod, n, training, need_g, 
     dgamma / dbeta come back as None when they were accumulated straight into bucket-backed .grad tensors."""
     if not (mod.use_bn or mod.relu):
         if out is not None:
-            out.copy_(dy)
+            torch.mul(dy, 1.0, out=out)       # a kernel: contiguous copy_ would be a memcpy node in a captured step
             return out, None, None
         return dy, None, None
     dgamma = dbeta = None

@@ -8,6 +8,11 @@ namespace ragmi {
 
 constexpr int MET_N = 8;   // per image: n_mask, n_gt_pos, sum smooth-L1, sum |e|, n_D1, n_thr1, n_thr2, n_thr3
 
+__global__ __launch_bounds__(256) void zero_floats_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void stereo_metrics_kernel(const float* __restrict__ est, const float* __restrict__ gt, int64_t hw,
                                                              float maxdisp, float* __restrict__ acc) {
   const int b = blockIdx.y;
@@ -85,7 +90,9 @@ extern "C" int ragmi_stereo_metrics_fwd(const void* disp_est, const void* disp_g
   RAGMI_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535, RAGMI_EINVAL, "stereo_metrics: bad size");
   const int64_t hw = (int64_t)H * W;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(acc, 0, sizeof(float) * MET_N * B, st) != hipSuccess) return fail(RAGMI_ELAUNCH, "stereo_metrics: memset failed");
+  // zeroed by a kernel, not hipMemsetAsync: memset / memcpy nodes of a captured hipGraph are corrupted by memcpys issued on the null
+  // stream between replays, so nothing on the training path may become one
+  hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)ceil_div((int64_t)MET_N * B, 256)), dim3(256), 0, st, (float*)acc, MET_N * B);
   const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(hw, 1024), 64));
   hipLaunchKernelGGL(stereo_metrics_kernel, dim3(gx, B), dim3(256), 0, st, (const float*)disp_est, (const float*)disp_gt, hw, maxdisp,
                      (float*)acc);

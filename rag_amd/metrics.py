@@ -61,7 +61,7 @@ class MaskedSmoothL1Fn(torch.autograd.Function):
         out = _raw(est, disp_gt, maxdisp)
         ctx.save_for_backward(est, disp_gt.contiguous(), out)
         ctx.maxdisp = float(maxdisp)
-        return out[0].clone()
+        return out[0] * 1.0          # a kernel, not a memcpy (see ragmi_stereo_metrics_fwd on hipGraph memcpy nodes)
 
     @staticmethod
     def backward(ctx, gout):

@@ -495,7 +495,7 @@ class _Cell(nn.Module):
                         del ids[:2]
                     else:
                         bs, cs = where[ids.pop(0)]
-                        buf[:, ch:ch + C].copy_(bs[:, cs:cs + C])   # lone identity: plain device copy
+                        torch.mul(bs[:, cs:cs + C], 1, out=buf[:, ch:ch + C])   # lone identity: a copy KERNEL (no memcpy node when captured)
                     written[k] = True
                 else:
                     bs, cs = where[ids.pop(0)]

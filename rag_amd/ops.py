@@ -609,3 +609,22 @@ def conv3d_k3_uses_x3(cin: int, cout: int, B: int, D: int, H: int, W: int, nset:
                       dtype: torch.dtype = torch.float32) -> bool:
     """True when conv3d_k3 (nset=1) / conv3d_k3_dual (nset=2, cin = both inputs) runs this shape on the bf16x3 kernel."""
     return bool(load_library().ragmi_conv3d_k3_uses_x3(cin, cout, B, D, H, W, nset, int(has_res), ntail, _DT[dtype]))
+
+
+def sgd_clip_step(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float,
+                  max_norm: float, first_step: bool, workspace: Optional[torch.Tensor] = None,
+                  norm_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """clip_grad_norm_ + SGD step over flat fp32 buffers in place (ragmi_sgd_clip_step); returns the 1-element total-norm tensor."""
+    _need_gpu(param, grad, buf, workspace, norm_out)
+    for t in (param, grad, buf):
+        if t.dim() != 1 or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != param.numel():
+            raise RuntimeError("sgd_clip_step: param / grad / momentum buffers must be flat contiguous fp32 of equal length")
+    lib = load_library()
+    if workspace is None:
+        workspace = torch.empty((lib.ragmi_sgd_workspace_bytes() // 4,), device=param.device, dtype=torch.float32)
+    if norm_out is None:
+        norm_out = torch.empty((1,), device=param.device, dtype=torch.float32)
+    check(lib.ragmi_sgd_clip_step(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(), float(lr), float(momentum),
+                                  float(weight_decay), float(max_norm), int(first_step), workspace.data_ptr(), norm_out.data_ptr(),
+                                  _stream()), "sgd_clip_step")
+    return norm_out

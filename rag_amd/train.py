@@ -79,9 +79,59 @@ def forward_backward(net, bucket: GradBucket, left, right, gt, *, task_arch=None
     return loss.detach()
 
 
+class FlatSGD:
+    """torch.optim.SGD(lr, momentum, weight_decay) of rag.py:64-70 over a GradBucket, with the parameters themselves moved
+    into one flat buffer next to the flat gradient: clip_grad_norm_ + step is then ONE pair of HIP launches
+    (ragmi_sgd_clip_step) instead of torch's multi-tensor launches over ~500 small tensors.  GPU only (no CPU fallback: on
+    the CPU use torch.optim.SGD via make_optimizer).  `param_groups[0]["lr"]` may be changed between steps like torch's."""
+
+    def __init__(self, bucket: GradBucket, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 3e-3):
+        if not bucket.flat.is_cuda:
+            raise RuntimeError("FlatSGD runs on the MI355X only; use make_optimizer (torch.optim.SGD) for CPU tensors")
+        self.bucket = bucket
+        self.param_groups = [dict(params=bucket.params, lr=lr, momentum=momentum, weight_decay=weight_decay)]
+        self.flat = torch.empty_like(bucket.flat)
+        off = 0
+        for p in bucket.params:                       # parameters become views of one buffer (values kept)
+            v = self.flat[off:off + p.numel()].view_as(p)
+            v.copy_(p.detach())
+            p.data = v
+            off += p.numel()
+        self.momentum_buffer = torch.zeros_like(self.flat)
+        self.steps = 0
+        from . import ops
+        self._ops = ops
+        self._ws = torch.empty((ops.load_library().ragmi_sgd_workspace_bytes() // 4,), device=self.flat.device, dtype=torch.float32)
+        self.total_norm = torch.zeros((1,), device=self.flat.device, dtype=torch.float32)
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.bucket.zero()
+
+    def step(self, clip: float = 0.0) -> torch.Tensor:
+        """clip_grad_norm_(clip) (clip <= 0: none) + SGD step; returns the pre-clip total gradient norm (device tensor)."""
+        g = self.param_groups[0]
+        self._ops.sgd_clip_step(self.flat, self.bucket.flat, self.momentum_buffer, g["lr"], g["momentum"], g["weight_decay"], clip,
+                                self.steps == 0 or g["momentum"] == 0.0, self._ws, self.total_norm)
+        self.steps += 1
+        torch.autograd.graph.increment_version(self.bucket.params)       # packed-weight caches key on ._version
+        return self.total_norm
+
+    def state_dict(self):
+        return {"momentum_buffer": self.momentum_buffer.clone(), "steps": self.steps,
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd) -> None:
+        self.momentum_buffer.copy_(sd["momentum_buffer"])
+        self.steps = int(sd["steps"])
+        self.param_groups[0].update(sd["param_groups"][0])
+
+
 def exchange_and_update(optimizer, bucket: GradBucket, *, clip: float = 5.0, dist=None) -> None:
     """gradient all-reduce (mean over replicas) -> clip_grad_norm_ -> optimizer step (rag.py:215-216)."""
     bucket.all_reduce_mean(dist)
+    if isinstance(optimizer, FlatSGD):
+        optimizer.step(clip)
+        return
     bucket.clip_(clip)
     optimizer.step()
 
@@ -98,7 +148,12 @@ class GraphedTrainStep:
     """The same step with forward + loss + backward replayed as ONE captured hipGraph (the ~2500 kernel launches of a
     step cost more host time than GPU time when issued one by one); the gradient exchange, clipping and the optimizer
     step stay eager (a handful of launches, and the collective stays outside the graph).  Inputs are copied into static
-    buffers; shapes, the architecture and which parameters train must not change after capture."""
+    buffers; shapes, the architecture and which parameters train must not change after capture.
+
+    Nothing on the captured path may be a memset or memcpy NODE (hipMemsetAsync, a contiguous same-dtype copy_/clone):
+    on this runtime a memcpy issued on the null stream between two replays (a `.item()`, a `.clone()`) corrupts such nodes
+    of an instantiated graph and the next replay computes garbage — measured: 6-7 of 8 runs with one 160-byte memset and one
+    4-byte clone in the graph, 0 of 16 once both were kernels (tests/test_hip_train.py drives exactly that pattern)."""
 
     def __init__(self, net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
                  features: bool = False, warmup: int = 2):
@@ -125,6 +180,8 @@ class GraphedTrainStep:
         return self.loss
 
 
-def make_optimizer(params, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 3e-3):
-    """rag.py:64-70: SGD over the parameters that require grad."""
+def make_optimizer(params, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 3e-3, bucket: Optional[GradBucket] = None):
+    """rag.py:64-70: SGD over the parameters that require grad.  With `bucket` (on the GPU): the fused flat-buffer FlatSGD."""
+    if bucket is not None and bucket.flat.is_cuda:
+        return FlatSGD(bucket, lr=lr, momentum=momentum, weight_decay=weight_decay)
     return torch.optim.SGD([p for p in params if p.requires_grad], lr=lr, momentum=momentum, weight_decay=weight_decay)

@@ -384,8 +384,12 @@ def test_sgd_step_changes_only_trained_units(ra):
             assert not same, k
 
 
-def test_graphed_train_step_matches_eager(ra):
-    """forward+backward replayed as one hipGraph (rag_amd.train.GraphedTrainStep) == the eager step, three steps in a row."""
+@pytest.mark.parametrize("flat", [False, True])
+def test_graphed_train_step_matches_eager(ra, flat):
+    """forward+backward replayed as one hipGraph (rag_amd.train.GraphedTrainStep) == the eager step, three steps in a row, with
+    torch.optim.SGD and with the fused FlatSGD.  The graphed loop is driven from the default stream with a device sync before
+    every step and no host read in between — the pattern under which work queued behind a hipGraphLaunch on the null stream
+    overtook the graph's tail (GraphedTrainStep now replays on a stream of its own)."""
     from rag_amd.train import GradBucket, GraphedTrainStep, make_optimizer, train_step
     g = load_golden("g6_train_step")
     maxdisp = int(g["maxdisp"])
@@ -399,12 +403,17 @@ def test_graphed_train_step_matches_eager(ra):
         net.stem3d0[0].eval()
         net.modify_param({"stem_3d0": [0]}, requires_grad=False)
         bucket = GradBucket(net.parameters())
-        opt = make_optimizer(net.parameters(), lr=1e-3)
+        opt = make_optimizer(net.parameters(), lr=1e-3, bucket=bucket if flat else None)
         losses = []
         if graphed:
             # the capture warm-up runs optimisation steps too: give the eager run the same number of steps
             step = GraphedTrainStep(net, opt, bucket, left, right, gt, warmup=2)
-            losses = [None, None] + [float(step()) for _ in range(3)]
+            held = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                held.append(step().clone())
+            torch.cuda.synchronize()
+            losses = [None, None] + [float(x) for x in held]
         else:
             losses = [float(train_step(net, opt, bucket, left, right, gt)) for _ in range(5)]
         finals.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
@@ -415,6 +424,51 @@ def test_graphed_train_step_matches_eager(ra):
         assert abs(a - b) < 2e-3 * max(1.0, abs(a)), (l0, l1)
     for k in s0:
         close(s1[k].float(), s0[k].float(), 5e-3, k)
+
+
+@pytest.mark.parametrize("n,clip,wd", [(1000, 5.0, 3e-3), (735024 // 4, 0.05, 3e-3), (77, 0.0, 0.0)])
+def test_sgd_clip_step_vs_torch(ra, n, clip, wd):
+    """ragmi_sgd_clip_step == clip_grad_norm_ + torch.optim.SGD(momentum 0.9, weight decay) for three steps (rag.py:64-70, 215-216)."""
+    p_ref = torch.nn.Parameter(torch.randn(n, generator=gen(81)))
+    opt = torch.optim.SGD([p_ref], lr=1e-2, momentum=0.9, weight_decay=wd)
+    p, buf = gpu(p_ref.detach().clone()), torch.zeros(n, device=DEV)
+    for step in range(3):
+        g = torch.randn(n, generator=gen(82 + step)) * (0.3 if step != 1 else 1e-3)       # step 1: norm below the clip threshold
+        p_ref.grad = g.clone()
+        total_ref = torch.nn.utils.clip_grad_norm_([p_ref], clip) if clip > 0 else torch.linalg.vector_norm(g)
+        opt.step()
+        g_dev = gpu(g)
+        total = ra.ops.sgd_clip_step(p, g_dev, buf, 1e-2, 0.9, wd, clip, step == 0)
+        close(total, total_ref.reshape(1), 3e-6, f"norm {step}")   # torch accumulates the norm in fp32
+        close(g_dev, p_ref.grad, 1e-6, f"clipped grad {step}")
+        close(p, p_ref.detach(), 1e-6, f"param {step}")
+        close(buf, opt.state[p_ref]["momentum_buffer"], 1e-6, f"momentum {step}")
+
+
+def test_flat_sgd_step_matches_torch_sgd(ra):
+    """The training step with rag_amd.train.FlatSGD (parameters and gradients in flat buffers, one fused clip + update) ends in
+    the same state as with clip_grad_norm_ + torch.optim.SGD; weight caches see the in-place update (loss keeps moving)."""
+    from rag_amd.train import FlatSGD, GradBucket, make_optimizer, train_step
+    g = load_golden("g6_train_step")
+    maxdisp = int(g["maxdisp"])
+    rows = g["rows"]
+    left, right, gt = gpu(g["left"]), gpu(g["right"]), gpu(g["gt"])
+    finals = []
+    for flat in (False, True):
+        net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=maxdisp)
+        net.load_state_dict(split_sd(g), strict=True)
+        net = net.to(DEV).train()
+        bucket = GradBucket(net.parameters())
+        opt = make_optimizer(net.parameters(), lr=1e-3, bucket=bucket if flat else None)
+        assert isinstance(opt, FlatSGD) == flat
+        losses = [float(train_step(net, opt, bucket, left, right, gt)) for _ in range(3)]
+        finals.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    (l0, s0), (l1, s1) = finals
+    assert l0[0] != l0[1] and l1[0] != l1[1]
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < 1e-3 * max(1.0, abs(a)), (l0, l1)
+    for k in s0:
+        close(s1[k].float(), s0[k].float(), 2e-3, k)
 
 
 # --------------------------------------------------------------------------- fused loss + metrics (SURVEY 8(f) N3)
