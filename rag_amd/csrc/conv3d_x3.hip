@@ -21,8 +21,10 @@ typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 // for a 2-deep box tile), the next plane travels HBM -> registers while the current one is multiplied.
 constexpr int X3_TY = 8, X3_TX = 32;
 constexpr int X3_HY = X3_TY + 2, X3_HX = X3_TX + 2, X3_PL = X3_HY * X3_HX;   // one halo plane: 340 voxels
-constexpr int X3_THREADS = 256, X3_WAVES = X3_THREADS / 64;
-constexpr int X3_NT = X3_TY * X3_TX / 16 / X3_WAVES;                  // 16-voxel column tiles per wave per plane (4)
+constexpr int X3_THREADS = 512, X3_WAVES = X3_THREADS / 64;
+// 8 waves per workgroup, two column tiles each: at <= 128 VGPRs two workgroups (4 waves per SIMD) share a CU, which hides the
+// LDS-read latency in front of every MFMA group far better than 4 waves x 4 tiles at 248 VGPRs did (557 -> 601 maps/s)
+constexpr int X3_NT = X3_TY * X3_TX / 16 / X3_WAVES;                  // 16-voxel column tiles per wave per plane (2)
 
 __device__ __forceinline__ unsigned short x3_bf16_rn(float v) {
   unsigned u = __float_as_uint(v);
@@ -87,7 +89,7 @@ struct X3Extra {
 // T = activation storage: float (three MFMAs per product) or bf16_t (the activations ARE bf16: no lo copy, two MFMAs per
 // product — weight hi and lo — and half the LDS operand traffic)
 template <class T, int NCG, int NSET>
-__global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 2 : 1)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
+__global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
@@ -355,7 +357,9 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0), ncgs = ncg / nset, nsls = (ncgs * 27 + 7) / 8, nsl = nset * nsls;
   a.tiles_x = (int)ceil_div(a.W, X3_TX); a.tiles_y = (int)ceil_div(a.H, X3_TY);
   const int ncog = (a.Cout + 15) / 16;
-  // depth segments: enough independent (column, segment) work items to fill several workgroups per CU, at least 8 planes each
+  // depth segments: enough independent (column, segment) work items to fill several workgroups per CU, at least 8 planes each.
+  // (Measured on the level-3 volumes: 2..16 segments and grids of 512 / 1024 / all items are within +-5 %; a model that minimises
+  // rounds x (planes + 2 halo planes) picked 2 segments and was 3-5 % slower than this rule.)
   const int64_t cols = (int64_t)a.tiles_x * a.tiles_y * a.B;
   const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(1536, cols * ncog), ceil_div(a.D, 8)));
   e.seg_len = (int)ceil_div(a.D, nseg);

@@ -1,0 +1,48 @@
+"""Kernel-by-kernel timeline of ONE headline forward pass from a rocprofv3 kernel trace.
+
+    cd /tmp && rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
+    python tools/step_timeline.py <dir> > profiles/rNN_step_timeline.txt
+
+The pass is found as the last run of dispatches that starts with costvol_stem_planes_kernel and ends with disp_softargmin_kernel.
+"""
+import csv
+import glob
+import re
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("ragmi::", "")
+    return re.sub(r"\(.*$", "", name)
+
+
+def main(root: str) -> None:
+    files = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)
+    if not files:
+        raise SystemExit("no *kernel_trace.csv under " + root)
+    rows = []
+    with open(files[0]) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    starts = [i for i, r in enumerate(rows) if "costvol_stem_planes_kernel" in r[2]]
+    ends = [i for i, r in enumerate(rows) if "disp_softargmin_kernel" in r[2]]
+    if not starts or not ends:
+        raise SystemExit("no forward pass found")
+    # the last complete pass that belongs to the Matching-Net bench (planes ... disp with no other planes in between)
+    e = ends[-1]
+    s = max(i for i in starts if i < e)
+    t0 = rows[s][0]
+    print("start_us  dur_us  gap_us  kernel")
+    prev_end = t0
+    total = 0.0
+    for st, en, name in rows[s:e + 1]:
+        print(f"{(st - t0) / 1e3:8.1f} {(en - st) / 1e3:7.1f} {(st - prev_end) / 1e3:7.1f}  {short(name)}")
+        prev_end = en
+        total += (en - st) / 1e3
+    print(f"# wall {(rows[e][1] - t0) / 1e3:.1f} us, kernel time {total:.1f} us, {e - s + 1} launches")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else ".")
