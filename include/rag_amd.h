@@ -207,6 +207,14 @@ int ragmi_trilinear3d_fwd(const void* x, void* y, int B, int C,
                           int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                           int align_corners, int dtype, void* stream);
 
+/* The same resample reading a channel slice (x_bstride elements between batch items) and writing y[b, y_ch0 + c] of a wider
+ * buffer (y_bstride), with an optional ReLU after the interpolation.  It is the second half of an UPSAMPLING
+ * `ConvBR_3d(1x1x1)(F.interpolate(x))` (rag_model.py:150-155, 358-365) run conv-first: the channel mix and the folded BatchNorm
+ * are affine and the taps sum to one, so act(bn(conv(interp(x)))) == act(interp(bn(conv(x)))) and the mix runs on 1/8 of
+ * the voxels. */
+int ragmi_trilinear3d_act_fwd(const void* x, int64_t x_bstride, void* y, int64_t y_bstride, int y_ch0, int relu, int B, int C,
+                              int Di, int Hi, int Wi, int Do, int Ho, int Wo, int align_corners, int dtype, void* stream);
+
 /*
  * Feature-Net stem: 2-D 3x3 / pad 1 / stride `stride` ConvBR (stem2d1 = ConvBR_2d(6, 12, 3,
  * stride=3, padding=1), rag_model.py:201).  x: [B, Cin, H, W] -> y: [B, Cout, (H-1)/stride+1, (W-1)/stride+1].

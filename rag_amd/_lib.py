@@ -62,6 +62,8 @@ SIGNATURES = {
     "ragmi_conv3d_k1_resample_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                              c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k1_resample_pair_fwd": (c_int, [c_k1r_p, c_k1r_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_trilinear3d_act_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_trilinear3d_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     "ragmi_conv2d_k3_strided_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -35,6 +35,15 @@ PRIMITIVES_3D = ["skip_connect_3d", "3d_conv_3x3"]
 ALL_CONV_ROWS = np.array([[0, 1], [1, 1], [2, 1], [3, 1], [5, 1], [6, 1]])
 ALL_SKIP_ROWS = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [5, 0], [6, 0]])
 ALL_CONV_GENOTYPE = Genotype(normal=ALL_CONV_ROWS, normal_concat=None, reduce=ALL_CONV_ROWS, reduce_concat=None)
+
+
+def _volume(size) -> int:
+    n = 1
+    for v in size:
+        n *= int(v)
+    return n
+
+
 ALL_SKIP_GENOTYPE = Genotype(normal=ALL_SKIP_ROWS, normal_concat=None, reduce=ALL_SKIP_ROWS, reduce_concat=None)
 
 
@@ -191,7 +200,14 @@ class _ConvBR(nn.Module):
                 raise NotImplementedError("ConvBR: fused resample is built for the 1x1x1 form only")
             if out is None:
                 out = torch.empty((x.shape[0], cout) + tuple(int(v) for v in resample_to), device=x.device, dtype=x.dtype)
-            ops.conv3d_k1_resample(x, resample_to, True, wk, scale, shift, self.relu, out, out_ch0)
+            if _volume(resample_to) > _volume(x.shape[2:]) and cout <= x.shape[1]:
+                # upsampling: mix the channels (and fold the BatchNorm) on the SMALL volume, then interpolate the Cout maps and
+                # apply the ReLU — both steps are affine and the taps sum to one, so only the rounding order differs
+                low = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
+                ops.conv3d_k1(x, wk, scale, shift, False, low)
+                ops.trilinear3d_act(low, resample_to, True, self.relu, out, out_ch0)
+            else:
+                ops.conv3d_k1_resample(x, resample_to, True, wk, scale, shift, self.relu, out, out_ch0)
             return out[:, :, 0] if squeeze else out
         if out is None:
             out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
@@ -457,7 +473,11 @@ class _Cell(nn.Module):
 
         # (buffer, first channel) of every state
         where: List[Tuple[torch.Tensor, int]] = []
-        if not pre_has[0] and not pre_has[1] and s0.shape[1] != C:
+        # an UP-sampled input runs conv-first through the ConvBR forward (channel mix on the small volume); everything else —
+        # down-sampling or an input already at the cell's size — shares one paired launch (measured: splitting an
+        # identity + down-sampling pair into two launches costs 43 us instead of 27)
+        grows = any(s is not None and _volume(size) > _volume(s.shape[2:]) and C <= s.shape[1] for s in (s0, s1))
+        if not pre_has[0] and not pre_has[1] and s0.shape[1] != C and not grows:
             # both 1x1x1 convs (each with its own fused resample) as ONE launch
             w0, sc0, sh0 = self.pre_preprocess.prepared()
             w1, sc1, sh1 = self.preprocess.prepared()

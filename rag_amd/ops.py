@@ -340,6 +340,19 @@ def trilinear3d(x: torch.Tensor, size: Sequence[int], align_corners: bool) -> to
     return out
 
 
+def trilinear3d_act(x: torch.Tensor, size: Sequence[int], align_corners: bool, relu: bool, out: torch.Tensor,
+                    out_ch0: int = 0) -> torch.Tensor:
+    """out[:, out_ch0:out_ch0+C] = act(F.interpolate(x, size, 'trilinear', align_corners)) — x may be a channel slice."""
+    dt = _act(x, out)
+    B, C, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = [int(s) for s in size]
+    if out_ch0 + C > out.shape[1] or tuple(out.shape[2:]) != (Do, Ho, Wo):
+        raise ValueError("trilinear3d_act: output buffer too small / wrong spatial size")
+    check(load_library().ragmi_trilinear3d_act_fwd(x.data_ptr(), _planes(x), out.data_ptr(), _planes(out), out_ch0, int(relu), B, C,
+                                                   Di, Hi, Wi, Do, Ho, Wo, int(bool(align_corners)), dt, _stream()), "trilinear3d_act")
+    return out
+
+
 def add(a: torch.Tensor, a_ch0: int, b: torch.Tensor, b_ch0: int, out: torch.Tensor, out_ch0: int, channels: int) -> torch.Tensor:
     """out[:, out_ch0:+C] = a[:, a_ch0:+C] + b[:, b_ch0:+C]."""
     dt = _act(a, b, out)
