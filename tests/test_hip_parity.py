@@ -261,6 +261,38 @@ def test_trilinear_vs_aten(ra, align, shape, size):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape,size", [((2, 5, 3, 4, 5), (6, 8, 10)), ((1, 8, 4, 8, 26), (8, 16, 52))])
+def test_trilinear_act_into_slice(ra, shape, size, relu):
+    """ragmi_trilinear3d_act_fwd: a channel SLICE of a wider tensor -> (ReLU of) its resample inside a wider output buffer."""
+    wide = torch.randn((shape[0], shape[1] + 3) + shape[2:], generator=gen(18))
+    x = wide[:, 2:2 + shape[1]]
+    ref = F.interpolate(x, size, mode="trilinear", align_corners=True)
+    ref = F.relu(ref) if relu else ref
+    out = torch.full((shape[0], shape[1] + 4) + tuple(size), 7.0, device=DEV)
+    ra.ops.trilinear3d_act(gpu(wide)[:, 2:2 + shape[1]], size, True, relu, out, 1)
+    np.testing.assert_allclose(out[:, 1:1 + shape[1]].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert float(out[:, 0].min()) == 7.0 and float(out[:, 1 + shape[1]:].min()) == 7.0          # neighbours untouched
+
+
+def test_convbr_upsample_runs_conv_first(ra):
+    """An up-sampling 1x1x1 ConvBR_3d (Cout <= Cin) mixes the channels on the small volume and interpolates afterwards
+    (rag_amd.modules._ConvBR.forward): same function as the reference order conv(interpolate(x)) up to rounding."""
+    torch.manual_seed(5)
+    m = ra.ConvBR_3d(24, 8, 1, 1, 0).eval()
+    with torch.no_grad():
+        m.bn.running_mean.normal_(0, 0.2)
+        m.bn.running_var.uniform_(0.5, 1.5)
+        m.bn.weight.uniform_(0.5, 1.5)
+        m.bn.bias.normal_(0, 0.2)
+    x = torch.randn((2, 24, 4, 6, 13), generator=gen(19))
+    size = (8, 12, 26)
+    with torch.no_grad():
+        ref = F.relu(m.bn(m.conv(F.interpolate(x, size, mode="trilinear", align_corners=True))))
+        out = m.to(DEV)(gpu(x), resample_to=size)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("cin,cout,shape,size", [(12, 8, (2, 8, 12, 20), (4, 6, 10)), (24, 16, (1, 7, 9, 13), (4, 5, 7)),
                                                  (48, 8, (1, 3, 4, 5), (6, 8, 10)), (48, 24, (1, 4, 8, 26), (8, 16, 52)),
                                                  (12, 4, (1, 64, 32, 104), (32, 16, 52))])
