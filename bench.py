@@ -415,18 +415,29 @@ def main():
             x3 = log_tx == "x3"
             kname = (f"conv3d_x3_kernel<{groups[0]}, {nset}>" if x3 else f"conv3d_k3_kernel<{groups[0]}, {log_tx}, {rows}, {nset}, 2, 0>")
             peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
-            roofline = {"kernel": kname, "bound": "mfma",
-                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": pmc_traffic_bytes(kname),
-                        "algorithmic_bytes_per_launch": nbytes / nlaunch,
-                        "launches_per_step": nlaunch // args.steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
-                        "flops_per_launch": flops / nlaunch,
-                        "share_of_step": round(secs / args.steps / (dt / args.steps), 3)}
+            # which roof bounds this kernel: the larger of its two floors per launch — HBM: algorithmic bytes / 8 TB/s;
+            # matrix cores: the MFMA flops it must ISSUE / dense peak (the bf16x3 form issues 3 bf16 MFMAs per fp32
+            # product, 2 with bf16 activation storage; row / K padding not counted)
+            issue = (2.0 if args.dtype == "bf16" else 3.0) if x3 else 1.0
+            t_hbm = (nbytes / nlaunch) / (PEAK_HBM_GBS * 1e9)
+            t_mfma = issue * (flops / nlaunch) / (peak * 1e12)
+            common = {"traffic": pmc_traffic_bytes(kname), "algorithmic_bytes_per_launch": nbytes / nlaunch,
+                      "launches_per_step": nlaunch // args.steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
+                      "flops_per_launch": flops / nlaunch, "share_of_step": round(secs / args.steps / (dt / args.steps), 3),
+                      "floor_us": {"hbm": round(t_hbm * 1e6, 1), "mfma": round(t_mfma * 1e6, 1)}}
+            if t_hbm >= t_mfma:
+                gbs = nbytes / secs * 1e-9
+                roofline = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(gbs / PEAK_HBM_GBS, 4), **common,
+                            "mfma": {"achieved_tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4)}}
+            else:
+                roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                            "frac": round(ach / peak, 4), **common}
             if x3:
-                roofline["note"] = ("fp32 convolution emulated on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate): "
-                                    "achieved = ALGORITHMIC fp32 flops / time against the bf16 dense peak; the kernel executes 3 bf16 "
-                                    "MFMAs per product plus Cout 12->16 / K padding; against the fp32 matrix peak (157.3) the same "
-                                    f"figure is {ach / PEAK_FP32_MFMA_TFLOPS:.2f}")
+                roofline["note"] = ("fp32 convolution emulated on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate). Its HBM "
+                                    "floor (input once + output once at 8 TB/s) is above its MFMA floor (3 bf16 MFMAs per product at "
+                                    "the 2.5 PFLOP/s dense peak), so HBM is the roof it is priced against; `mfma` = ALGORITHMIC fp32 "
+                                    f"flops / time against the bf16 dense peak ({ach / PEAK_FP32_MFMA_TFLOPS:.2f} of the fp32 matrix peak 157.3)")
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
                 log(f"  conv3d {'x3 (bf16x3) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
