@@ -172,7 +172,10 @@ class ConvBRGroupFn(torch.autograd.Function):
         x = _dense(x)
         n, C = len(mods), mods[0].conv.out_channels
         B = x.shape[0]
-        wcat = torch.cat([params[3 * i].detach() for i in range(n)])
+        # concatenated as 2-D rows: ATen's cat of 5-D tensors falls back to one contiguous copy_ (a MEMCPY, i.e. a memcpy node of a
+        # captured step — DESIGN.md 4.4) per input; up to 4-D it is one batched kernel
+        w0 = params[0]
+        wcat = torch.cat([params[3 * i].detach().reshape(C, -1) for i in range(n)]).view((n * C,) + tuple(w0.shape[1:]))
         raw = torch.empty((B, n * C) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
         ops.conv3d_k3(x, ops.conv3d_k3_pack(wcat), n * C, None, None, False, raw)
         nvox = B * _vol(x)

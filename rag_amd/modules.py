@@ -136,14 +136,14 @@ class _ConvBR(nn.Module):
         if x.dtype != torch.float32:
             raise NotImplementedError("rag_amd: the training path is fp32 (bf16 storage is inference only)")
         if self._geometry() == -3:
-            return ag.StridedStemFn.apply(x if x.dim() == 4 else x[:, :, 0], self.conv.weight, self.bn.weight, self.bn.bias, self)
+            return ag.StridedStemFn.apply(x if x.dim() == 4 else x.squeeze(2), self.conv.weight, self.bn.weight, self.bn.bias, self)
         squeeze = x.dim() == 4
         if squeeze:
             x = x.unsqueeze(2)
         if resample_to is not None:
             x = ag.resample(x, resample_to, True)
         y = ag.ConvBRFn.apply(x, self.conv.weight, self.bn.weight, self.bn.bias, self)
-        return y[:, :, 0] if squeeze else y
+        return y.squeeze(2) if squeeze else y      # (a select's backward is zeros + copy_: a memcpy node when captured)
 
     def costvol_fusable(self, C_fea: int) -> bool:
         """This unit can consume (left_fea, right_fea) directly instead of the cost volume (ragmi_costvol_stem_fwd)."""
@@ -388,7 +388,7 @@ class _Cell(nn.Module):
     def forward(self, prev_prev_input, prev_input):
         run = self._run_autograd if self.autograd_mode(prev_prev_input, prev_input) else (lambda a, b: self._run(a, b)[0])
         if prev_input.dim() == 4:     # 2-D cell: run on depth-1 volumes
-            return prev_input, run(prev_prev_input.unsqueeze(2), prev_input.unsqueeze(2))[:, :, 0]
+            return prev_input, run(prev_prev_input.unsqueeze(2), prev_input.unsqueeze(2)).squeeze(2)
         return prev_input, run(prev_prev_input, prev_input)
 
     def _run_autograd(self, prev_prev_input, prev_input):

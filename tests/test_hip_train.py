@@ -471,6 +471,36 @@ def test_flat_sgd_step_matches_torch_sgd(ra):
         close(s1[k].float(), s0[k].float(), 2e-3, k)
 
 
+def test_training_step_issues_no_memcpy_or_memset(ra):
+    """Nothing in forward + loss + backward may be a device memcpy / memset: captured into a hipGraph those become memcpy /
+    memset NODES, which this runtime does not replay safely next to null-stream copies (rag_amd.train.GraphedTrainStep).
+    Typical offenders: a contiguous same-dtype copy_/clone, torch.cat of 5-D tensors, the backward of x[:, :, 0]."""
+    from rag_amd.train import GradBucket, forward_backward
+    try:
+        from torch.profiler import ProfilerActivity, profile
+    except Exception as exc:  # noqa: BLE001
+        pytest.skip(f"torch.profiler unavailable: {exc}")
+    g = load_golden("g6_train_step")
+    rows = g["rows"]
+    net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=int(g["maxdisp"]))
+    net.load_state_dict(split_sd(g), strict=True)
+    net = net.to(DEV).train()
+    bucket = GradBucket(net.parameters())
+    left, right, gt = gpu(g["left"]), gpu(g["right"]), gpu(g["gt"])
+    forward_backward(net, bucket, left, right, gt)
+    torch.cuda.synchronize()
+    try:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            forward_backward(net, bucket, left, right, gt)
+            torch.cuda.synchronize()
+        names = [e.name for e in prof.events()]
+    except RuntimeError as exc:
+        pytest.skip(f"profiler could not trace the device: {exc}")
+    assert any("ragmi" in n for n in names), "the profile saw no HIP kernels of this library"
+    bad = sorted({n for n in names if "memcpy" in n.lower() or "memset" in n.lower() or "copyBuffer" in n})
+    assert not bad, bad
+
+
 # --------------------------------------------------------------------------- fused loss + metrics (SURVEY 8(f) N3)
 @pytest.mark.parametrize("B,H,W,maxdisp,case", [(2, 36, 48, 24, "plain"), (4, 192, 384, 192, "plain"), (3, 33, 47, 48, "skip"),
                                                 (1, 24, 24, 192, "sparse")])
