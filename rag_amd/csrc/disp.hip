@@ -64,12 +64,13 @@ __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
       b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1);
     }
     const float t = -fmaf(tb.y + tb.w, b0, tb.z * b1);
-    const float mn = fmaxf(m, t);
-    const float r = __builtin_amdgcn_exp2f((m - mn) * K);   // 2^(-inf) = 0 on the first sample
-    const float e = __builtin_amdgcn_exp2f((t - mn) * K);
+    // one of (m - m'), (t - m') is exactly 0 and 2^0 is exactly 1: ONE transcendental per sample, the same bits as two
+    const bool up = t > m;                                   // the running maximum moves
+    const float x = __builtin_amdgcn_exp2f((up ? m - t : t - m) * K);   // 2^(-inf) = 0 on the first sample
+    const float r = up ? x : 1.f, e = up ? 1.f : x;
     s = fmaf(s, r, e);
     ws = fmaf(ws, r, e * (float)dd);
-    m = mn;
+    m = up ? t : m;
   }
   a.out[(int64_t)b * npix + o] = ws / s;
 }
