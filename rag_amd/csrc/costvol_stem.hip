@@ -78,7 +78,8 @@ struct PlanesArgs {
   int C, Cout, H, W, ndesc;
   PlaneDesc d[CS_MAXDESC];
 };
-constexpr int CS_TX = 64, CS_TY = 8, CS_PX = 4;     // workgroup tile; pixels per thread along x (weights read once per 4 pixels)
+constexpr int CS_TX = 64, CS_TY = 8, CS_PX = 2;     // workgroup tile; pixels per thread along x (4 px: 87 us, 2 px: 53 us, 1 px: 57 us — the
+                                                    // grid is small, so threads count for more than weight reuse per LDS read)
 constexpr int CS_RS = CS_TX + 5;                     // LDS row stride = 5 mod 32: the 16 x 4 lanes of a wave spread 2 per bank
 constexpr int CS_NT = (CS_TX / CS_PX) * CS_TY;       // threads per workgroup
 constexpr int CS_CC = 4;                             // input channels staged in LDS at a time
@@ -181,13 +182,24 @@ struct CombineArgs {
 };
 template <class T>
 __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a) {
-  // one thread per voxel of the flattened (i, y, x) volume: every wave is full (rows of W = 416 leave a 256-wide row block
-  // 19 % idle) and there is no per-workgroup prologue; the per-channel parameters and the tail weights are wave-uniform
-  // reads of global memory (scalar loads), not LDS broadcasts (~120 LDS instructions per thread in the first version)
-  const int64_t HWi = (int64_t)a.H * a.W;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= HWi * a.D) return;
-  const int i = (int)(idx / HWi), r = (int)(idx - (int64_t)i * HWi), y = r / a.W, x = r - y * a.W, b = blockIdx.z;
+  __shared__ float par[2 * CS_MAXC + 2 * (4 * CS_MAXC + 8)];      // scale | shift | per tail: w[4][Cout] scale[4] shift[4]
+  for (int e = threadIdx.x; e < a.Cout; e += 256) {
+    par[e] = a.scale ? a.scale[e] : 1.f;
+    par[CS_MAXC + e] = a.shift ? a.shift[e] : 0.f;
+  }
+  for (int t = 0; t < a.ntail; ++t) {
+    float* p = par + 2 * CS_MAXC + t * (4 * CS_MAXC + 8);
+    const ragmi_tail_t& tl = a.tail[t];
+    for (int e = threadIdx.x; e < tl.cout * a.Cout; e += 256) p[e] = static_cast<const float*>(tl.weight)[e];
+    for (int e = threadIdx.x; e < tl.cout; e += 256) {
+      p[4 * CS_MAXC + e] = tl.scale ? static_cast<const float*>(tl.scale)[e] : 1.f;
+      p[4 * CS_MAXC + 4 + e] = tl.shift ? static_cast<const float*>(tl.shift)[e] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.W) return;
+  const int y = blockIdx.y % a.H, i = blockIdx.y / a.H, b = blockIdx.z;
   const int cls = (i == 0 ? 1 : 0) + (i == a.D - 1 ? 2 : 0);
   const int t = x - i, tc = min(max(t, -3), 2), xr = x == a.W - 1 ? 1 : 0;
   const float* ws = a.ws + b * a.ws_bstride;
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
   for (int co = 0; co < CS_MAXC; ++co) {
     if (co < a.Cout) {
       float s = (pa ? pa[co * sa] : 0.f) + (pb ? pb[co * sb] : 0.f);
-      if (a.scale) s = fmaf(s, a.scale[co], a.shift[co]);
+      s = fmaf(s, par[co], par[CS_MAXC + co]);
       v[co] = a.relu ? fmaxf(s, 0.f) : s;
     } else {
       v[co] = 0.f;
@@ -220,17 +232,15 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
   for (int co = 0; co < CS_MAXC; ++co)
     if (co < a.Cout) st(py + co * DHW, v[co]);
   for (int tl = 0; tl < a.ntail; ++tl) {
+    const float* p = par + 2 * CS_MAXC + tl * (4 * CS_MAXC + 8);
     const ragmi_tail_t& td = a.tail[tl];
-    const float* tw = static_cast<const float*>(td.weight);
-    const float* tsc = static_cast<const float*>(td.scale);
-    const float* tsh = static_cast<const float*>(td.shift);
     T* pt = static_cast<T*>(td.y) + b * td.y_bstride + (int64_t)td.y_ch0 * DHW + vox;
     for (int k = 0; k < td.cout; ++k) {
       float s = 0.f;
 #pragma unroll
       for (int co = 0; co < CS_MAXC; ++co)
-        if (co < a.Cout) s = fmaf(tw[k * a.Cout + co], v[co], s);
-      if (tsc) s = fmaf(s, tsc[k], tsh[k]);
+        if (co < a.Cout) s = fmaf(p[k * a.Cout + co], v[co], s);
+      s = fmaf(s, p[4 * CS_MAXC + k], p[4 * CS_MAXC + 4 + k]);
       st(pt + k * DHW, td.relu ? fmaxf(s, 0.f) : s);
     }
   }
@@ -348,8 +358,8 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
                   "costvol_stem: tail %d needs weight, y and 1..4 output channels", t);
     ca.tail[t] = tails[t];
   }
-  RAGMI_REQUIRE(ceil_div((int64_t)D * H * W, 256) < (1ll << 31), RAGMI_EUNSUPPORTED, "costvol_stem: volume exceeds the grid limit");
-  const dim3 cgrid((unsigned)ceil_div((int64_t)D * H * W, 256), 1, (unsigned)B);
+  RAGMI_REQUIRE((int64_t)D * H <= 65535, RAGMI_EUNSUPPORTED, "costvol_stem: D*H exceeds the grid limit");
+  const dim3 cgrid((unsigned)ceil_div(W, 256), (unsigned)(D * H), (unsigned)B);
   if (dtype == RAGMI_BF16) hipLaunchKernelGGL(costvol_stem_combine_kernel<bf16_t>, cgrid, dim3(256), 0, st, ca);
   else hipLaunchKernelGGL(costvol_stem_combine_kernel<float>, cgrid, dim3(256), 0, st, ca);
   return check_launch("costvol_stem");
