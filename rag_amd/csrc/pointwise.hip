@@ -114,29 +114,51 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
   float acc[NCO];
 #pragma unroll
   for (int j = 0; j < NCO; ++j) acc[j] = 0.f;
-  // U channels per trip: 8U independent gathers in flight before the first use (the kernel is latency-bound at the
-  // small volumes it runs on, so the number of dependent round trips is what matters)
-  constexpr int U = NCO <= 8 ? 8 : 4;
-  for (int c0 = 0; c0 < a.Cin; c0 += U) {
-    float tap[U][8];
+  // U channels per trip: 8U independent gathers in flight before the first use.  4 (32 loads, ~70 VGPRs) beats 8 (64 loads, 105
+  // VGPRs) on the big HBM-bound launches — cell 3 at the headline shape: 78 us vs 91 — and 2 is no better; the 4-wide slab keeps 8
+  constexpr int U = NCO <= 4 ? 8 : 4;
+  if (r.Di == r.Do && r.Hi == r.Ho && r.Wi == r.Wo) {
+    // an input already at the output size (the partner of a resampled one in a paired launch): index o, weight 1 — one load
+    // per channel instead of eight, 16 channels in flight per trip; the same value the interpolation formula gives (1*v + 0*v')
+    constexpr int UI = 16;
+    for (int c0 = 0; c0 < a.Cin; c0 += UI) {
+      float xv[UI];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const T* pc = xp + (int64_t)min(c0 + u, a.Cin - 1) * ivol;
-      tap[u][0] = ld(pc + r00 + lx.i0); tap[u][1] = ld(pc + r00 + lx.i1); tap[u][2] = ld(pc + r01 + lx.i0); tap[u][3] = ld(pc + r01 + lx.i1);
-      tap[u][4] = ld(pc + r10 + lx.i0); tap[u][5] = ld(pc + r10 + lx.i1); tap[u][6] = ld(pc + r11 + lx.i0); tap[u][7] = ld(pc + r11 + lx.i1);
+      for (int u = 0; u < UI; ++u) xv[u] = ld(xp + (int64_t)min(c0 + u, a.Cin - 1) * ivol + o);
+#pragma unroll
+      for (int u = 0; u < UI; ++u) {
+        if (c0 + u >= a.Cin) break;
+        const int ci = c0 + u;
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) {
+          const int co = a.co0 + j;
+          const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
+          acc[j] = fmaf(wv, xv[u], acc[j]);
+        }
+      }
     }
+  } else {
+    for (int c0 = 0; c0 < a.Cin; c0 += U) {
+      float tap[U][8];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (c0 + u >= a.Cin) break;
-      const int ci = c0 + u;
-      const float a0 = ly.w0 * (lx.w0 * tap[u][0] + lx.w1 * tap[u][1]) + ly.w1 * (lx.w0 * tap[u][2] + lx.w1 * tap[u][3]);
-      const float a1 = ly.w0 * (lx.w0 * tap[u][4] + lx.w1 * tap[u][5]) + ly.w1 * (lx.w0 * tap[u][6] + lx.w1 * tap[u][7]);
-      const float xv = lz.w0 * a0 + lz.w1 * a1;
+      for (int u = 0; u < U; ++u) {
+        const T* pc = xp + (int64_t)min(c0 + u, a.Cin - 1) * ivol;
+        tap[u][0] = ld(pc + r00 + lx.i0); tap[u][1] = ld(pc + r00 + lx.i1); tap[u][2] = ld(pc + r01 + lx.i0); tap[u][3] = ld(pc + r01 + lx.i1);
+        tap[u][4] = ld(pc + r10 + lx.i0); tap[u][5] = ld(pc + r10 + lx.i1); tap[u][6] = ld(pc + r11 + lx.i0); tap[u][7] = ld(pc + r11 + lx.i1);
+      }
 #pragma unroll
-      for (int j = 0; j < NCO; ++j) {
-        const int co = a.co0 + j;
-        const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
-        acc[j] = fmaf(wv, xv, acc[j]);
+      for (int u = 0; u < U; ++u) {
+        if (c0 + u >= a.Cin) break;
+        const int ci = c0 + u;
+        const float a0 = ly.w0 * (lx.w0 * tap[u][0] + lx.w1 * tap[u][1]) + ly.w1 * (lx.w0 * tap[u][2] + lx.w1 * tap[u][3]);
+        const float a1 = ly.w0 * (lx.w0 * tap[u][4] + lx.w1 * tap[u][5]) + ly.w1 * (lx.w0 * tap[u][6] + lx.w1 * tap[u][7]);
+        const float xv = lz.w0 * a0 + lz.w1 * a1;
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) {
+          const int co = a.co0 + j;
+          const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
+          acc[j] = fmaf(wv, xv, acc[j]);
+        }
       }
     }
   }
@@ -180,19 +202,24 @@ static int fill_k1r(K1RArgs& r, const void* x, int64_t x_bstride, int Di, int Hi
 
 template <class T>
 static int launch_k1r(const K1RArgs* r, int n, int B, hipStream_t s) {
-  // slab width: same policy as the plain kernel (one voxel per thread here)
+  // slab width (output channels per thread; every slab gathers the input again).  One slab covering all outputs when the
+  // launch has threads to spare or is HBM-bound (>= 128 MB of input: re-reading it costs more than the parallelism buys —
+  // cell 4 at the headline shape: 25.6 us with 16 vs 30.2 with 12); otherwise the widest EVEN split that yields enough threads
+  // (cell 6: 26.0 us with 8 vs 29.9 with 12, whose second slab carries 4 of 16 channels at the full gather cost)
   const int cmax = n == 2 ? (r[0].k.Cout > r[1].k.Cout ? r[0].k.Cout : r[1].k.Cout) : r[0].k.Cout;
   const int64_t threads = (int64_t)B * r[0].Do * r[0].Ho * r[0].Wo * n, want = 256 * 256 * 2;
+  int64_t in_bytes = 0;
+  for (int i = 0; i < n; ++i) in_bytes += (int64_t)B * r[i].k.Cin * r[i].Di * r[i].Hi * r[i].Wi * (int64_t)sizeof(T);
   static const int widths[5] = {24, 16, 12, 8, 4};
   int cover = 24;
   for (int w : widths)
     if (w >= cmax) cover = w;
   int nco = 4;
-  if (threads >= want) {
+  if (threads >= want || in_bytes >= (128ll << 20)) {
     nco = cover;
   } else {
     for (int w : widths)
-      if (w <= cover && threads * ceil_div(cmax, w) >= want) { nco = w; break; }
+      if (w <= cover && (w == cover || cmax % w == 0) && threads * ceil_div(cmax, w) >= want) { nco = w; break; }
   }
   switch (nco) {
     case 24: launch_k1r_nco<T, 24>(r, n, B, s); break;

@@ -309,6 +309,29 @@ def test_conv3d_k1_resample_vs_aten(ra, cin, cout, shape, size):
     assert float(out[:, :1].abs().max()) == 0.0 and float(out[:, 1 + cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cins,cout,shapes,size", [((48, 24), 16, ((4, 8, 26), (8, 16, 52)), (4, 8, 26)),
+                                                   ((24, 48), 16, ((7, 9, 13), (4, 5, 7)), (4, 5, 7)),
+                                                   ((12, 12), 8, ((8, 12, 20), (8, 12, 20)), (4, 6, 10)),
+                                                   ((50, 20), 8, ((3, 4, 5), (3, 4, 5)), (3, 4, 5))])
+def test_conv3d_k1_resample_pair_vs_aten(ra, cins, cout, shapes, size):
+    """The paired launch (a cell's pre_preprocess + preprocess): each input resampled or ALREADY at the output size (one load per
+    channel instead of eight taps), written into adjacent channel slices of one buffer."""
+    B = 2
+    outs, specs = [], []
+    out = torch.zeros((B, 2 * cout + 1) + tuple(size), device=DEV)
+    for k, (cin, shp) in enumerate(zip(cins, shapes)):
+        x = torch.randn((B, cin) + shp, generator=gen(44 + k))
+        w = torch.randn((cout, cin, 1, 1, 1), generator=gen(46 + k)) * (2.0 / cin) ** 0.5
+        scale, shift = torch.rand(cout, generator=gen(48 + k)) + 0.5, torch.randn(cout, generator=gen(50 + k)) * 0.1
+        xi = x if tuple(shp) == tuple(size) else F.interpolate(x, size, mode="trilinear", align_corners=True)
+        outs.append(F.relu(F.conv3d(xi, w) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)))
+        specs.append((gpu(x), gpu(w.reshape(cout, cin)), gpu(scale), gpu(shift), True, k * cout))
+    ra.ops.conv3d_k1_resample_pair(specs, size, out)
+    np.testing.assert_allclose(out[:, :cout].cpu().numpy(), outs[0].numpy(), **TOL)
+    np.testing.assert_allclose(out[:, cout:2 * cout].cpu().numpy(), outs[1].numpy(), **TOL)
+    assert float(out[:, 2 * cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,H,W,stride", [(6, 12, 36, 60, 3), (3, 5, 17, 23, 2), (6, 12, 48, 96, 3), (4, 4, 9, 9, 4)])
 def test_conv2d_k3_strided_vs_aten(ra, cin, cout, H, W, stride):
     """Feature-Net stem2d1 (3x3, pad 1, stride 3; rag_model.py:201)."""
