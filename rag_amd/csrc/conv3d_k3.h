@@ -575,7 +575,8 @@ static int launch_cfg_valu(K3Args a, hipStream_t s) {
   a.tiles_z = (int)ceil_div(a.D, 4);
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
-  launch_one<T, 1, LOG_TX, R, 1, 2, VCO>(a, ntiles, 1, s);
+  // one output channel fits 128 VGPRs without spilling: four waves per SIMD hide the LDS-read chains of the VALU form better
+  launch_one<T, 1, LOG_TX, R, 1, (VCO == 1 ? 4 : 2), VCO>(a, ntiles, 1, s);
   return check_launch("conv3d_k3_small");
 }
 
