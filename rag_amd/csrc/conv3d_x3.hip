@@ -98,8 +98,11 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   uint2* const lhi = x3_lds;
   uint2* const llo = x3_lds + NCG * 3 * X3_PL;                                          // absent for bf16 storage
   uint4* const lw = reinterpret_cast<uint4*>(x3_lds + (BF ? 1 : 2) * NCG * 3 * X3_PL);  // [set][slice][hi/lo][64 lanes]
-  int2* const loff = reinterpret_cast<int2*>(lw + NSL * 2 * 64);                        // [set][slice][8 pairs]: (in-plane offset incl. cg, dz)
-  float* const par = reinterpret_cast<float*>(loff + NSL * 8);                          // scale[2][16] | shift[2][16]
+  // operand byte offsets, ready to use: [ring phase 0..2][slice][lane quarter kb] -> (pair 2kb, pair 2kb+1) of that slice with the ring
+  // rotation already applied, so the K loop spends no VALU work on addresses (one 8-byte table read per slice instead of two
+  // plus ~8 instructions of mod-3 arithmetic)
+  int2* const loff = reinterpret_cast<int2*>(lw + NSL * 2 * 64);
+  float* const par = reinterpret_cast<float*>(loff + 3 * NSL * 4);                      // scale[2][16] | shift[2][16]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog = blockIdx.y;
   const int HW = a.H * a.W;
@@ -108,9 +111,16 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     const int set = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
     lw[i] = e.wf[set][(int64_t)cog * NSLS * 2 * 64 + r];
   }
-  for (int i = tid; i < NSL * 8; i += X3_THREADS) {
-    const int set = i / (NSLS * 8), P = i % (NSLS * 8), cgl = P / 27, tap = P % 27;
-    loff[i] = cgl < NCGS ? make_int2((set * NCGS + cgl) * 3 * X3_PL + ((tap / 3) % 3) * X3_HX + tap % 3, tap / 9) : make_int2(0, 0);
+  for (int i = tid; i < 3 * NSL * 4; i += X3_THREADS) {
+    const int ring = i / (NSL * 4), q = i % (NSL * 4), set = q / (NSLS * 4);
+    int o[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int P = (q % (NSLS * 4)) * 2 + j, cgl = P / 27, tap = P % 27;
+      const int slot = (ring + tap / 9) % 3;          // plane z+dz-1 sits in slot (ring + dz) % 3
+      o[j] = cgl < NCGS ? (((set * NCGS + cgl) * 3 + slot) * X3_PL + ((tap / 3) % 3) * X3_HX + tap % 3) * (int)sizeof(uint2) : 0;
+    }
+    loff[i] = make_int2(o[0], o[1]);
   }
   for (int i = tid; i < 32; i += X3_THREADS) {
     const int set = i >> 4, co = cog * 16 + (i & 15);
@@ -183,13 +193,12 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       if constexpr (!BF) llo[d] = make_uint2(l01, l23);
     }
   };
-  // this wave's column tiles of a plane: nt = wave * X3_NT + i -> (row y = nt / 2, x half = nt % 2)
-  int vbase[X3_NT];
-#pragma unroll
-  for (int i = 0; i < X3_NT; ++i) {
-    const int nt = wave * X3_NT + i;
-    vbase[i] = (nt >> 1) * X3_HX + (nt & 1) * 16 + n;
-  }
+  // this wave's column tiles of a plane: nt = wave * X3_NT + i -> (row y = nt / 2, x half = nt % 2); X3_NT is even, so tile i
+  // sits a compile-time distance behind tile 0 (an immediate offset of the LDS read)
+  static_assert(X3_NT % 2 == 0, "tile deltas below assume an even number of column tiles per wave");
+  const int vb0 = ((wave * X3_NT >> 1) * X3_HX + n) * (int)sizeof(uint2);
+  const char* const lbytes = reinterpret_cast<const char*>(x3_lds);
+  constexpr int LO_BYTES = NCG * 3 * X3_PL * (int)sizeof(uint2);
   const int g = cog * 4 + kb, ngroups = (a.Cout + 3) >> 2;
   // per-lane destinations, read ONCE: indexing the kernel-argument arrays with a lane-dependent index inside the loop is a
   // vector memory load per use, and its s_waitcnt vmcnt drains the prefetch that is supposed to fly under the MFMAs
@@ -228,22 +237,24 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) acc[st][i] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int ring = (z - 1 + 3) % 3;                // slot of plane z-1; plane z+dz-1 (dz = 0..2) sits in slot (ring + dz) % 3
+      const int2* const lo_r = loff + ring * (NSL * 4) + kb;      // this lane's offset pairs for the current ring phase
 #pragma unroll
       for (int s = 0; s < NSL; ++s) {
         const int st = s / NSLS;                        // compile time after unrolling
         const x3_bf16x8 ah = __builtin_bit_cast(x3_bf16x8, lw[(s * 2 + 0) * 64 + lane]);
         const x3_bf16x8 al = __builtin_bit_cast(x3_bf16x8, lw[(s * 2 + 1) * 64 + lane]);
-        const int2 p0 = loff[s * 8 + 2 * kb], p1 = loff[s * 8 + 2 * kb + 1];
-        int s0 = ring + p0.y, s1 = ring + p1.y;
-        s0 -= s0 >= 3 ? 3 : 0; s1 -= s1 >= 3 ? 3 : 0;
-        const int o0 = p0.x + s0 * X3_PL, o1 = p1.x + s1 * X3_PL;
+        const int2 po = lo_r[s * 4];
+        const char* const a0 = lbytes + vb0 + po.x;
+        const char* const a1 = lbytes + vb0 + po.y;
         x3_bf16x8 bh[X3_NT], bl[X3_NT];
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) {
-          const uint2 h0 = lhi[vbase[i] + o0], h1 = lhi[vbase[i] + o1];
+          constexpr int ROWB = X3_HX * (int)sizeof(uint2), HALFB = 16 * (int)sizeof(uint2);
+          const int d = (i >> 1) * ROWB + (i & 1) * HALFB;          // compile time: tile i relative to tile 0
+          const uint2 h0 = *reinterpret_cast<const uint2*>(a0 + d), h1 = *reinterpret_cast<const uint2*>(a1 + d);
           bh[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
           if constexpr (!BF) {
-            const uint2 l0 = llo[vbase[i] + o0], l1 = llo[vbase[i] + o1];
+            const uint2 l0 = *reinterpret_cast<const uint2*>(a0 + d + LO_BYTES), l1 = *reinterpret_cast<const uint2*>(a1 + d + LO_BYTES);
             bl[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
           }
         }
@@ -368,7 +379,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   RAGMI_REQUIRE(nwork < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
   e.bf16 = dtype == RAGMI_BF16 ? 1 : 0;
-  const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)nsl * 8 * sizeof(int2) +
+  const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
                      64 * sizeof(float);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
   const dim3 grid((unsigned)std::min<int64_t>(nwork, 1024), ncog);
