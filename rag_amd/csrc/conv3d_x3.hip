@@ -88,7 +88,7 @@ struct X3Extra {
 // K-slice are in flight under the MFMAs of the current one) and the prefetch registers are static.
 // T = activation storage: float (three MFMAs per product) or bf16_t (the activations ARE bf16: no lo copy, two MFMAs per
 // product — weight hi and lo — and half the LDS operand traffic)
-template <class T, int NCG, int NSET>
+template <class T, int NCG, int NSET, bool TAILS>
 __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
@@ -132,8 +132,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // 16x16x32 product whose K slots are laid out so that every lane quarter feeds ITS OWN four channels — slots 8kb..8kb+3 carry
   // v_hi, slots 8kb+4..8kb+7 carry v_lo of channels 4kb..4kb+3 — so no value crosses lanes.  Rows: tail 0 -> 0..3, tail 1 -> 4..7.
   //   ta1 = W_hi in all eight slots (W_hi * (v_hi + v_lo)),  ta2 = W_lo in the hi slots only (W_lo * v_hi)
-  x3_bf16x8 ta1, ta2;
-  {
+  // (TAILS is compile time: the instantiations without fused tails have ~20 more registers for the main loop)
+  x3_bf16x8 ta1{}, ta2{};
+  float tsc[4] = {1.f, 1.f, 1.f, 1.f}, tsh[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (TAILS) {
     unsigned short h1[8], h2[8];
     const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row
 #pragma unroll
@@ -148,14 +150,13 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     }
     ta1 = __builtin_bit_cast(x3_bf16x8, make_uint4(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16), h1[4] | ((unsigned)h1[5] << 16), h1[6] | ((unsigned)h1[7] << 16)));
     ta2 = __builtin_bit_cast(x3_bf16x8, make_uint4(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16), h2[4] | ((unsigned)h2[5] << 16), h2[6] | ((unsigned)h2[7] << 16)));
-  }
-  // this lane's tail outputs after that product: rows 4 kb + r -> tail kb, output r
-  float tsc[4], tsh[4];
+    // this lane's tail outputs after that product: rows 4 kb + r -> tail kb, output r
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const bool ok = kb < a.ntail && r < a.tail_cout[kb < 2 ? kb : 0];
-    tsc[r] = (ok && a.tail_scale[kb]) ? a.tail_scale[kb][r] : 1.f;
-    tsh[r] = (ok && a.tail_shift[kb]) ? a.tail_shift[kb][r] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = kb < a.ntail && r < a.tail_cout[kb < 2 ? kb : 0];
+      tsc[r] = (ok && a.tail_scale[kb]) ? a.tail_scale[kb][r] : 1.f;
+      tsh[r] = (ok && a.tail_shift[kb]) ? a.tail_shift[kb][r] : 0.f;
+    }
   }
   float pf[NPF][4];
   unsigned valid = 0;
@@ -204,9 +205,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // vector memory load per use, and its s_waitcnt vmcnt drains the prefetch that is supposed to fly under the MFMAs
   const int my_ych = g < ngroups ? a.y_ch[g < RAGMI_MAX_GROUPS ? g : 0] : 0;
   const int tsel = kb & 1;
-  T* const my_tail = static_cast<T*>(a.tail_y[tsel]);
-  const int64_t my_tail_bstride = a.tail_bstride[tsel];
-  const int my_tail_ch0 = a.tail_ch0[tsel], my_tail_cout = kb < a.ntail ? a.tail_cout[tsel] : 0, my_tail_relu = a.tail_relu[tsel];
+  T* const my_tail = TAILS ? static_cast<T*>(a.tail_y[tsel]) : nullptr;
+  const int64_t my_tail_bstride = TAILS ? a.tail_bstride[tsel] : 0;
+  const int my_tail_ch0 = TAILS ? a.tail_ch0[tsel] : 0, my_tail_cout = (TAILS && kb < a.ntail) ? a.tail_cout[tsel] : 0;
+  const int my_tail_relu = TAILS ? a.tail_relu[tsel] : 0;
   // XCD-aware schedule: workgroup j runs on XCD j % 8 (round-robin dispatch); give every XCD one contiguous chunk of the
   // (x-fastest) work list so that neighbouring columns — which share halo rows and cache lines — meet in the same L2
   const int chunk = (e.nwork + 7) / 8;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           for (int r = 0; r < 4; ++r)
             if (4 * g + r < a.Cout) st(py + r * DHW, v[r]);
         }
-        if (a.ntail > 0) {                              // uniform
+        if constexpr (TAILS) {
           unsigned l01, l23;
           const unsigned h01 = x3_split2(v[0], v[1], l01), h23 = x3_split2(v[2], v[3], l23);
           const x3_bf16x8 bv = __builtin_bit_cast(x3_bf16x8, make_uint4(h01, h23, l01, l23));
@@ -343,16 +345,20 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
   return true;
 }
 
-template <class T, int NCG, int NSET>
-static int x3_launch_typed(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
+template <class T, int NCG, int NSET, bool TAILS>
+static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3d_x3_kernel<T, NCG, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET>), grid, dim3(X3_THREADS), lds, st, a, e);
+  hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET, TAILS>), grid, dim3(X3_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3");
+}
+template <class T, int NCG, int NSET>
+static int x3_launch_typed(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
+  return a.ntail > 0 ? x3_launch_tails<T, NCG, NSET, true>(a, e, grid, lds, st) : x3_launch_tails<T, NCG, NSET, false>(a, e, grid, lds, st);
 }
 template <int NCG, int NSET>
 static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
