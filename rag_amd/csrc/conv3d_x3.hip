@@ -101,8 +101,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // operand byte offsets, ready to use: [ring phase 0..2][slice][lane quarter kb] -> (pair 2kb, pair 2kb+1) of that slice with the ring
   // rotation already applied, so the K loop spends no VALU work on addresses (one 8-byte table read per slice instead of two
   // plus ~8 instructions of mod-3 arithmetic)
-  int2* const loff = reinterpret_cast<int2*>(lw + NSL * 2 * 64);
-  float* const par = reinterpret_cast<float*>(loff + 3 * NSL * 4);                      // scale[2][16] | shift[2][16]
+  uint4* const ltail = lw + NSL * 2 * 64;             // fused-tail weight fragments ta1 | ta2, [2][64 lanes] (kept out of the registers)
+  int2* const loff = reinterpret_cast<int2*>(ltail + 2 * 64);
+  float* const par = reinterpret_cast<float*>(loff + 3 * NSL * 4);                      // scale[2][16] | shift[2][16] | tail scale[4 kb][4] | tail shift[4][4]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog = blockIdx.y;
   const int HW = a.H * a.W;
@@ -132,9 +133,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // 16x16x32 product whose K slots are laid out so that every lane quarter feeds ITS OWN four channels — slots 8kb..8kb+3 carry
   // v_hi, slots 8kb+4..8kb+7 carry v_lo of channels 4kb..4kb+3 — so no value crosses lanes.  Rows: tail 0 -> 0..3, tail 1 -> 4..7.
   //   ta1 = W_hi in all eight slots (W_hi * (v_hi + v_lo)),  ta2 = W_lo in the hi slots only (W_lo * v_hi)
-  // (TAILS is compile time: the instantiations without fused tails have ~20 more registers for the main loop)
-  x3_bf16x8 ta1{}, ta2{};
-  float tsc[4] = {1.f, 1.f, 1.f, 1.f}, tsh[4] = {0.f, 0.f, 0.f, 0.f};
+  // (TAILS is compile time; the tail fragments and parameters live in LDS and are fetched in the epilogue — in registers they cost
+  // ~20 VGPRs of a 128-VGPR budget and the main loop spilled)
   if constexpr (TAILS) {
     unsigned short h1[8], h2[8];
     const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row
@@ -148,14 +148,16 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       h1[j] = hi;
       h2[j] = j < 4 ? lo : (unsigned short)0;
     }
-    ta1 = __builtin_bit_cast(x3_bf16x8, make_uint4(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16), h1[4] | ((unsigned)h1[5] << 16), h1[6] | ((unsigned)h1[7] << 16)));
-    ta2 = __builtin_bit_cast(x3_bf16x8, make_uint4(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16), h2[4] | ((unsigned)h2[5] << 16), h2[6] | ((unsigned)h2[7] << 16)));
+    if (tid < 64) {
+      ltail[lane] = make_uint4(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16), h1[4] | ((unsigned)h1[5] << 16), h1[6] | ((unsigned)h1[7] << 16));
+      ltail[64 + lane] = make_uint4(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16), h2[4] | ((unsigned)h2[5] << 16), h2[6] | ((unsigned)h2[7] << 16));
+    }
     // this lane's tail outputs after that product: rows 4 kb + r -> tail kb, output r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = kb < a.ntail && r < a.tail_cout[kb < 2 ? kb : 0];
-      tsc[r] = (ok && a.tail_scale[kb]) ? a.tail_scale[kb][r] : 1.f;
-      tsh[r] = (ok && a.tail_shift[kb]) ? a.tail_shift[kb][r] : 0.f;
+    if (tid < 16) {
+      const int tk = tid >> 2, r = tid & 3;
+      const bool ok = tk < a.ntail && r < a.tail_cout[tk < 2 ? tk : 0];
+      par[64 + tid] = (ok && a.tail_scale[tk < 2 ? tk : 0]) ? a.tail_scale[tk < 2 ? tk : 0][r] : 1.f;
+      par[80 + tid] = (ok && a.tail_shift[tk < 2 ? tk : 0]) ? a.tail_shift[tk < 2 ? tk : 0][r] : 0.f;
     }
   }
   float pf[NPF][4];
@@ -205,10 +207,6 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // vector memory load per use, and its s_waitcnt vmcnt drains the prefetch that is supposed to fly under the MFMAs
   const int my_ych = g < ngroups ? a.y_ch[g < RAGMI_MAX_GROUPS ? g : 0] : 0;
   const int tsel = kb & 1;
-  T* const my_tail = TAILS ? static_cast<T*>(a.tail_y[tsel]) : nullptr;
-  const int64_t my_tail_bstride = TAILS ? a.tail_bstride[tsel] : 0;
-  const int my_tail_ch0 = TAILS ? a.tail_ch0[tsel] : 0, my_tail_cout = (TAILS && kb < a.ntail) ? a.tail_cout[tsel] : 0;
-  const int my_tail_relu = TAILS ? a.tail_relu[tsel] : 0;
   // XCD-aware schedule: workgroup j runs on XCD j % 8 (round-robin dispatch); give every XCD one contiguous chunk of the
   // (x-fastest) work list so that neighbouring columns — which share halo rows and cache lines — meet in the same L2
   const int chunk = (e.nwork + 7) / 8;
@@ -297,15 +295,23 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           unsigned l01, l23;
           const unsigned h01 = x3_split2(v[0], v[1], l01), h23 = x3_split2(v[2], v[3], l23);
           const x3_bf16x8 bv = __builtin_bit_cast(x3_bf16x8, make_uint4(h01, h23, l01, l23));
+          const x3_bf16x8 ta1 = __builtin_bit_cast(x3_bf16x8, ltail[lane]), ta2 = __builtin_bit_cast(x3_bf16x8, ltail[64 + lane]);
           f32x4 tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta1, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           tacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta2, bv, tacc, 0, 0, 0);
+          // destination of this lane quarter's tail: a select between the two (wave-uniform) descriptors, not an indexed load
+          const int my_tail_cout = kb < a.ntail ? (tsel ? a.tail_cout[1] : a.tail_cout[0]) : 0;
           if (my_tail_cout > 0 && inside) {
-            T* pt = my_tail + b * my_tail_bstride + (int64_t)my_tail_ch0 * DHW + vox;
+            T* const my_tail = static_cast<T*>(tsel ? a.tail_y[1] : a.tail_y[0]);
+            const int64_t tb = tsel ? a.tail_bstride[1] : a.tail_bstride[0];
+            const int tch0 = tsel ? a.tail_ch0[1] : a.tail_ch0[0], trelu = tsel ? a.tail_relu[1] : a.tail_relu[0];
+            const float4 tsc = *reinterpret_cast<const float4*>(par + 64 + 4 * kb), tsh = *reinterpret_cast<const float4*>(par + 80 + 4 * kb);
+            const float sc4[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, sh4[4] = {tsh.x, tsh.y, tsh.z, tsh.w};
+            T* pt = my_tail + b * tb + (int64_t)tch0 * DHW + vox;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (r < my_tail_cout) {
-                float u = fmaf(tacc[r], tsc[r], tsh[r]);
-                st(pt + r * DHW, my_tail_relu ? fmaxf(u, 0.f) : u);
+                float u = fmaf(tacc[r], sc4[r], sh4[r]);
+                st(pt + r * DHW, trelu ? fmaxf(u, 0.f) : u);
               }
           }
         }
@@ -386,7 +392,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   e.nwork = (int)nwork;
   e.bf16 = dtype == RAGMI_BF16 ? 1 : 0;
   const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
-                     64 * sizeof(float);
+                     2 * 64 * sizeof(uint4) + 96 * sizeof(float);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
   const dim3 grid((unsigned)std::min<int64_t>(nwork, 1024), ncog);
   if (nset == 2) {
