@@ -471,6 +471,39 @@ def test_flat_sgd_step_matches_torch_sgd(ra):
         close(s1[k].float(), s0[k].float(), 2e-3, k)
 
 
+def test_flat_sgd_resume_from_checkpoint(ra, tmp_path):
+    """Parameters that are views of FlatSGD's flat buffer survive save_checkpoint / load_checkpoint (run.py:194-196 file layout), and
+    an optimizer rebuilt from its state_dict continues exactly where the original would have."""
+    from rag_amd import checkpoint as ck
+    from rag_amd.train import FlatSGD, GradBucket, make_optimizer, train_step
+    g = load_golden("g6_train_step")
+    rows = g["rows"]
+    left, right, gt = gpu(g["left"]), gpu(g["right"]), gpu(g["gt"])
+    net = ra.Network(ra.Genotype(rows, None, rows, None), DEV, maxdisp=int(g["maxdisp"]))
+    net.load_state_dict(split_sd(g), strict=True)
+    net = net.to(DEV).train()
+    bucket = GradBucket(net.parameters())
+    opt = make_optimizer(net.parameters(), lr=1e-3, bucket=bucket)
+    for _ in range(2):
+        train_step(net, opt, bucket, left, right, gt)
+    path = tmp_path / "resume.ckpt"
+    ck.save_checkpoint(path, net, [net.arch_init], task=0, optimizer=opt)
+    data = torch.load(path, map_location="cpu", weights_only=False)
+    net2, _ = ck.load_checkpoint(data, device=DEV)
+    net2 = net2.train()
+    for k, v in net.state_dict().items():
+        close(net2.state_dict()[k].float(), v.float(), 0.0, k)
+    bucket2 = GradBucket(net2.parameters())
+    opt2 = make_optimizer(net2.parameters(), lr=1e-3, bucket=bucket2)
+    assert isinstance(opt2, FlatSGD)
+    opt2.load_state_dict(data["optimizer"])
+    l1 = float(train_step(net, opt, bucket, left, right, gt))
+    l2 = float(train_step(net2, opt2, bucket2, left, right, gt))
+    assert abs(l1 - l2) <= 2e-4 * max(1.0, abs(l1)), (l1, l2)
+    for k, v in net.state_dict().items():
+        close(net2.state_dict()[k].float(), v.float(), 2e-4, k)
+
+
 def test_training_step_issues_no_memcpy_or_memset(ra):
     """Nothing in forward + loss + backward may be a device memcpy / memset: captured into a hipGraph those become memcpy /
     memset NODES, which this runtime does not replay safely next to null-stream copies (rag_amd.train.GraphedTrainStep).
