@@ -26,33 +26,6 @@ namespace ragmi {
 // one pack element per thread: packed[((g*nchunks + ch)*NVG + v)*64 + lane]
 // transpose: the source is the weight of the FORWARD conv, [Cin][Cout][taps]; pack its data-gradient conv
 // W'[co][ci][tap] = W[ci][co][taps-1-tap].  planar: the source has 9 taps (a 2-D 3x3 weight) living in the dz = 1 plane.
-__global__ void conv3d_k3_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin,
-                                      int nchunks, int64_t total, int transpose, int planar) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int lane = (int)(idx & 63);
-  int64_t t = idx >> 6;
-  const int v = (int)(t % NVG);
-  t /= NVG;
-  const int ch = (int)(t % nchunks);
-  const int g = (int)(t / nchunks);
-  const int a = lane >> 2, m = lane & 3;
-  const int q = 16 * v + a;  // pair index: c_local * 27 + tap
-  float val = 0.f;
-  if (q < NPAIR) {
-    const int ci = ch * CK + q / 27, tap = q % 27, co = g * 4 + m;
-    if (ci < Cin && co < Cout) {
-      const int taps = planar ? 9 : 27;
-      int t = planar ? tap - 9 : tap;                    // planar: only dz == 1 (taps 9..17) is non-zero
-      if (t >= 0 && t < taps) {
-        if (transpose) t = taps - 1 - t;
-        val = transpose ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t];
-      }
-    }
-  }
-  packed[idx] = val;
-}
-
 // tile shape: widest x-tile whose padding waste is small; rows per lane sized so the grid still
 // fills 256 CUs a few times over.  0: TX=32,R=4   1: TX=16,R=2   2: TX=8,R=1
 static int choose_cfg(int B, int D, int H, int W) {
@@ -125,10 +98,7 @@ extern "C" int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cou
   RAGMI_REQUIRE(Cout > 0 && Cin > 0, RAGMI_EINVAL, "conv3d_k3_pack: non-positive size");
   RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3_pack: dtype %d not built", dtype);
   const int64_t total = k3_section_elems(Cout, Cin);
-  hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), (const float*)weight, (float*)packed, Cout, Cin,
-                     (Cin + CK - 1) / CK, total, transpose ? 1 : 0, planar2d ? 1 : 0);
-  x3_pack((const float*)weight, (float*)packed + total, Cout, Cin, transpose ? 1 : 0, planar2d ? 1 : 0, static_cast<hipStream_t>(stream));
+  pack_both((const float*)weight, (float*)packed, total, Cout, Cin, transpose ? 1 : 0, planar2d ? 1 : 0, static_cast<hipStream_t>(stream));
   return check_launch("conv3d_k3_pack");
 }
 

@@ -30,6 +30,34 @@ constexpr int NPAIR = CK * 27;               // (cin, tap) pairs per chunk = 108
 constexpr int NVG = (NPAIR + 15) / 16;       // VGPRs per output group per chunk = 7
 constexpr int PACK_PER_GC = NVG * 64;        // packed floats per (group, chunk) = 448
 
+// fp32-MFMA section of the packed weights: element idx of packed[groups][nchunks][NVG][64]; lane 4a+m of VGPR v holds
+// w[co = 4g + m][pair q = 16v + a] (q = c_local * 27 + tap).  transpose: the data-gradient weight (Cout <-> Cin swapped,
+// taps flipped); planar: the source is a 2-D 3x3 weight embedded in the middle z-slice.
+__device__ __forceinline__ float k3_pack_value(const float* __restrict__ w, int Cout, int Cin, int nchunks, int64_t idx, int transpose,
+                                               int planar) {
+  const int lane = (int)(idx & 63);
+  int64_t t = idx >> 6;
+  const int v = (int)(t % NVG);
+  t /= NVG;
+  const int ch = (int)(t % nchunks);
+  const int g = (int)(t / nchunks);
+  const int a = lane >> 2, m = lane & 3;
+  const int q = 16 * v + a;  // pair index: c_local * 27 + tap
+  float val = 0.f;
+  if (q < NPAIR) {
+    const int ci = ch * CK + q / 27, tap = q % 27, co = g * 4 + m;
+    if (ci < Cin && co < Cout) {
+      const int taps = planar ? 9 : 27;
+      int tt = planar ? tap - 9 : tap;                   // planar: only dz == 1 (taps 9..17) is non-zero
+      if (tt >= 0 && tt < taps) {
+        if (transpose) tt = taps - 1 - tt;
+        val = transpose ? w[((int64_t)ci * Cout + co) * taps + tt] : w[((int64_t)co * Cin + ci) * taps + tt];
+      }
+    }
+  }
+  return val;
+}
+
 struct K3Args {
   const void* x;          // activations: float or bf16_t per the kernel's storage type T
   int64_t x_bstride;
@@ -561,7 +589,8 @@ RAGMI_K3_DECL(s2_cfg2);
 #undef RAGMI_K3_DECL
 // bf16x3 form (conv3d_x3.hip): fp32 accuracy on the bf16 matrix cores, used for the big level-3 volumes
 int64_t x3_packed_words(int Cout, int Cin);
-int x3_pack(const float* w, float* dst, int Cout, int Cin, int transpose, int planar, hipStream_t s);
+// both sections of the packed weights (fp32-MFMA section of `total_k3` floats, then the bf16x3 fragments) in ONE launch
+int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, hipStream_t s);
 bool x3_eligible(const K3Args& a, int nset, int dtype);
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
 int launch_k3_valu_f32(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights

@@ -51,9 +51,8 @@ __device__ __forceinline__ unsigned x3_split2(float v0, float v1, unsigned& lo) 
 // wf[((cog * nsls + s) * 2 + hl) * 64 + lane] (uint4 = 8 bf16): A[row = lane & 15][k = 8 (lane>>4) + j],
 // k -> pair P = 8 s + 2 (lane>>4) + (j>>2) = cg * 27 + tap, channel 4 cg + (j&3).  The source is indexed like the fp32
 // pack (transpose / planar options of ragmi_conv3d_k3_pack_ex).
-__global__ void x3_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wf, int Cout, int Cin, int nsls, int ncog,
-                               int transpose, int planar) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void x3_pack_one(const float* __restrict__ w, uint4* __restrict__ wf, int Cout, int Cin, int nsls, int ncog,
+                                            int transpose, int planar, int idx) {
   if (idx >= ncog * nsls * 64) return;
   const int lane = idx & 63, s = (idx >> 6) % nsls, cog = idx / (64 * nsls);
   const int co = cog * 16 + (lane & 15), kb = lane >> 4;
@@ -326,10 +325,23 @@ int64_t x3_packed_words(int Cout, int Cin) {
   return (int64_t)ncog * nsls * 2 * 64 * 4;
 }
 
-int x3_pack(const float* w, float* dst, int Cout, int Cin, int transpose, int planar, hipStream_t s) {
+// the two sections of ragmi_conv3d_k3_pack_ex in one launch: workgroups [0, nb_k3) fill the fp32-MFMA section, the rest the
+// bf16x3 fragments (a training step packs ~150 weights; each launch it does not make is ~3.5 us)
+__global__ void pack_both_kernel(const float* __restrict__ w, float* __restrict__ packed, int64_t total_k3, int nb_k3, int Cout, int Cin,
+                                 int nchunks, int nsls, int ncog, int transpose, int planar) {
+  if ((int)blockIdx.x < nb_k3) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < total_k3) packed[idx] = k3_pack_value(w, Cout, Cin, nchunks, idx, transpose, planar);
+  } else {
+    x3_pack_one(w, reinterpret_cast<uint4*>(packed + total_k3), Cout, Cin, nsls, ncog, transpose, planar,
+                ((int)blockIdx.x - nb_k3) * 256 + threadIdx.x);
+  }
+}
+int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, hipStream_t s) {
   const int ncgs = (Cin + 3) / 4, nsls = (ncgs * 27 + 7) / 8, ncog = (Cout + 15) / 16;
-  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)ceil_div((int64_t)ncog * nsls * 64, 256)), dim3(256), 0, s, w,
-                     reinterpret_cast<uint4*>(dst), Cout, Cin, nsls, ncog, transpose, planar);
+  const int nb_k3 = (int)ceil_div(total_k3, 256), nb_x3 = (int)ceil_div((int64_t)ncog * nsls * 64, 256);
+  hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)(nb_k3 + nb_x3)), dim3(256), 0, s, w, packed, total_k3, nb_k3, Cout, Cin,
+                     (Cin + CK - 1) / CK, nsls, ncog, transpose, planar);
   return RAGMI_OK;
 }
 
