@@ -168,6 +168,12 @@ int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride,
                         int B, int Cin, int Cout, int64_t DHW,
                         int dtype, void* stream);
 
+/* The same with the weight given TRANSPOSED in memory when w_transposed != 0 (weight[ci][co], i.e. [Cin][Cout] row-major): the
+ * data gradient of a 1x1x1 conv is this conv with the forward weight read in place — no transposed copy per step. */
+int ragmi_conv3d_k1_fwd_ex(const void* x, int64_t x_bstride, const void* weight, int w_transposed, const void* scale,
+                           const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0, int B, int Cin,
+                           int Cout, int64_t DHW, int dtype, void* stream);
+
 /*
  * Trilinear resample fused into the 1x1x1 ConvBR_3d that consumes it:
  *   y[b, y_ch0 + co] = act(bn(W . interpolate(x, [Do,Ho,Wo], 'trilinear', align_corners)))

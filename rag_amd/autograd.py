@@ -88,7 +88,7 @@ class ConvBRFn(torch.autograd.Function):
             if k == 3:
                 ops.conv3d_k3(draw, ops.conv3d_k3_pack(w, transpose=True), cin, None, None, False, dx)
             else:
-                ops.conv3d_k1(draw, w.reshape(cout, cin).t().contiguous(), None, None, False, dx)
+                ops.conv3d_k1(draw, w.reshape(cout, cin), None, None, False, dx, transposed=True)   # W^T read in place
         if need_w:
             tw = _direct(mod.conv.weight)
             if k == 3:

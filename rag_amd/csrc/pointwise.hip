@@ -13,7 +13,7 @@ namespace ragmi {
 struct K1Args {
   const void* x;   // activations: float or bf16_t, per the kernel's storage type
   int64_t x_bstride;
-  const float* w;  // [Cout][Cin]
+  const float* w;  // element (co, ci) at w[co * w_sco + ci * w_sci]: [Cout][Cin] row-major, or its transpose read in place
   const float* scale;
   const float* shift;
   void* y;
@@ -22,6 +22,7 @@ struct K1Args {
   int Cin, Cout, co0;
   int64_t dhw;
   int relu;
+  int w_sco, w_sci;
 };
 
 template <class T, int NCO, bool VEC>
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
 #pragma unroll
     for (int j = 0; j < NCO; ++j) {
       const int co = a.co0 + j;
-      const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
+      const float wv = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
 #pragma unroll
       for (int k = 0; k < V; ++k) acc[j][k] = fmaf(wv, xv[k], acc[j][k]);
     }
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
 #pragma unroll
         for (int j = 0; j < NCO; ++j) {
           const int co = a.co0 + j;
-          const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
+          const float wv = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
           acc[j] = fmaf(wv, xv[u], acc[j]);
         }
       }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
 #pragma unroll
         for (int j = 0; j < NCO; ++j) {
           const int co = a.co0 + j;
-          const float wv = co < a.Cout ? a.w[(int64_t)co * a.Cin + ci] : 0.f;
+          const float wv = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
           acc[j] = fmaf(wv, xv, acc[j]);
         }
       }
@@ -193,7 +194,7 @@ static int fill_k1r(K1RArgs& r, const void* x, int64_t x_bstride, int Di, int Hi
                 "conv3d_k1_resample: bad size");
   RAGMI_REQUIRE(B <= 65535 && (int64_t)Di * Hi * Wi < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: size too large");
   r.k = K1Args{x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
-               y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu};
+               y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu, Cin, 1};
   r.Di = Di; r.Hi = Hi; r.Wi = Wi; r.Do = Do; r.Ho = Ho; r.Wo = Wo;
   r.sd = lin_scale(Di, Do, align_corners); r.sh = lin_scale(Hi, Ho, align_corners); r.sw = lin_scale(Wi, Wo, align_corners);
   r.align = align_corners ? 1 : 0;
@@ -290,6 +291,12 @@ static void launch_k1(const K1Args& a, int B, hipStream_t s) {
 extern "C" int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride, const void* weight, const void* scale,
                                    const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0, int B, int Cin,
                                    int Cout, int64_t DHW, int dtype, void* stream) {
+  return ragmi_conv3d_k1_fwd_ex(x, x_bstride, weight, 0, scale, shift, relu, y, y_bstride, y_ch0, B, Cin, Cout, DHW, dtype, stream);
+}
+
+extern "C" int ragmi_conv3d_k1_fwd_ex(const void* x, int64_t x_bstride, const void* weight, int w_transposed, const void* scale,
+                                      const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0, int B, int Cin,
+                                      int Cout, int64_t DHW, int dtype, void* stream) {
   using namespace ragmi;
   RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k1: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1: scale/shift must both be given or both NULL");
@@ -297,7 +304,7 @@ extern "C" int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride, const void*
   RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1: dtype %d not built", dtype);
   RAGMI_REQUIRE(B <= 65535 && Cout <= 4 * 65535, RAGMI_EUNSUPPORTED, "conv3d_k1: B or Cout too large");
   K1Args a{x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
-           y, y_bstride, y_ch0, Cin, Cout, 0, DHW, relu};
+           y, y_bstride, y_ch0, Cin, Cout, 0, DHW, relu, w_transposed ? 1 : Cin, w_transposed ? Cout : 1};
   // 16-B columns need alignment; small volumes use one voxel per thread for 4x the parallelism
   const bool vec = (DHW % 4 == 0) && (x_bstride % 4 == 0) && (y_bstride % 4 == 0) && aligned4(x, dtype) && aligned4(y, dtype) &&
                    (int64_t)B * DHW >= (1 << 18);

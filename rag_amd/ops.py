@@ -255,19 +255,22 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
 
 
 def conv3d_k1(x: torch.Tensor, weight2d: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
-              relu: bool, out: torch.Tensor, out_ch0: int = 0) -> torch.Tensor:
-    """Fused 1x1x1 ConvBR_3d writing out[:, out_ch0:out_ch0+Cout]."""
+              relu: bool, out: torch.Tensor, out_ch0: int = 0, transposed: bool = False) -> torch.Tensor:
+    """Fused 1x1x1 ConvBR_3d writing out[:, out_ch0:out_ch0+Cout].  `transposed`: weight2d is [Cin, Cout] (the forward weight of
+    the conv whose data gradient this is), read in place."""
     _need_gpu(weight2d, scale, shift)
     dt = _act(x, out)
     B, Cin = x.shape[:2]
-    Cout = weight2d.shape[0]
+    Cout = weight2d.shape[1 if transposed else 0]
+    if not weight2d.is_contiguous() or weight2d.shape[0 if transposed else 1] != Cin:
+        raise ValueError("conv3d_k1: weight must be contiguous [Cout, Cin] (or [Cin, Cout] with transposed=True)")
     dhw = 1
     for s in x.shape[2:]:
         dhw *= s
     if out_ch0 + Cout > out.shape[1] or tuple(out.shape[2:]) != tuple(x.shape[2:]):
         raise ValueError("conv3d_k1: output buffer too small / wrong spatial size")
-    check(load_library().ragmi_conv3d_k1_fwd(
-        x.data_ptr(), _planes(x), weight2d.data_ptr(),
+    check(load_library().ragmi_conv3d_k1_fwd_ex(
+        x.data_ptr(), _planes(x), weight2d.data_ptr(), int(transposed),
         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
         out.data_ptr(), _planes(out), out_ch0, B, Cin, Cout, dhw, dt, _stream()), "conv3d_k1")
     return out

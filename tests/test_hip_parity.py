@@ -332,6 +332,19 @@ def test_conv3d_k1_resample_pair_vs_aten(ra, cins, cout, shapes, size):
     assert float(out[:, 2 * cout:].abs().max()) == 0.0
 
 
+def test_conv3d_k1_transposed_weight(ra):
+    """ragmi_conv3d_k1_fwd_ex with the weight transposed in memory ([Cin, Cout]) == the plain call on its transposed copy: the
+    1x1x1 data gradient reads the forward weight in place."""
+    x = torch.randn((2, 24, 3, 5, 7), generator=gen(60))
+    w = torch.randn((10, 24), generator=gen(61)) * 0.2            # conv 24 -> 10
+    ref = torch.empty((2, 10, 3, 5, 7), device=DEV)
+    ra.ops.conv3d_k1(gpu(x), gpu(w), None, None, False, ref)
+    out = torch.zeros((2, 12, 3, 5, 7), device=DEV)
+    ra.ops.conv3d_k1(gpu(x), gpu(w.t().contiguous()), None, None, False, out, 1, transposed=True)
+    np.testing.assert_array_equal(out[:, 1:11].cpu().numpy(), ref.cpu().numpy())
+    assert float(out[:, 0].abs().max()) == 0.0 and float(out[:, 11].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,H,W,stride", [(6, 12, 36, 60, 3), (3, 5, 17, 23, 2), (6, 12, 48, 96, 3), (4, 4, 9, 9, 4)])
 def test_conv2d_k3_strided_vs_aten(ra, cin, cout, H, W, stride):
     """Feature-Net stem2d1 (3x3, pad 1, stride 3; rag_model.py:201)."""
