@@ -987,8 +987,9 @@ extern "C" int ragmi_conv3d_k1_wgrad(const void* x, int64_t x_bstride, const voi
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && DHW > 0 && B <= 65535 && Cout <= 65535, RAGMI_EINVAL, "conv3d_k1_wgrad: bad size");
   const int nci = (int)ceil_div(Cin, K1W_CI), nco = (int)ceil_div(Cout, K1W_CO);
   RAGMI_REQUIRE((int64_t)nci * nco <= 65535, RAGMI_EUNSUPPORTED, "conv3d_k1_wgrad: too many channel blocks");
-  // about four workgroups per CU over the launch; each flushes 48 atomics
-  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(DHW, 256), ceil_div(1024, (int64_t)nci * nco * B)));
+  // about two workgroups per CU over the launch; each flushes 48 same-address atomics (measured on the training step:
+  // 256 -> 282.8, 512 -> 283.5, 1024 -> 281.1, 2048 -> 277.2 pairs/s)
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(DHW, 256), ceil_div(512, (int64_t)nci * nco * B)));
   hipLaunchKernelGGL(conv3d_k1_wgrad_kernel, dim3(gx, nci * nco, B), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)x,
                      x_bstride, (const float*)g, g_bstride, g_ch0, (float*)dw, Cin, Cout, DHW, nci);
   return check_launch("conv3d_k1_wgrad");
