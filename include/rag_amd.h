@@ -299,11 +299,12 @@ int ragmi_bn_train_stats_fwd(const void* x, int64_t x_bstride, int B, int C, int
                              void* workspace, void* mean, void* invstd, void* scale, void* shift, void* stream);
 
 /* the two launches of a train-mode BatchNorm + ReLU forward: statistics, then finalize (as ragmi_bn_train_stats_fwd) fused with the
- * affine + ReLU pass y[b, y_ch0+c] = act(x[b,c]*scale[c] + shift[c]) */
+ * affine + ReLU pass y[b, y_ch0+c] = act(x[b,c]*scale[c] + shift[c]) (+ res[b, res_ch0+c] when res != NULL: a cell's running sum of
+ * branches, rag_model.py:163-172, without a separate add launch) */
 int ragmi_bn_train_act_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, const void* gamma, const void* beta,
                            void* running_mean, void* running_var, void* num_batches_tracked, float momentum, float eps, int relu,
                            void* workspace, void* mean, void* invstd, void* scale, void* shift, void* y, int64_t y_bstride, int y_ch0,
-                           void* stream);
+                           const void* res, int64_t res_bstride, int res_ch0, void* stream);
 
 /* the two launches of its adjoint: the reduction of ragmi_bn_act_bwd_coeffs, then coefficients + dx = g*c1 + x*c2 + c3 in one pass
  * (dgamma / dbeta may be NULL; accumulate != 0: +=) */

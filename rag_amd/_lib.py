@@ -80,7 +80,8 @@ SIGNATURES = {
     "ragmi_sgd_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
                                     c_void_p]),
     "ragmi_bn_train_act_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
-                                       c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+                                       c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                       c_void_p, c_int64, c_int, c_void_p]),
     "ragmi_bn_act_bwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "ragmi_bn_act_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,

@@ -121,9 +121,10 @@ def _bn_forward(raw, n, gamma, beta, mod):
     return scale, shift, mean, invstd, False
 
 
-def _bn_forward_act(raw, n, gamma, beta, mod):
+def _bn_forward_act(raw, n, gamma, beta, mod, res=None):
     """BatchNorm + ReLU of a ConvBR forward: (y, scale, shift, mean, invstd, training).  Train mode is two launches
-    (ragmi_bn_train_act_fwd: statistics, then finalize + running-stat update + affine + ReLU in one kernel)."""
+    (ragmi_bn_train_act_fwd: statistics, then finalize + running-stat update + affine + ReLU in one kernel).  `res` is added after
+    the activation in the same pass (a cell's sum of branches)."""
     bn = mod.bn
     if mod.use_bn and bn.training:
         if bn.momentum is None:
@@ -131,10 +132,13 @@ def _bn_forward_act(raw, n, gamma, beta, mod):
         track = bn.track_running_stats and bn.running_mean is not None
         y, st = ops.bn_train_act(raw, gamma.detach(), beta.detach(), bn.running_mean if track else None,
                                  bn.running_var if track else None, bn.num_batches_tracked if track else None, bn.momentum, bn.eps,
-                                 mod.relu)
+                                 mod.relu, res=res)
         return y, st[2], st[3], st[0], st[1], True
     scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
-    y = ops.bn_act(raw, scale, shift, mod.relu) if (mod.use_bn or mod.relu) else raw
+    if mod.use_bn or mod.relu or res is not None:
+        y = ops.bn_act(raw, scale, shift, mod.relu, res=res)
+    else:
+        y = raw
     return y, scale, shift, mean, invstd, training
 
 
@@ -165,12 +169,18 @@ class ConvBRGroupFn(torch.autograd.Function):
     """Sibling 3x3(x3) ConvBRs that read the SAME tensor (a cell state feeding several new states, rag_model.py:163-172) as
     one convolution with the weights stacked along Cout: one forward conv, one data-gradient conv (which also sums the
     siblings' contributions to dx) and one weight-gradient launch instead of one of each per sibling; BatchNorm stays per
-    unit (each keeps its own mode, statistics and parameters).  apply(x, mods, w0, gamma0, beta0, w1, ...) -> (y0, y1, ...)."""
+    unit (each keeps its own mode, statistics and parameters).  apply(x, mods, w0, gamma0, beta0, w1, ..., res0, res1, ...) ->
+    (y0, y1, ...): the optional trailing `res_i` (one per unit, or none at all) is added to unit i's output after its activation —
+    the other branch of the state it feeds (rag_model.py:170-172), so a cell's sum of two branches costs no launch of its own."""
 
     @staticmethod
     def forward(ctx, x, mods, *params):
         x = _dense(x)
         n, C = len(mods), mods[0].conv.out_channels
+        res = [_dense(t) for t in params[3 * n:]]
+        if res and len(res) != n:
+            raise ValueError("ConvBRGroupFn: residual inputs come one per unit or not at all")
+        ctx.has_res = bool(res)
         B = x.shape[0]
         # concatenated as 2-D rows: ATen's cat of 5-D tensors falls back to one contiguous copy_ (a MEMCPY, i.e. a memcpy node of a
         # captured step — DESIGN.md 4.4) per input; up to 4-D it is one batched kernel
@@ -183,7 +193,8 @@ class ConvBRGroupFn(torch.autograd.Function):
         ctx.training = []
         for i, m in enumerate(mods):
             r = raw[:, i * C:(i + 1) * C]
-            y, scale, shift, mean, invstd, training = _bn_forward_act(r, nvox, params[3 * i + 1], params[3 * i + 2], m)
+            y, scale, shift, mean, invstd, training = _bn_forward_act(r, nvox, params[3 * i + 1], params[3 * i + 2], m,
+                                                                      res=res[i] if res else None)
             outs.append(y)
             saved += [scale, shift, mean, invstd]
             ctx.training.append(training)
@@ -219,7 +230,9 @@ class ConvBRGroupFn(torch.autograd.Function):
                 for i in range(n):
                     if need_w[i]:
                         grads[3 * i] = dw[i * C:(i + 1) * C]
-        return (dx, None, *grads)
+        # the residual enters after the activation: its gradient is the output gradient itself
+        gres = [dys[i] if ctx.needs_input_grad[2 + 3 * n + i] else None for i in range(n)] if ctx.has_res else []
+        return (dx, None, *grads, *gres)
 
 
 class StridedStemFn(torch.autograd.Function):

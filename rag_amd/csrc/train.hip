@@ -194,6 +194,9 @@ struct BnFinActArgs {
   float* y;
   int64_t x_bstride, y_bstride, dhw;
   int y_ch0, relu;
+  const float* res;        // optional: y = act(..) + res[b, res_ch0 + c] (a cell's running sum of branches)
+  int64_t res_bstride;
+  int res_ch0;
 };
 __global__ __launch_bounds__(256) void bn_finalize_act_kernel(BnFinActArgs a) {
   const int c = blockIdx.y, b = blockIdx.z;
@@ -220,15 +223,22 @@ __global__ __launch_bounds__(256) void bn_finalize_act_kernel(BnFinActArgs a) {
   if (i0 >= a.dhw) return;
   const float* px = a.x + b * a.x_bstride + (int64_t)c * a.dhw;
   float* py = a.y + b * a.y_bstride + (int64_t)(a.y_ch0 + c) * a.dhw;
+  const float* pr = a.res ? a.res + b * a.res_bstride + (int64_t)(a.res_ch0 + c) * a.dhw : nullptr;
   auto one = [&](float xv) {
     const float v = fmaf(xv, sc, sh);
     return a.relu ? fmaxf(v, 0.f) : v;
   };
-  if ((a.dhw & 3) == 0 && (((reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(py)) & 15) == 0)) {
+  const uintptr_t al = reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(py) | reinterpret_cast<uintptr_t>(pr);
+  if ((a.dhw & 3) == 0 && (al & 15) == 0) {
     const float4 xv = *reinterpret_cast<const float4*>(px + i0);
-    *reinterpret_cast<float4*>(py + i0) = make_float4(one(xv.x), one(xv.y), one(xv.z), one(xv.w));
+    float4 o = make_float4(one(xv.x), one(xv.y), one(xv.z), one(xv.w));
+    if (pr) {
+      const float4 rv = *reinterpret_cast<const float4*>(pr + i0);
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    *reinterpret_cast<float4*>(py + i0) = o;
   } else {
-    for (int k = 0; k < 4 && i0 + k < a.dhw; ++k) py[i0 + k] = one(px[i0 + k]);
+    for (int k = 0; k < 4 && i0 + k < a.dhw; ++k) py[i0 + k] = one(px[i0 + k]) + (pr ? pr[i0 + k] : 0.f);
   }
 }
 
@@ -815,7 +825,7 @@ extern "C" int ragmi_bn_train_stats_fwd(const void* x, int64_t x_bstride, int B,
 extern "C" int ragmi_bn_train_act_fwd(const void* x, int64_t x_bstride, int B, int C, int64_t DHW, const void* gamma, const void* beta,
                                       void* running_mean, void* running_var, void* num_batches_tracked, float momentum, float eps,
                                       int relu, void* workspace, void* mean, void* invstd, void* scale, void* shift, void* y,
-                                      int64_t y_bstride, int y_ch0, void* stream) {
+                                      int64_t y_bstride, int y_ch0, const void* res, int64_t res_bstride, int res_ch0, void* stream) {
   using namespace ragmi;
   RAGMI_REQUIRE(x && gamma && beta && workspace && mean && invstd && scale && shift && y, RAGMI_EINVAL, "bn_train_act: null pointer");
   RAGMI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), RAGMI_EINVAL, "bn_train_act: running_mean/var go together");
@@ -830,6 +840,7 @@ extern "C" int ragmi_bn_train_act_fwd(const void* x, int64_t x_bstride, int B, i
                        (long long*)num_batches_tracked, (float*)mean, (float*)invstd, (float*)scale, (float*)shift, nparts,
                        (double)B * (double)DHW, eps, momentum};
   a.x = (const float*)x; a.y = (float*)y; a.x_bstride = x_bstride; a.y_bstride = y_bstride; a.dhw = DHW; a.y_ch0 = y_ch0; a.relu = relu;
+  a.res = (const float*)res; a.res_bstride = res_bstride; a.res_ch0 = res_ch0;
   hipLaunchKernelGGL(bn_finalize_act_kernel, dim3((unsigned)ceil_div(DHW, 1024), C, B), dim3(256), 0, st, a);
   return check_launch("bn_train_act");
 }

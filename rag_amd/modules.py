@@ -421,7 +421,15 @@ class _Cell(nn.Module):
                        and states[j].dtype == torch.float32)
             if grouped:
                 params = [p for _k, op in convs for p in (op.conv.weight, op.bn.weight, op.bn.bias)]
-                outs = dict(zip([k for k, _op in convs], ag.ConvBRGroupFn.apply(states[j], tuple(op for _k, op in convs), *params)))
+                # every target already holding exactly one contribution: hand it to the group as that unit's residual, the sum
+                # then comes out of the BatchNorm + ReLU pass (no add launch, no extra tensor)
+                fuse = all(len(pending[k]) == 1 and pending[k][0].dtype == torch.float32 for k, _op in convs)
+                res = [pending[k][0] for k, _op in convs] if fuse else []
+                outs = dict(zip([k for k, _op in convs],
+                                ag.ConvBRGroupFn.apply(states[j], tuple(op for _k, op in convs), *params, *res)))
+                if fuse:
+                    for k, _op in convs:
+                        pending[k].clear()
             for k, op in out_ops:
                 pending[k].append(outs[k] if (grouped and isinstance(op, _ConvBR)) else op(states[j]))
         return torch.cat(states[-self.block_multiplier:], dim=1)

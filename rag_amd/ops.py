@@ -424,11 +424,15 @@ def bn_train_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, run
 
 
 def bn_train_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
-                 running_var: Optional[torch.Tensor], num_batches_tracked: Optional[torch.Tensor], momentum: float, eps: float, relu: bool):
+                 running_var: Optional[torch.Tensor], num_batches_tracked: Optional[torch.Tensor], momentum: float, eps: float, relu: bool,
+                 res: Optional[torch.Tensor] = None):
     """Train-mode BatchNorm + ReLU of the raw conv output x as two launches (ragmi_bn_train_act_fwd): returns (y, stats) with
-    stats the [4, C] tensor (mean, invstd, scale, shift); the running statistics are updated in place."""
-    _need_gpu(x, gamma, beta, running_mean, running_var)
+    stats the [4, C] tensor (mean, invstd, scale, shift); the running statistics are updated in place.  `res` (same shape) is added
+    after the activation."""
+    _need_gpu(x, gamma, beta, running_mean, running_var, res)
     B, C = x.shape[:2]
+    if res is not None and tuple(res.shape) != tuple(x.shape):
+        raise ValueError("bn_train_act: res must have the shape of x")
     lib = load_library()
     ws = torch.empty((lib.ragmi_bn_workspace_elems(B, C, _vol(x)),), device=x.device, dtype=torch.float32)
     st = torch.empty((4, C), device=x.device, dtype=torch.float32)
@@ -439,7 +443,7 @@ def bn_train_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, runni
     check(lib.ragmi_bn_train_act_fwd(x.data_ptr(), _planes(x), B, C, _vol(x), gamma.data_ptr(), beta.data_ptr(), p(running_mean),
                                      p(running_var), p(num_batches_tracked), float(momentum), float(eps), int(relu), ws.data_ptr(),
                                      st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), y.data_ptr(), _planes(y), 0,
-                                     _stream()), "bn_train_act")
+                                     p(res), _planes(res) if res is not None else 0, 0, _stream()), "bn_train_act")
     return y, st
 
 
