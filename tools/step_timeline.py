@@ -3,7 +3,8 @@
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
     python tools/step_timeline.py <dir> > profiles/rNN_step_timeline.txt
 
-The pass is found as the last run of dispatches that starts with costvol_stem_planes_kernel and ends with disp_softargmin_kernel.
+The pass is found as the last run of dispatches that starts with costvol_stem_planes_kernel (or the kernel named by a second
+argument) and ends with disp_softargmin_kernel.
 """
 import csv
 import glob
@@ -17,7 +18,7 @@ def short(name: str) -> str:
     return re.sub(r"\(.*$", "", name)
 
 
-def main(root: str) -> None:
+def main(root: str, first: str = "costvol_stem_planes_kernel") -> None:
     files = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)
     if not files:
         raise SystemExit("no *kernel_trace.csv under " + root)
@@ -26,7 +27,7 @@ def main(root: str) -> None:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "costvol_stem_planes_kernel" in r[2]]
+    starts = [i for i, r in enumerate(rows) if first in r[2]]
     ends = [i for i, r in enumerate(rows) if "disp_softargmin_kernel" in r[2]]
     if not starts or not ends:
         raise SystemExit("no forward pass found")
@@ -45,4 +46,5 @@ def main(root: str) -> None:
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else ".")
+    # optional second argument: name fragment of the pass's FIRST kernel (conv2d_k3_strided_kernel = the end-to-end pass from images)
+    main(sys.argv[1] if len(sys.argv) > 1 else ".", *(sys.argv[2:3]))
