@@ -100,13 +100,15 @@ constexpr int K3_MAX_WLDS_BYTES = 36 * 1024;   // weight cache budget per workgr
 //
 // T = activation storage type (float, or bf16_t for RAGMI_BF16): halo loads convert to fp32 on their way into LDS and
 // the epilogue rounds once at the store; LDS tile, MFMA operands, accumulators, BN and the tails are fp32 either way.
-template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
+// FLAT: the tile form for depth-1 volumes (the 2-D Feature-Net convolutions, rag_model.py:47-111): the four waves split the tile's
+// rows instead of its z-planes (TZ = 1, 4x the rows) — with one z-plane per wave three of four waves would idle there.
+template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0, bool FLAT = false>
 __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   static_assert(VCO == 0 || (G == 1 && NSET == 1 && VCO <= 4), "VALU form: one output group, one set");
   constexpr int TX = 1 << LOG_TX;
   constexpr int YS = 64 / TX;      // lane sub-rows per wave
-  constexpr int TY = YS * R;       // output rows per tile
-  constexpr int TZ = 4;            // one z-plane per wave
+  constexpr int TY = YS * R * (FLAT ? 4 : 1);   // output rows per tile
+  constexpr int TZ = FLAT ? 1 : 4; // one z-plane per wave (FLAT: one plane, waves stacked along y)
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
   constexpr int TILE = CK * HZ * HY * HX;
   // staging map: thread -> (sy, zz, xx) of the halo; passes over compile-time (c, k): yy = k*SY + sy
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
 
   // compute-side lane geometry
   const int xl = lane & (TX - 1), ysub = lane >> LOG_TX;
-  const float* rd = tile + (wave * HY + ysub * R) * HX + xl;  // lane's (c=0, dz=0, rr=0, dx=0) tap
+  const int wz = FLAT ? 0 : wave, wy = FLAT ? wave * YS * R : 0;   // this wave's plane / first row inside the tile
+  const float* rd = tile + (wz * HY + wy + ysub * R) * HX + xl;  // lane's (c=0, dz=0, rr=0, dx=0) tap
   // staging-side thread geometry
   const int sxx = tid % HX, szz = (tid / HX) % HZ, ssy = tid / (HX * HZ);
   const bool sactive = ssy < SY;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     constexpr int NM = VCO > 0 ? VCO : 4;   // channels of a group actually computed
     int b, x0, y0, z0;
     decode(t, b, x0, y0, z0);
-    const int gz = z0 + wave, gx = x0 + xl, gy0 = y0 + ysub * R;
+    const int gz = z0 + wz, gx = x0 + xl, gy0 = y0 + wy + ysub * R;
     if (!FULL && (gz >= a.D || gx >= a.W)) return;
     const unsigned off0 = (unsigned)(gz * HW + gy0 * a.W + gx);
     T* yb = static_cast<T*>(a.y) + (int64_t)b * a.y_bstride;
@@ -516,10 +519,10 @@ inline int split_groups(int ngroups) {
   return 1;
 }
 
-template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0>
+template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0, bool FLAT = false>
 static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
-  constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
-  constexpr size_t tile_bytes = (size_t)CK * 6 * (TY + 2) * (TX + 2) * sizeof(float);
+  constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R * (FLAT ? 4 : 1);
+  constexpr size_t tile_bytes = (size_t)CK * (FLAT ? 3 : 6) * (TY + 2) * (TX + 2) * sizeof(float);
   const size_t wbytes = (size_t)G * (a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0)) * PACK_PER_GC * sizeof(float);
   // cache the weights in LDS when they fit the budget (policy switch for experiments: RAGMI_K3_WLDS=0 never,
   // 1 whenever they fit, 2 (default) only for multi-stage tiles)
@@ -535,7 +538,7 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   const size_t lds = tile_bytes + (VCO > 0 ? (size_t)a.Cout * a.Cin * 27 * sizeof(float) : (a.w_in_lds ? wbytes : 0));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)std::max<size_t>(tile_bytes + K3_MAX_WLDS_BYTES, 80 * 1024));
     attr_set = true;
   }
@@ -547,31 +550,31 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   for (int i = 0; i < ncached; ++i)
     if (cached_lds[i] == lds) slots = cached_slots[i];
   if (slots == 0) {
-    slots = persistent_slots(conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO>, lds);
+    slots = persistent_slots(conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT>, lds);
     if (ncached < 8) { cached_lds[ncached] = lds; cached_slots[ncached] = slots; ++ncached; }
   }
   static const int occ_cap = [] { const char* e = getenv("RAGMI_K3_MAX_WG_PER_CU"); return e ? atoi(e) : 0; }();   // experiment
   if (occ_cap > 0) slots = std::min(slots, occ_cap * 256);
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
   if (gx >= 8) gx -= gx % 8;   // the XCD-aware schedule wants a multiple of 8 workgroups per split
-  hipLaunchKernelGGL((conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
 }
 
 // one tile configuration: sets the tile counts and launches with G = split_groups(ngroups)
-template <class T, int LOG_TX, int R, int NSET, int WPS>
+template <class T, int LOG_TX, int R, int NSET, int WPS, bool FLAT = false>
 static int launch_cfg(K3Args a, int ngroups, hipStream_t s) {
-  constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
+  constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R * (FLAT ? 4 : 1);
   a.tiles_x = (int)ceil_div(a.W, TX);
   a.tiles_y = (int)ceil_div(a.H, TY);
-  a.tiles_z = (int)ceil_div(a.D, 4);
+  a.tiles_z = (int)ceil_div(a.D, FLAT ? 1 : 4);
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
   const int G = split_groups(ngroups), nsplits = ngroups / G;
   switch (G) {
-    case 1: launch_one<T, 1, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
-    case 2: launch_one<T, 2, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
-    case 3: launch_one<T, 3, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
-    default: launch_one<T, 4, LOG_TX, R, NSET, WPS>(a, ntiles, nsplits, s); break;
+    case 1: launch_one<T, 1, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
+    case 2: launch_one<T, 2, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
+    case 3: launch_one<T, 3, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
+    default: launch_one<T, 4, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
   }
   return check_launch("conv3d_k3");
 }

@@ -2,5 +2,8 @@
 #include "conv3d_k3.h"
 
 namespace ragmi {
-int launch_k3_s2_cfg1_bf16(const K3Args& a, int ngroups, hipStream_t s) { return launch_cfg<bf16_t, 4, 2, 2, 2>(a, ngroups, s); }
+int launch_k3_s2_cfg1_bf16(const K3Args& a, int ngroups, hipStream_t s) {
+  // depth-1 volumes (the 2-D Feature-Net convolutions): the tile form whose four waves split y instead of z
+  return a.D == 1 ? launch_cfg<bf16_t, 4, 2, 2, 2, true>(a, ngroups, s) : launch_cfg<bf16_t, 4, 2, 2, 2>(a, ngroups, s);
+}
 }  // namespace ragmi
