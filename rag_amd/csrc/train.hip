@@ -660,6 +660,12 @@ __global__ __launch_bounds__(256) void disp_softargmin_bwd_kernel(DispBwdArgs a)
   const int wx0 = lin_index(min(blockIdx.x * DB_T, a.Wo - 1), a.w, a.Wo, a.sw, 0).i0;
   const int nwin = a.d * DB_WIN * DB_WIN;
   for (int e = threadIdx.x; e < nwin; e += 256) win[e] = 0.f;
+  float4* const ztab = reinterpret_cast<float4*>(win + nwin);      // [maxdisp]: the fine-disparity taps, as in the forward kernel
+  for (int dd = threadIdx.x; dd < a.maxdisp; dd += 256) {
+    const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
+    const bool same = lz.i1 == lz.i0;
+    ztab[dd] = make_float4((float)lz.i0, lz.w0, same ? 0.f : lz.w1, same ? lz.w1 : 0.f);
+  }
   __syncthreads();
   const int hw = a.h * a.w;
   const float* base = a.cost + (int64_t)b * a.d * hw;
@@ -674,37 +680,53 @@ __global__ __launch_bounds__(256) void disp_softargmin_bwd_kernel(DispBwdArgs a)
       const float* p = base + (int64_t)z * hw;
       return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
     };
+    // Both passes walk the fine disparities in order like the forward kernel (disp.hip): the coarse pair (cz, cz+1) only moves
+    // forward, so each coarse plane is sampled once per pass (not twice per fine sample), the fine taps come from the LDS table and
+    // the softmax runs in base 2 with one exponential per sample.
+    constexpr float K = 1.4426950408889634f;
     // pass 1: softmax statistics (max, sum, expectation), exactly as the forward
     float m = -INFINITY, s = 0.f, ws = 0.f;
-    for (int dd = 0; dd < a.maxdisp; ++dd) {
-      const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
-      const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
-      const float mn = fmaxf(m, t);
-      const float r = expf(m - mn), e = expf(t - mn);
-      s = s * r + e;
-      ws = ws * r + e * (float)dd;
-      m = mn;
+    {
+      int cz = 0;
+      float b0 = plane(0), b1 = plane(a.d > 1 ? 1 : 0);
+      for (int dd = 0; dd < a.maxdisp; ++dd) {
+        const float4 tb = ztab[dd];
+        const int i0 = (int)tb.x;
+        while (i0 > cz) { ++cz; b0 = b1; b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1); }
+        const float t = -fmaf(tb.y + tb.w, b0, tb.z * b1);
+        const bool up = t > m;
+        const float x = __builtin_amdgcn_exp2f((up ? m - t : t - m) * K);
+        const float r = up ? x : 1.f, e = up ? 1.f : x;
+        s = fmaf(s, r, e);
+        ws = fmaf(ws, r, e * (float)dd);
+        m = up ? t : m;
+      }
     }
     const float outv = ws / s, gout = a.dout[((int64_t)b * a.Ho + oy) * a.Wo + ox];
-    // pass 2: walk the fine samples again; a0 / a1 collect the gradient of coarse planes z / z+1
+    const float ginv = -gout / s;
+    // pass 2: walk the fine samples again; a0 / a1 collect the gradient of coarse planes cz / cz+1
     auto flush = [&](int z, float gv) {
       if (gv == 0.f) return;
       float* p = win + z * (DB_WIN * DB_WIN);
       atomicAdd(p + l00, gv * w00); atomicAdd(p + l01, gv * w01); atomicAdd(p + l10, gv * w10); atomicAdd(p + l11, gv * w11);
     };
-    int z = 0;
+    int cz = 0;
+    float b0 = plane(0), b1 = plane(a.d > 1 ? 1 : 0);
     float a0 = 0.f, a1 = 0.f;
     for (int dd = 0; dd < a.maxdisp; ++dd) {
-      const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
-      const float t = -(lz.w0 * plane(lz.i0) + lz.w1 * plane(lz.i1));
-      const float pd = expf(t - m) / s;
-      const float gv = -gout * pd * ((float)dd - outv);   // d out / d v_fine, v = +cost (softMIN)
-      while (lz.i0 > z) { flush(z, a0); a0 = a1; a1 = 0.f; ++z; }
-      a0 = fmaf(gv, lz.w0, a0);
-      if (lz.i1 != lz.i0) a1 = fmaf(gv, lz.w1, a1); else a0 = fmaf(gv, lz.w1, a0);
+      const float4 tb = ztab[dd];
+      const int i0 = (int)tb.x;
+      while (i0 > cz) {
+        flush(cz, a0); a0 = a1; a1 = 0.f;
+        ++cz; b0 = b1; b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1);
+      }
+      const float t = -fmaf(tb.y + tb.w, b0, tb.z * b1);
+      const float gv = ginv * __builtin_amdgcn_exp2f((t - m) * K) * ((float)dd - outv);   // d out / d v_fine, v = +cost (softMIN)
+      a0 = fmaf(gv, tb.y + tb.w, a0);
+      a1 = fmaf(gv, tb.z, a1);
     }
-    flush(z, a0);
-    if (z + 1 < a.d) flush(z + 1, a1);
+    flush(cz, a0);
+    if (cz + 1 < a.d) flush(cz + 1, a1);
   }
   __syncthreads();
   float* gbase = a.dcost + (int64_t)b * a.d * hw;
@@ -1042,8 +1064,8 @@ extern "C" int ragmi_disp_softargmin_bwd(const void* cost, const void* dout, voi
                 lin_scale(d, maxdisp, 0), lin_scale(h, Ho, 0), lin_scale(w, Wo, 0)};
   // the coarse window of a 16 x 16 fine tile must fit DB_WIN cells per axis: holds for the x3 upsample of Disp (16/3 + 2 taps <= 8)
   RAGMI_REQUIRE(Ho == 3 * h && Wo == 3 * w, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: built for the x3 upsample of Disp (Ho = 3h, Wo = 3w)");
-  const size_t lds = (size_t)d * DB_WIN * DB_WIN * sizeof(float);
-  RAGMI_REQUIRE(lds <= 64 * 1024, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: d = %d planes exceed the LDS window (max 256)", d);
+  const size_t lds = (size_t)d * DB_WIN * DB_WIN * sizeof(float) + (size_t)maxdisp * sizeof(float4);
+  RAGMI_REQUIRE(lds <= 64 * 1024, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: d = %d planes / maxdisp = %d exceed the LDS window", d, maxdisp);
   hipLaunchKernelGGL(disp_softargmin_bwd_kernel, dim3((unsigned)ceil_div(Wo, DB_T), (unsigned)ceil_div(Ho, DB_T), B), dim3(256), lds,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("disp_softargmin_bwd");
