@@ -646,96 +646,115 @@ struct DispBwdArgs {
   int d, h, w, maxdisp, Ho, Wo;
   float sd, sh, sw;
 };
-// A workgroup owns a 16 x 16 tile of fine pixels.  The coarse cells its pixels touch form a small window (about
-// 16/3 + 2 per axis); the per-plane contributions are summed in an LDS copy of that window (LDS float atomics) and the
-// window is flushed with one global atomic per cell per workgroup — ~40x fewer global atomics than one per tap.
+// A workgroup owns a 16 x 16 tile of fine pixels; the coarse cells its pixels touch form a window of at most 8 x 8.  All pixels
+// reach a coarse plane's flush point at the same fine disparity, so a plane's contributions are reduced over the tile WITHOUT
+// atomics: every thread parks its value in LDS, a separable gather (columns, then rows: W_x[16][8] and W_y[16][8] hold the
+// bilinear weights of each fine column / row onto the window's columns / rows) gives the 64 cell sums, and each cell is added to
+// global memory once per plane.  (The first version summed into an LDS window with ds_add_f32: ~9 lanes per address, 447 of the
+// kernel's 565 us.)
 constexpr int DB_T = 16, DB_WIN = 8;      // fine tile edge; coarse window edge (16/3 -> 6 cells + 1 each side for the taps)
 __global__ __launch_bounds__(256) void disp_softargmin_bwd_kernel(DispBwdArgs a) {
-  extern __shared__ float win[];           // [d][DB_WIN][DB_WIN]
-  const int b = blockIdx.z;
-  const int ox = blockIdx.x * DB_T + (threadIdx.x & (DB_T - 1)), oy = blockIdx.y * DB_T + (threadIdx.x >> 4);
+  extern __shared__ float4 ztab[];         // [maxdisp]: the fine-disparity taps, as in the forward kernel
+  __shared__ float pix[DB_T * DB_T], colsum[DB_T][DB_WIN], wxw[DB_T][DB_WIN], wyw[DB_T][DB_WIN];
+  const int b = blockIdx.z, tid = threadIdx.x;
+  const int tx = tid & (DB_T - 1), ty = tid >> 4;
+  const int ox = blockIdx.x * DB_T + tx, oy = blockIdx.y * DB_T + ty;
   const bool live = ox < a.Wo && oy < a.Ho;
   // window origin: the first coarse cell touched by the tile's first pixel (uniform over the workgroup)
   const int wy0 = lin_index(min(blockIdx.y * DB_T, a.Ho - 1), a.h, a.Ho, a.sh, 0).i0;
   const int wx0 = lin_index(min(blockIdx.x * DB_T, a.Wo - 1), a.w, a.Wo, a.sw, 0).i0;
-  const int nwin = a.d * DB_WIN * DB_WIN;
-  for (int e = threadIdx.x; e < nwin; e += 256) win[e] = 0.f;
-  float4* const ztab = reinterpret_cast<float4*>(win + nwin);      // [maxdisp]: the fine-disparity taps, as in the forward kernel
-  for (int dd = threadIdx.x; dd < a.maxdisp; dd += 256) {
+  for (int dd = tid; dd < a.maxdisp; dd += 256) {
     const LinIdx lz = lin_index(dd, a.d, a.maxdisp, a.sd, 0);
     const bool same = lz.i1 == lz.i0;
     ztab[dd] = make_float4((float)lz.i0, lz.w0, same ? 0.f : lz.w1, same ? lz.w1 : 0.f);
   }
+  if (tid < 2 * DB_T) {                    // bilinear weights of the tile's columns (tid < 16) / rows onto the window
+    const bool col = tid < DB_T;
+    const int k = tid & (DB_T - 1);
+    const int o = (col ? blockIdx.x : blockIdx.y) * DB_T + k, n_out = col ? a.Wo : a.Ho;
+    const LinIdx l = lin_index(min(o, n_out - 1), col ? a.w : a.h, n_out, col ? a.sw : a.sh, 0);
+    const int j0 = l.i0 - (col ? wx0 : wy0), j1 = l.i1 - (col ? wx0 : wy0);
+    for (int j = 0; j < DB_WIN; ++j) {
+      const float wv = o < n_out ? (j == j0 ? l.w0 : 0.f) + (j == j1 ? l.w1 : 0.f) : 0.f;
+      if (col) wxw[k][j] = wv; else wyw[k][j] = wv;
+    }
+  }
   __syncthreads();
   const int hw = a.h * a.w;
   const float* base = a.cost + (int64_t)b * a.d * hw;
-  if (live) {
-    const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
-    const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
-    const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1, o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
-    const float w00 = ly.w0 * lx.w0, w01 = ly.w0 * lx.w1, w10 = ly.w1 * lx.w0, w11 = ly.w1 * lx.w1;
-    const int l00 = (ly.i0 - wy0) * DB_WIN + (lx.i0 - wx0), l01 = (ly.i0 - wy0) * DB_WIN + (lx.i1 - wx0);
-    const int l10 = (ly.i1 - wy0) * DB_WIN + (lx.i0 - wx0), l11 = (ly.i1 - wy0) * DB_WIN + (lx.i1 - wx0);
-    auto plane = [&](int z) -> float {
-      const float* p = base + (int64_t)z * hw;
-      return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
-    };
-    // Both passes walk the fine disparities in order like the forward kernel (disp.hip): the coarse pair (cz, cz+1) only moves
-    // forward, so each coarse plane is sampled once per pass (not twice per fine sample), the fine taps come from the LDS table and
-    // the softmax runs in base 2 with one exponential per sample.
-    constexpr float K = 1.4426950408889634f;
-    // pass 1: softmax statistics (max, sum, expectation), exactly as the forward
-    float m = -INFINITY, s = 0.f, ws = 0.f;
-    {
-      int cz = 0;
-      float b0 = plane(0), b1 = plane(a.d > 1 ? 1 : 0);
-      for (int dd = 0; dd < a.maxdisp; ++dd) {
-        const float4 tb = ztab[dd];
-        const int i0 = (int)tb.x;
-        while (i0 > cz) { ++cz; b0 = b1; b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1); }
-        const float t = -fmaf(tb.y + tb.w, b0, tb.z * b1);
-        const bool up = t > m;
-        const float x = __builtin_amdgcn_exp2f((up ? m - t : t - m) * K);
-        const float r = up ? x : 1.f, e = up ? 1.f : x;
-        s = fmaf(s, r, e);
-        ws = fmaf(ws, r, e * (float)dd);
-        m = up ? t : m;
-      }
-    }
-    const float outv = ws / s, gout = a.dout[((int64_t)b * a.Ho + oy) * a.Wo + ox];
-    const float ginv = -gout / s;
-    // pass 2: walk the fine samples again; a0 / a1 collect the gradient of coarse planes cz / cz+1
-    auto flush = [&](int z, float gv) {
-      if (gv == 0.f) return;
-      float* p = win + z * (DB_WIN * DB_WIN);
-      atomicAdd(p + l00, gv * w00); atomicAdd(p + l01, gv * w01); atomicAdd(p + l10, gv * w10); atomicAdd(p + l11, gv * w11);
-    };
+  float* gbase = a.dcost + (int64_t)b * a.d * hw;
+  const LinIdx ly = lin_index(min(oy, a.Ho - 1), a.h, a.Ho, a.sh, 0);
+  const LinIdx lx = lin_index(min(ox, a.Wo - 1), a.w, a.Wo, a.sw, 0);
+  const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1, o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
+  auto plane = [&](int z) -> float {
+    const float* p = base + (int64_t)z * hw;
+    return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
+  };
+  // Both passes walk the fine disparities in order like the forward kernel (disp.hip): the coarse pair (cz, cz+1) only moves
+  // forward, so each coarse plane is sampled once per pass, the fine taps come from the LDS table and the softmax runs in base 2
+  // with one exponential per sample.
+  constexpr float K = 1.4426950408889634f;
+  // pass 1: softmax statistics (max, sum, expectation), exactly as the forward
+  float m = -INFINITY, s = 0.f, ws = 0.f;
+  {
     int cz = 0;
     float b0 = plane(0), b1 = plane(a.d > 1 ? 1 : 0);
-    float a0 = 0.f, a1 = 0.f;
     for (int dd = 0; dd < a.maxdisp; ++dd) {
       const float4 tb = ztab[dd];
       const int i0 = (int)tb.x;
-      while (i0 > cz) {
-        flush(cz, a0); a0 = a1; a1 = 0.f;
-        ++cz; b0 = b1; b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1);
-      }
+      while (i0 > cz) { ++cz; b0 = b1; b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1); }
       const float t = -fmaf(tb.y + tb.w, b0, tb.z * b1);
-      const float gv = ginv * __builtin_amdgcn_exp2f((t - m) * K) * ((float)dd - outv);   // d out / d v_fine, v = +cost (softMIN)
-      a0 = fmaf(gv, tb.y + tb.w, a0);
-      a1 = fmaf(gv, tb.z, a1);
+      const bool up = t > m;
+      const float x = __builtin_amdgcn_exp2f((up ? m - t : t - m) * K);
+      const float r = up ? x : 1.f, e = up ? 1.f : x;
+      s = fmaf(s, r, e);
+      ws = fmaf(ws, r, e * (float)dd);
+      m = up ? t : m;
     }
-    flush(cz, a0);
-    if (cz + 1 < a.d) flush(cz + 1, a1);
   }
-  __syncthreads();
-  float* gbase = a.dcost + (int64_t)b * a.d * hw;
-  for (int e = threadIdx.x; e < nwin; e += 256) {
-    const float v = win[e];
-    if (v == 0.f) continue;
-    const int cx = wx0 + e % DB_WIN, cy = wy0 + (e / DB_WIN) % DB_WIN, z = e / (DB_WIN * DB_WIN);
-    if (cx < a.w && cy < a.h) atomicAdd(gbase + (int64_t)z * hw + cy * a.w + cx, v);
+  const float outv = ws / s;
+  const float ginv = live ? -a.dout[((int64_t)b * a.Ho + oy) * a.Wo + ox] / s : 0.f;   // pixels outside the image contribute nothing
+  // one coarse plane's gradient: tile-wide reduction of the per-pixel values onto the window cells, then one global add per cell
+  auto flush = [&](int z, float gv) {      // called by EVERY thread at the same point
+    pix[tid] = gv;
+    __syncthreads();
+    if (tid < DB_T * DB_WIN) {             // (row r, window column j): sum over the row's 16 columns
+      const int r = tid >> 3, j = tid & (DB_WIN - 1);
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < DB_T; ++c) acc = fmaf(wxw[c][j], pix[r * DB_T + c], acc);
+      colsum[r][j] = acc;
+    }
+    __syncthreads();
+    if (tid < DB_WIN * DB_WIN) {           // (window row jy, window column jx): sum over the 16 rows
+      const int jy = tid >> 3, jx = tid & (DB_WIN - 1);
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < DB_T; ++r) acc = fmaf(wyw[r][jy], colsum[r][jx], acc);
+      const int cx = wx0 + jx, cy = wy0 + jy;
+      if (acc != 0.f && cx < a.w && cy < a.h) atomicAdd(gbase + (int64_t)z * hw + cy * a.w + cx, acc);
+    }
+    // (the next flush writes pix only after its own barrier-separated readers are done: colsum readers finish before any thread
+    // can pass the first barrier of the next flush, because they must arrive at it themselves)
+  };
+  // pass 2: walk the fine samples again; a0 / a1 collect the gradient of coarse planes cz / cz+1
+  int cz = 0;
+  float b0 = plane(0), b1 = plane(a.d > 1 ? 1 : 0);
+  float a0 = 0.f, a1 = 0.f;
+  for (int dd = 0; dd < a.maxdisp; ++dd) {
+    const float4 tb = ztab[dd];
+    const int i0 = (int)tb.x;
+    while (i0 > cz) {                      // wave- and workgroup-uniform: the table is the same for every pixel
+      flush(cz, a0); a0 = a1; a1 = 0.f;
+      ++cz; b0 = b1; b1 = plane(cz + 1 < a.d ? cz + 1 : a.d - 1);
+    }
+    const float t = -fmaf(tb.y + tb.w, b0, tb.z * b1);
+    const float gv = ginv * __builtin_amdgcn_exp2f((t - m) * K) * ((float)dd - outv);   // d out / d v_fine, v = +cost (softMIN)
+    a0 = fmaf(gv, tb.y + tb.w, a0);
+    a1 = fmaf(gv, tb.z, a1);
   }
+  flush(cz, a0);
+  if (cz + 1 < a.d) flush(cz + 1, a1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1064,8 +1083,8 @@ extern "C" int ragmi_disp_softargmin_bwd(const void* cost, const void* dout, voi
                 lin_scale(d, maxdisp, 0), lin_scale(h, Ho, 0), lin_scale(w, Wo, 0)};
   // the coarse window of a 16 x 16 fine tile must fit DB_WIN cells per axis: holds for the x3 upsample of Disp (16/3 + 2 taps <= 8)
   RAGMI_REQUIRE(Ho == 3 * h && Wo == 3 * w, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: built for the x3 upsample of Disp (Ho = 3h, Wo = 3w)");
-  const size_t lds = (size_t)d * DB_WIN * DB_WIN * sizeof(float) + (size_t)maxdisp * sizeof(float4);
-  RAGMI_REQUIRE(lds <= 64 * 1024, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: d = %d planes / maxdisp = %d exceed the LDS window", d, maxdisp);
+  const size_t lds = (size_t)maxdisp * sizeof(float4);
+  RAGMI_REQUIRE(lds <= 48 * 1024, RAGMI_EUNSUPPORTED, "disp_softargmin_bwd: maxdisp = %d exceeds the tap table (3072)", maxdisp);
   hipLaunchKernelGGL(disp_softargmin_bwd_kernel, dim3((unsigned)ceil_div(Wo, DB_T), (unsigned)ceil_div(Ho, DB_T), B), dim3(256), lds,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("disp_softargmin_bwd");
