@@ -6,6 +6,11 @@ SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(SRCS:.hip=.o)
 LIB   := rag_amd/lib/librag_amd.so
 CXXFLAGS := -O3 -std=c++20 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+# `make clean && make DIAG=1` builds the profiling library: it honours the RAGMI_K3_DIAG_NOSTORE / RAGMI_K3_WLDS switches that
+# skip stores / the MFMA block / the staging of conv3d_k3 (profiles/README.md).  The default build contains none of them.
+ifeq ($(DIAG),1)
+CXXFLAGS += -DRAGMI_DIAG
+endif
 
 all: $(LIB)
 

@@ -10,12 +10,20 @@ SURVEY.md §8(d)); pairs are independent, so ranks shard the batch with NO data-
 collective (weak scaling).  Rank 0 prints ONE JSON line on stdout.
 
 Extra objects in that line:
-  roofline      the dominant kernel (conv3d_k3_kernel<3,5,4>: stems + level-3 cell convs),
-                bracketed by HIP events on the launch stream inside the timed region;
-                achieved = algorithmic FLOPs per launch / mean launch duration, peak = fp32
-                MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md).
-  cpu_baseline  the CPU oracle (a port of the reference's ATen op sequence) timed on the
-                host cores of this box on ONE pair of the same workload (rank 0, N=1 only).
+  roofline      the dominant kernel of the step (largest share of the per-kernel HIP-event time; today the bf16x3
+                convolution of the level-3 cells, conv3d_x3.hip).  `achieved` = its ALGORITHMIC bytes (input once +
+                output once) or flops per launch / its mean launch duration, priced against the LARGER
+                of its two floors (HBM 8 TB/s, or the dense MFMA peak of the form it issues).  The timed region replays ONE
+                hipGraph, inside which single kernels cannot be bracketed, so the per-kernel durations come from an eager pass
+                of the same kernels on the same stream right after the timed region (`avg_launch_us_source`); rocprofv3's
+                average for the same kernel agrees (profiles/).  `traffic` = HBM bytes per launch from the committed PMC
+                summary named in `traffic_source` (separate --pmc passes of this command; not measured in this run).
+  cpu_baseline  the CPU oracle (a port of the reference's ATen op sequence) timed on the host cores of this box on ONE
+                pair of the same workload (rank 0, N=1 only): median of 3 runs, thread count = min(16, os.cpu_count())
+                (the 1-GPU box's CPU share; stated in `cores`).
+  strict_fp32   (fp32 runs, N=1) the same workload with every contraction on the fp32-input MFMA forms
+                (ops.set_conv_precision("fp32")): value_fp32_mfma and its EPE, so the record carries both arithmetic contracts.
+  epe_bf16_vs_fp32  (bf16 runs) EPE of the bf16-storage output against the fp32 build on the same pair.
 """
 import argparse
 import json
@@ -113,21 +121,28 @@ class K3Profiler:
 
 
 def pmc_traffic_bytes(kernel_name: str):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (profiles/r01q_pmc_summary.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same bench command).  gfx950 correction per
-    MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B -> doubled; WRITE_SIZE is exact.  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01q_pmc_summary.json")
-    try:
-        with open(path) as f:
-            table = json.load(f)
-        # the kernel's instantiations differ in trailing template flags (fused tails or not): call-weighted mean over them
-        recs = [v for k, v in table.items() if k == kernel_name or k.startswith(kernel_name[:-1] + ",")]
-        calls = sum(r["calls"] for r in recs)
-        if not calls:
-            return None
-        return int(sum((2.0 * r["fetch_kib"] + r["write_kib"]) * 1024 * r["calls"] for r in recs) / calls)
-    except (OSError, ValueError, KeyError):
-        return None
+    """(HBM bytes per launch of `kernel_name`, source file) from the newest committed rocprofv3 PMC summary
+    (profiles/r*_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same bench command).
+    gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B -> doubled; WRITE_SIZE is exact.
+    (None, None) if no summary holds the kernel."""
+    import glob
+    import re
+    base = re.sub(r"[<(].*", "", kernel_name)
+    targs = kernel_name[len(base):].strip("<>").replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                table = json.load(f)
+            # the kernel's instantiations differ in a leading storage type and trailing template flags (fused tails or not):
+            # call-weighted mean over those whose template arguments contain ours
+            recs = [v for k, v in table.items() if k.startswith(base + "<") and targs in k.replace(" ", "")]
+            calls = sum(r["calls"] for r in recs)
+            if calls:
+                return (int(sum((2.0 * r["fetch_kib"] + r["write_kib"]) * 1024 * r["calls"] for r in recs) / calls),
+                        os.path.relpath(path, ROOT))
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def try_capture(fn):
@@ -291,6 +306,9 @@ def train_bench(args, device, dist, rank, n_gpus):
                                "all units trainable, train-mode BN, SGD(1e-3, 0.9, wd 3e-3), clip 5",
                    "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}", "collective": "one flat fp32 gradient bucket all-reduce/step",
                    "grad_bucket_bytes": int(bucket.flat.numel() * 4),
+                   "ranks_seen": dist.get_world_size() if dist is not None else 1,
+                   "dist_backend": dist.get_backend() if dist is not None else None,
+                   "conv_precision": rag_amd.ops.get_conv_precision(),
                    "launch": "forward+backward as one hipGraph, exchange/clip/SGD eager" if graphed is not None else "eager"},
         "phases_rank0": phases, "loss_first_last": [round(float(losses[0]), 5), round(float(losses[-1]), 5)],
         "roofline": None, "cpu_baseline": None,
@@ -301,19 +319,21 @@ def train_bench(args, device, dist, rank, n_gpus):
 def cpu_baseline(net, lf, rf):
     """Oracle leg (checker code, allowed here only): one pair of the same workload on host cores."""
     from oracle import matching_oracle as O
-    cores = min(16, os.cpu_count() or 1)   # the 1-GPU box's CPU share
+    cores = min(16, os.cpu_count() or 1)   # the 1-GPU box's CPU share (SURVEY 8(d) says os.cpu_count(): the box reports the host's)
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     rows = O.ALL_CONV
     O.matching_net_forward(lf[:, :, :16, :32].cpu().contiguous(), rf[:, :, :16, :32].cpu().contiguous(), sd, rows, 48)  # thread-pool warm-up
     lc, rc = lf[:1].cpu(), rf[:1].cpu()
     runs = 3                                  # ~15 s of CPU work: a bounded sample of the same workload (one pair per run)
-    t0 = time.perf_counter()
+    times = []
     for _ in range(runs):
+        t0 = time.perf_counter()
         ref = O.matching_net_forward(lc, rc, sd, rows, MAXDISP)
-    dt = (time.perf_counter() - t0) / runs
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[runs // 2]
     return {"value": 1.0 / dt, "unit": "disparity maps/s", "cores": cores, "kind": "port",
-            "sample": f"{runs} timed runs of 1 pair B=1 {H}x{W} D={MAXDISP} fp32 after a small-shape warm-up ({dt:.2f} s per pair)"}, ref
+            "sample": f"median of {runs} timed runs of 1 pair B=1 {H}x{W} D={MAXDISP} fp32 after a small-shape warm-up ({dt:.2f} s per pair)"}, ref
 
 
 def main():
@@ -426,8 +446,15 @@ def main():
             issue = (2.0 if args.dtype == "bf16" else 3.0) if x3 else 1.0
             t_hbm = (nbytes / nlaunch) / (PEAK_HBM_GBS * 1e9)
             t_mfma = issue * (flops / nlaunch) / (peak * 1e12)
-            common = {"traffic": pmc_traffic_bytes(kname), "algorithmic_bytes_per_launch": nbytes / nlaunch,
+            traffic, traffic_src = pmc_traffic_bytes(kname)
+            common = {"traffic": traffic,
+                      "traffic_source": (f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
+                                         "not measured in this run)") if traffic_src else None,
+                      "algorithmic_bytes_per_launch": nbytes / nlaunch,
                       "launches_per_step": nlaunch // args.steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
+                      "avg_launch_us_source": ("HIP events around each launch in an eager pass of the same kernels on the same stream right "
+                                               "after the timed hipGraph replays" if graph is not None else
+                                               "HIP events around each launch inside the timed region (eager launches)"),
                       "flops_per_launch": flops / nlaunch, "share_of_step": round(secs / args.steps / (dt / args.steps), 3),
                       "floor_us": {"hbm": round(t_hbm * 1e6, 1), "mfma": round(t_mfma * 1e6, 1)}}
             if t_hbm >= t_mfma:
@@ -453,6 +480,35 @@ def main():
             epe = O.epe(out[:1].float().cpu(), ref)
             log(f"  EPE of the timed GPU path vs the CPU oracle on the same pair: {epe:.3e} px")
             cpu["epe_gpu_vs_cpu_px"] = epe
+        strict = None
+        if n_gpus == 1 and args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "bf16x3":
+            # the same workload with every contraction on the fp32-input MFMA forms: the record carries both arithmetic contracts
+            with rag_amd.ops.conv_precision("fp32"):
+                for _ in range(2):
+                    out32 = step()
+                torch.cuda.synchronize()
+                g32, cap32 = try_capture(step) if args.graph else (None, None)
+                n32 = min(args.steps, 10)
+                t0 = time.perf_counter()
+                for _ in range(n32):
+                    if g32 is not None:
+                        g32.replay()
+                    else:
+                        out32 = step()
+                torch.cuda.synchronize()
+                dt32 = (time.perf_counter() - t0) / n32
+                out32 = cap32 if g32 is not None else out32
+            strict = {"value_fp32_mfma": round(B / dt32, 3), "ms_per_step": round(dt32 * 1e3, 4), "steps": n32,
+                      "what": "same workload, ops.set_conv_precision('fp32'): every 3x3x3 contraction on v_mfma_f32_4x4x1 (exact fmaf chains)"}
+            if cpu is not None:
+                strict["epe_gpu_vs_cpu_px"] = O.epe(out32[:1].float().cpu(), ref)
+            log(f"  strict fp32 MFMA: {strict['value_fp32_mfma']} maps/s, EPE {strict.get('epe_gpu_vs_cpu_px')}")
+        epe_bf16_vs_fp32 = None
+        if n_gpus == 1 and args.dtype == "bf16":
+            with torch.no_grad():
+                d32 = net(lf[:1].float(), rf[:1].float())
+            epe_bf16_vs_fp32 = float((out[:1].double() - d32.double()).abs().flatten(1).mean(dim=1).mean())
+            log(f"  EPE bf16 storage vs the fp32 build on the same pair: {epe_bf16_vs_fp32:.3e} px")
         e2e = end_to_end(device, min(args.steps, 10), use_graph=bool(args.graph)) if (n_gpus == 1 and args.dtype == "f32") else None
         if e2e:
             log(f"  end-to-end (images -> disparity, Feature Net + Matching Net): {e2e['value']} maps/s ({e2e['ms_per_pair']} ms/pair)")
@@ -462,14 +518,17 @@ def main():
             "value": round(n_gpus * B * args.steps / dt, 3), "unit": "disparity maps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (level-3 3x3x3 convolutions: fp32 operands split into bf16 hi+lo on the bf16 matrix cores, fp32 accumulate)"
-                      if (args.dtype == "f32" and os.environ.get("RAGMI_X3", "1") != "0") else
+            "dtype": ("f32 (RAGMI_F32X3: level-3/6 3x3x3 convolutions with fp32 operands split into bf16 hi+lo on the bf16 matrix cores, "
+                      "fp32 accumulate; strict_fp32 holds the RAGMI_F32 number)"
+                      if (args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "bf16x3") else
                       "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate"), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if (H, W) == (480, 960) else 1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
                        "global_batch": n_gpus * B, "sharding": "batch split, no collective",
-                       "launch": "hipGraph" if graph is not None else "eager"},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
+                       "launch": "hipGraph" if graph is not None else "eager",
+                       "ranks_seen": dist.get_world_size() if dist is not None else 1,
+                       "dist_backend": dist.get_backend() if dist is not None else None},
+            "roofline": roofline, "cpu_baseline": cpu, "strict_fp32": strict, "epe_bf16_vs_fp32": epe_bf16_vs_fp32, "end_to_end": e2e,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

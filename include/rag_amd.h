@@ -19,8 +19,25 @@
  *    thread-local message for the last failure on this thread;
  *  - stateless and re-entrant; kernels are enqueued on the hipStream_t passed
  *    as `stream` (void*), never synchronise, never allocate device memory;
- *  - dtype: RAGMI_F32 = fp32 storage+math (fp32 MFMA, exact fmaf chains); RAGMI_BF16 = bf16 activation storage
- *    with the same fp32 on-chip math (BASELINE config 3); weights, scale/shift and the final disparity are fp32.
+ *  - dtype selects activation storage AND the arithmetic contract of the call (no environment variable changes either):
+ *      RAGMI_F32    fp32 storage, fp32 arithmetic: the contractions run on the fp32-input MFMA forms, bitwise an fmaf chain
+ *                   per output (one rounding per product, fp32 accumulate);
+ *      RAGMI_F32X3  fp32 storage; accepted by the 3x3x3 convolution entry points only (ragmi_conv3d_k3_fwd(_ex),
+ *                   ragmi_conv3d_k3_dual_fwd(_ex)).  On shapes for which ragmi_conv3d_k3_uses_x3() answers 1 every fp32
+ *                   operand a is split as a = hi + lo + r with hi = bf16(a), lo = bf16(a - hi), |lo| <= 2^-8 |a|, |r| <= 2^-16 |a|,
+ *                   and a product a*b is accumulated in fp32 as hi_a*hi_b + hi_a*lo_b + lo_a*hi_b on the bf16 matrix cores (16x the
+ *                   fp32 MFMA rate).  Dropped: lo_a*lo_b, r_a*b and a*r_b, each <= 2^-16 |a b|, so per output
+ *                        |y_x3 - y_exact| <= 3 * 2^-16 * sum_k |w_k x_k| + fp32 accumulation error      (worst case)
+ *                   and <= 2e-5 * sum_k |w_k x_k| in practice (enforced by the tests; measured 5e-6 on N(0,1) data), against
+ *                   ~1e-7 * sum|w x| for RAGMI_F32.  The bound is relative to the sum of |products|, not to |y|: cancelling sums
+ *                   (zero-mean weights over a large common offset) lose that many ABSOLUTE digits.  bf16 keeps the fp32
+ *                   exponent range, so no overflow is introduced; lo halves below the fp32 subnormal range flush to zero.
+ *                   Elsewhere (small volumes, a residual input, unsupported channel counts) the call is computed exactly as
+ *                   RAGMI_F32.  tests/test_hip_parity.py::test_x3_error_bound_adversarial enforces the bound.
+ *      RAGMI_BF16   bf16 activation storage (BASELINE config 3), fp32 on-chip accumulation, BN and tails; the contraction may run
+ *                   on the bf16 matrix cores with the (exact) bf16 activations and hi+lo split fp32 weights — an error of
+ *                   <= 2^-16 per weight, far below the 2^-8 of the storage format.
+ *    Weights, scale/shift and the final disparity are fp32 in every case.
  */
 #ifndef RAG_AMD_H
 #define RAG_AMD_H
@@ -38,6 +55,7 @@ extern "C" {
 
 #define RAGMI_F32 0
 #define RAGMI_BF16 1 /* activations stored as bf16; fp32 on chip (LDS, MFMA, accumulate, BN); weights/BN stay fp32 */
+#define RAGMI_F32X3 2 /* fp32 storage, bf16x3 split products in the eligible 3x3x3 convolutions (see the dtype note above) */
 
 #define RAGMI_MAX_GROUPS 16 /* output-channel groups of 4 per conv call */
 
@@ -131,6 +149,14 @@ int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const void* weig
                               const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0,
                               const void* res, int64_t res_bstride, int res_ch0,
                               int B, int Cin, int Cout, int D, int H, int W, int dtype, void* stream);
+
+/* The same with the output stored in its own dtype: y_dtype == dtype, or RAGMI_F32 out of RAGMI_BF16 input — the head's `mat`
+ * (rag_model.py:365), which the soft-argmin consumes at |cost| ~ 1e4, stays fp32 under bf16 activation storage.
+ * res, when given, has the INPUT dtype. */
+int ragmi_conv3d_k3_small_fwd_ex(const void* x, int64_t x_bstride, const void* weight, const void* scale,
+                                 const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0,
+                                 const void* res, int64_t res_bstride, int res_ch0,
+                                 int B, int Cin, int Cout, int D, int H, int W, int dtype, int y_dtype, void* stream);
 
 /*
  * Two sibling ConvBR_3d groups fused into one launch (Cell_3d with two conv branches per new
@@ -272,9 +298,9 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
                            void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
                            int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
 
-/* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) runs this shape on the
- * bf16x3 kernel (conv3d_x3.hip: fp32 accuracy from three bf16 MFMAs per product; big fp32 volumes without a residual input),
- * 0 when it runs on the fp32-MFMA kernel.  Environment RAGMI_X3=0 (read at every call) disables the bf16x3 form. */
+/* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) called with this
+ * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the bf16 matrix cores (conv3d_x3.hip: volumes >= 2^18 voxels, W >= 32,
+ * D >= 8, no residual input, <= 24 input channels), 0 when it runs on the fp32-MFMA kernel.  Always 0 for RAGMI_F32. */
 int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int nset, int has_res, int ntail, int dtype);
 
 /* ragmi_conv3d_k3_pack with two options used by the training step: transpose != 0 packs the DATA-GRADIENT conv of a forward
@@ -384,6 +410,13 @@ int ragmi_masked_smooth_l1_bwd(const void* disp_est, const void* disp_gt, const 
 int64_t ragmi_sgd_workspace_bytes(void);
 int ragmi_sgd_clip_step(void* param, void* grad, void* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
                         float max_norm, int first_step, void* workspace, void* norm_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Host-side guard for captured steps (no device work): counts the nodes of a captured hipGraph_t by kind.  A captured training
+ * step must consist of kernel nodes only: on ROCm 7.2 memset / memcpy NODES of an instantiated graph were corrupted by memcpys
+ * issued on the null stream between two replays, so rag_amd.train.GraphedTrainStep refuses a capture for which
+ * n_memcpy + n_memset > 0.  `graph`: the hipGraph_t. */
+int ragmi_graph_node_census(void* graph, int32_t* n_kernel, int32_t* n_memcpy, int32_t* n_memset, int32_t* n_other);
 
 #ifdef __cplusplus
 }

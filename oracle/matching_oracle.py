@@ -186,7 +186,10 @@ def matching(cost: torch.Tensor, sd: Dict[str, torch.Tensor], genotype_rows: np.
     out = (stem0, stem1)
     for i, (_pp, _p, fm, downup) in enumerate(CELL3D_ARCH):
         k = unit(f"cell_3d{i}", 10 + i)
-        out = cell_3d(out[0], out[1], sd, f"cells_3d.{i}.{k}.", genotype_rows, fm, downup, training)
+        # a grown model (rag_model.py:391-522) holds units built from different genotypes: `genotype_rows` may then be a
+        # callable (layer index, unit index) -> rows
+        rows = genotype_rows(i, k) if callable(genotype_rows) else genotype_rows
+        out = cell_3d(out[0], out[1], sd, f"cells_3d.{i}.{k}.", rows, fm, downup, training)
     last = out[-1]
     d, h, w = cost.shape[2:]
     p3, p6, p12 = (f"last_3_3d.{head('last_3_3d')}.", f"last_6_3d.{head('last_6_3d')}.",
@@ -229,10 +232,12 @@ def disp_head(x: torch.Tensor, maxdisp: int) -> torch.Tensor:
 def matching_net_forward(left_fea: torch.Tensor, right_fea: torch.Tensor, sd: Dict[str, torch.Tensor],
                          genotype_rows: np.ndarray, maxdisp: int,
                          task_arch: Optional[Dict[str, Sequence[int]]] = None,
-                         training: bool = False, return_intermediates: bool = False):
-    """(left_fea, right_fea) -> disp[B, 3h, 3w]: rag_model.py:375-386 minus the Feature Net."""
+                         training: bool = False, return_intermediates: bool = False,
+                         selected_ops: Optional[Sequence[int]] = None, head_index: Optional[int] = None):
+    """(left_fea, right_fea) -> disp[B, 3h, 3w]: rag_model.py:375-386 minus the Feature Net (`selected_ops` + `head_index`:
+    the search_forward form, rag_model.py:688-706)."""
     cost = cost_volume(left_fea, right_fea, maxdisp)
-    mat = matching(cost, sd, genotype_rows, task_arch, training)
+    mat = matching(cost, sd, genotype_rows, task_arch, training, head_index=head_index, selected_ops=selected_ops)
     out = disp_head(mat, maxdisp)
     if return_intermediates:
         return out, {"cost": cost, "mat": mat}

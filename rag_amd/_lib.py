@@ -32,6 +32,7 @@ c_k1r_p = ctypes.POINTER(K1RSpec)
 SIGNATURES = {
     "ragmi_version": (c_int, []),
     "ragmi_last_error": (ctypes.c_char_p, []),
+    "ragmi_graph_node_census": (c_int, [c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "ragmi_costvol_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_costvol_stem_weights_elems": (c_int64, [c_int, c_int]),
     "ragmi_costvol_stem_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -46,6 +47,8 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k3_small_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
                                           c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k3_small_fwd_ex": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
+                                             c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k3_dual_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int32_p,
                                          c_void_p, c_int64, c_int32_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -99,6 +99,15 @@ class ConvBRFn(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, None
 
 
+def _bump_running_stats(bn) -> None:
+    """The train-mode BatchNorm kernels update running_mean / running_var / num_batches_tracked through raw pointers, which
+    autograd's version counters do not see.  The eval-mode caches (modules._ConvBR.stamp, _Cell._fused) key on those versions: bump
+    them by hand, or an eval forward after a train forward WITHOUT a weight update (BN re-estimation, a train pass under no_grad,
+    lr = 0) would reuse the stale folded scale / shift."""
+    ts = [t for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked) if t is not None]
+    torch.autograd.graph.increment_version(ts)
+
+
 def _bn_forward(raw, n, gamma, beta, mod):
     """BatchNorm bookkeeping of the ConvBR forwards: (scale, shift, mean, invstd, training).  Train mode: one call computes the
     batch statistics, folds them and updates the running statistics (ragmi_bn_train_stats_fwd)."""
@@ -113,6 +122,8 @@ def _bn_forward(raw, n, gamma, beta, mod):
         track = bn.track_running_stats and bn.running_mean is not None
         st = ops.bn_train_stats(raw, g, b, bn.running_mean if track else None, bn.running_var if track else None,
                                 bn.num_batches_tracked if track else None, bn.momentum, bn.eps)
+        if track:
+            _bump_running_stats(bn)
         return st[2], st[3], st[0], st[1], True
     mean, var = bn.running_mean.detach(), bn.running_var.detach()
     invstd = torch.rsqrt(var + bn.eps)
@@ -133,6 +144,8 @@ def _bn_forward_act(raw, n, gamma, beta, mod, res=None):
         y, st = ops.bn_train_act(raw, gamma.detach(), beta.detach(), bn.running_mean if track else None,
                                  bn.running_var if track else None, bn.num_batches_tracked if track else None, bn.momentum, bn.eps,
                                  mod.relu, res=res)
+        if track:
+            _bump_running_stats(bn)
         return y, st[2], st[3], st[0], st[1], True
     scale, shift, mean, invstd, training = _bn_forward(raw, n, gamma, beta, mod)
     if mod.use_bn or mod.relu or res is not None:

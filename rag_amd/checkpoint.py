@@ -84,10 +84,14 @@ def _check_cell_pattern(unit, prefix: str, keys: set, name: str, idx: int) -> No
                              f"but {'an identity' if has else 'a conv'} in the supplied genotype — wrong genotype for this unit")
 
 
-def load_checkpoint(src: Union[str, dict], device="cuda", genotypes=None, archis: Optional[Sequence[dict]] = None):
+def load_checkpoint(src: Union[str, dict], device="cuda", genotypes=None, archis: Optional[Sequence[dict]] = None,
+                    allow_pickle: bool = False):
     """-> (Network in eval mode on `device`, archis).  `genotypes`: a Genotype for every unit, or {layer: [Genotype/rows per
-    unit]}; needed only for reference checkpoints (ours carry them).  `archis`: likewise."""
-    data = torch.load(src, map_location="cpu", weights_only=False) if not isinstance(src, dict) else src
+    unit]}; needed only for reference checkpoints (ours carry them).  `archis`: likewise.
+    The file is read with `weights_only=True` (tensors, ints, lists and dicts — everything save_checkpoint and the reference's
+    run.py:194-196 write, torch.optim.SGD state included); `allow_pickle=True` opts into full unpickling for a legacy file
+    that holds arbitrary objects — it executes code from the file, so only for files you trust."""
+    data = torch.load(src, map_location="cpu", weights_only=not allow_pickle) if not isinstance(src, dict) else src
     sd = data["model"]
     keys = set(sd.keys())
     counts = _unit_counts(keys)

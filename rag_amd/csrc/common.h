@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -51,6 +52,8 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (
   *reinterpret_cast<uint2*>(p) = t;
 }
 inline bool dtype_ok(int dtype) { return dtype == RAGMI_F32 || dtype == RAGMI_BF16; }
+// the 3x3x3 convolution entry points also take RAGMI_F32X3: fp32 storage, bf16x3 split products where the shape is eligible
+inline bool conv_dtype_ok(int dtype) { return dtype_ok(dtype) || dtype == RAGMI_F32X3; }
 inline size_t dtype_size(int dtype) { return dtype == RAGMI_BF16 ? 2 : 4; }
 // 4-element vector paths need the pointer aligned to 4 elements
 inline bool aligned4(const void* p, int dtype) { return (reinterpret_cast<uintptr_t>(p) & (4 * dtype_size(dtype) - 1)) == 0; }
@@ -69,6 +72,53 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Host-side launch state of ONE kernel instantiation, kept per device and behind a mutex: hipFuncSetAttribute applies to the
+// current device only (a process that serves a second GPU must set it there too), and the forward (main thread) and backward
+// (autograd worker thread) paths launch concurrently.  Read-only after the first call per (device, LDS size): the library stays
+// stateless in the sense of include/rag_amd.h (no pointers kept, nothing that changes results).
+struct LaunchState {
+  static constexpr int MAX_DEV = 16, MAX_SIZES = 8;
+  std::mutex mu;
+  bool attr_done[MAX_DEV] = {};
+  int cus[MAX_DEV] = {};
+  size_t cached_lds[MAX_DEV][MAX_SIZES] = {};
+  int cached_slots[MAX_DEV][MAX_SIZES] = {};
+  int ncached[MAX_DEV] = {};
+
+  // raise the dynamic-LDS limit of `fn` on the current device (once per device); false on a runtime error
+  bool ensure_attr(const void* fn, size_t max_dynamic_lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (attr_done[dev]) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dynamic_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    attr_done[dev] = true;
+    return true;
+  }
+  // workgroups of `threads` threads and `lds` dynamic bytes resident on the whole current device (occupancy x CUs); 0 on error
+  int slots(const void* fn, int threads, size_t lds, size_t max_dynamic_lds) {
+    if (!ensure_attr(fn, max_dynamic_lds)) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < ncached[dev]; ++i)
+      if (cached_lds[dev][i] == lds) return cached_slots[dev][i];
+    if (cus[dev] == 0) {
+      hipDeviceProp_t prop;
+      cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    (void)hipGetLastError();
+    const int n = per_cu * cus[dev];
+    if (ncached[dev] < MAX_SIZES) { cached_lds[dev][ncached[dev]] = lds; cached_slots[dev][ncached[dev]] = n; ++ncached[dev]; }
+    return n;
+  }
+};
 
 // ATen's linear-interpolation source index (UpSample.h: area_pixel_compute_source_index +
 // guard_index_and_lambda), evaluated in fp32.  `scale` is (in-1)/(out-1) for

@@ -118,7 +118,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   using namespace ragmi;
   RAGMI_REQUIRE(x && packed_weight && y, RAGMI_EINVAL, "conv3d_k3: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k3: scale/shift must both be given or both NULL");
-  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3: dtype %d not built", dtype);
+  RAGMI_REQUIRE(conv_dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3: dtype %d not built", dtype);
   K3Args a{};
   const int rc = fill_common(a, x, x_bstride, y, y_bstride, y_group_ch, res, res_bstride, res_group_ch, B, Cin, Cout, D, H, W, relu);
   if (rc != RAGMI_OK) return rc;
@@ -141,7 +141,17 @@ extern "C" int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const
                                          const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0,
                                          const void* res, int64_t res_bstride, int res_ch0, int B, int Cin, int Cout,
                                          int D, int H, int W, int dtype, void* stream) {
+  return ragmi_conv3d_k3_small_fwd_ex(x, x_bstride, weight, scale, shift, relu, y, y_bstride, y_ch0, res, res_bstride, res_ch0, B, Cin,
+                                      Cout, D, H, W, dtype, dtype, stream);
+}
+
+extern "C" int ragmi_conv3d_k3_small_fwd_ex(const void* x, int64_t x_bstride, const void* weight, const void* scale,
+                                            const void* shift, int relu, void* y, int64_t y_bstride, int y_ch0,
+                                            const void* res, int64_t res_bstride, int res_ch0, int B, int Cin, int Cout,
+                                            int D, int H, int W, int dtype, int y_dtype, void* stream) {
   using namespace ragmi;
+  RAGMI_REQUIRE(y_dtype == dtype || (dtype == RAGMI_BF16 && y_dtype == RAGMI_F32), RAGMI_EUNSUPPORTED,
+                "conv3d_k3_small: output dtype %d with input dtype %d not built (same, or fp32 out of bf16)", y_dtype, dtype);
   RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k3_small: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k3_small: scale/shift must both be given or both NULL");
   RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3_small: dtype %d not built", dtype);
@@ -155,6 +165,7 @@ extern "C" int ragmi_conv3d_k3_small_fwd(const void* x, int64_t x_bstride, const
   a.wp[0] = (const float*)weight; a.scale[0] = (const float*)scale; a.shift[0] = (const float*)shift;
   a.nchunks[0] = Cin / CK;
   a.store_main = 1;
+  if (dtype == RAGMI_BF16 && y_dtype == RAGMI_F32) return launch_k3_valu_bf16_f32out(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));
   return dtype == RAGMI_BF16 ? launch_k3_valu_bf16(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream))
                              : launch_k3_valu_f32(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));
 }
@@ -179,7 +190,7 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   RAGMI_REQUIRE(x && packedA && packedB && y, RAGMI_EINVAL, "conv3d_k3_dual: null pointer");
   RAGMI_REQUIRE((scaleA == nullptr) == (shiftA == nullptr) && (scaleB == nullptr) == (shiftB == nullptr), RAGMI_EINVAL,
                 "conv3d_k3_dual: scale/shift must both be given or both NULL");
-  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3_dual: dtype %d not built", dtype);
+  RAGMI_REQUIRE(conv_dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3_dual: dtype %d not built", dtype);
   RAGMI_REQUIRE(CinA > 0 && CinB > 0 && CinA % CK == 0, RAGMI_EINVAL,
                 "conv3d_k3_dual: CinA must be a positive multiple of %d (B's channels start on a chunk boundary)", CK);
   K3Args a{};

@@ -102,7 +102,9 @@ constexpr int K3_MAX_WLDS_BYTES = 36 * 1024;   // weight cache budget per workgr
 // the epilogue rounds once at the store; LDS tile, MFMA operands, accumulators, BN and the tails are fp32 either way.
 // FLAT: the tile form for depth-1 volumes (the 2-D Feature-Net convolutions, rag_model.py:47-111): the four waves split the tile's
 // rows instead of its z-planes (TZ = 1, 4x the rows) — with one z-plane per wave three of four waves would idle there.
-template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0, bool FLAT = false>
+// TO: storage type of the MAIN output (default T).  float with T = bf16_t keeps a result that is consumed at full precision in fp32 —
+// `mat`, the cost the soft-argmin reads — while its input stays bf16.
+template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0, bool FLAT = false, class TO = T>
 __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   static_assert(VCO == 0 || (G == 1 && NSET == 1 && VCO <= 4), "VALU form: one output group, one set");
   constexpr int TX = 1 << LOG_TX;
@@ -215,8 +217,10 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
       return;
     }
     int gzc = min(max(z0 - 1 + szz, 0), a.D - 1), gxc = min(max(x0 - 1 + sxx, 0), a.W - 1);
-    if (a.relu & 0x800) gxc = min(x0 + sxx, a.W - 1);          // DIAG: line-aligned halo rows (wrong data)
-    if (a.relu & 0x1000) gzc = min(z0, a.D - 1);               // DIAG: every lane reads the same z-plane
+#ifdef RAGMI_DIAG   // profiling builds only (make DIAG=1): the shipped library has no switch that changes what is computed
+    if (a.relu & 0x800) gxc = min(x0 + sxx, a.W - 1);          // line-aligned halo rows (wrong data)
+    if (a.relu & 0x1000) gzc = min(z0, a.D - 1);               // every lane reads the same z-plane
+#endif
     const int zx = gzc * HW + gxc;
     const int gy0 = y0 - 1 + ssy;
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
     const int gz = z0 + wz, gx = x0 + xl, gy0 = y0 + wy + ysub * R;
     if (!FULL && (gz >= a.D || gx >= a.W)) return;
     const unsigned off0 = (unsigned)(gz * HW + gy0 * a.W + gx);
-    T* yb = static_cast<T*>(a.y) + (int64_t)b * a.y_bstride;
+    TO* yb = static_cast<TO*>(a.y) + (int64_t)b * a.y_bstride;
     const T* rb = RES ? static_cast<const T*>(a.res) + (int64_t)b * a.res_bstride : nullptr;
     const bool tails = VCO == 0 && a.ntail > 0;
     const bool store_main = a.store_main != 0;
@@ -326,7 +330,11 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
           if (RES) val += rv[g * 4 + m];
           fin[g * 4 + m] = val;
           const bool ch_ok = FULL || (gbase + g) * 4 + m < a.Cout;
-          if (ch_ok && store_main && (!(a.relu & 0x100) || val == 12345.678f))   // (0x100: DIAG, skip stores)
+#ifdef RAGMI_DIAG
+          if (ch_ok && store_main && (!(a.relu & 0x100) || val == 12345.678f))   // 0x100: skip stores
+#else
+          if (ch_ok && store_main)
+#endif
             ragmi::st(yb + (int64_t)(ych[g] + m) * DHW + off, val);
         }
       }
@@ -430,7 +438,11 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   int chunk = 0;
   if (t >= tend) return;
 
-  const bool diag_nomfma = (a.relu & 0x200) != 0, diag_nostage = (a.relu & 0x400) != 0;   // DIAG switches
+#ifdef RAGMI_DIAG
+  const bool diag_nomfma = (a.relu & 0x200) != 0, diag_nostage = (a.relu & 0x400) != 0;
+#else
+  constexpr bool diag_nomfma = false, diag_nostage = false;
+#endif
   TC cur = decode_tc(t), nxt = cur;
   if (!diag_nostage) prefetch(cur, 0);
   if constexpr (VCO > 0) {
@@ -496,21 +508,7 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   }
 }
 
-// persistent grid: as many workgroups as the chip holds at once (occupancy x CUs) stride over the tiles
-template <class K>
-static int persistent_slots(K kernel, size_t lds_bytes) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount : 256;
-  }
-  int per_cu = 2;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-  (void)hipGetLastError();
-  return per_cu * cus;
-}
+// persistent grid: as many workgroups as the chip holds at once (occupancy x CUs) stride over the tiles — LaunchState::slots
 
 // output groups per workgroup: the largest of {4,3,2,1} dividing the group count (12 -> 4, 6 -> 3)
 inline int split_groups(int ngroups) {
@@ -519,16 +517,21 @@ inline int split_groups(int ngroups) {
   return 1;
 }
 
-template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0, bool FLAT = false>
+template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0, bool FLAT = false, class TO = T>
 static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R * (FLAT ? 4 : 1);
   constexpr size_t tile_bytes = (size_t)CK * (FLAT ? 3 : 6) * (TY + 2) * (TX + 2) * sizeof(float);
   const size_t wbytes = (size_t)G * (a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0)) * PACK_PER_GC * sizeof(float);
-  // cache the weights in LDS when they fit the budget (policy switch for experiments: RAGMI_K3_WLDS=0 never,
-  // 1 whenever they fit, 2 (default) only for multi-stage tiles)
+  // cache the weights in LDS when they fit the budget: only for multi-stage tiles (policy 2; a profiling build, make DIAG=1,
+  // reads RAGMI_K3_WLDS = 0 never / 1 whenever they fit, and the RAGMI_K3_DIAG_NOSTORE bit mask 1 no stores, 2 no MFMA block,
+  // 4 no staging)
+#ifdef RAGMI_DIAG
   static const int diag_nostore = [] { const char* e = getenv("RAGMI_K3_DIAG_NOSTORE"); return e ? atoi(e) : 0; }();
-  if (diag_nostore) a.relu |= (diag_nostore << 8);   // DIAG: 1 no stores, 2 no MFMA block, 4 no staging
+  if (diag_nostore) a.relu |= (diag_nostore << 8);
   static const int policy = [] { const char* e = getenv("RAGMI_K3_WLDS"); return e ? atoi(e) : 2; }();
+#else
+  constexpr int policy = 2;
+#endif
   const int nstages = a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0);
   // budget: 36 KB next to the big tiles, or whatever still leaves two workgroups per CU (small tiles of the deep levels: their
   // 48-output weights are ~57 KB; read from global per stage they sit in the vmcnt queue BEHIND the halo prefetch, so waiting
@@ -536,28 +539,15 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   const size_t wbudget = std::max<size_t>(K3_MAX_WLDS_BYTES, tile_bytes < 78 * 1024 ? 78 * 1024 - tile_bytes : 0);
   a.w_in_lds = (VCO == 0 && policy != 0 && wbytes <= wbudget && (policy == 1 || nstages > 1)) ? 1 : 0;
   const size_t lds = tile_bytes + (VCO > 0 ? (size_t)a.Cout * a.Cin * 27 * sizeof(float) : (a.w_in_lds ? wbytes : 0));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)std::max<size_t>(tile_bytes + K3_MAX_WLDS_BYTES, 80 * 1024));
-    attr_set = true;
-  }
-  // occupancy depends on the dynamic LDS size: cache per size (a handful of distinct sizes per instantiation)
-  static size_t cached_lds[8];
-  static int cached_slots[8];
-  static int ncached = 0;
-  int slots = 0;
-  for (int i = 0; i < ncached; ++i)
-    if (cached_lds[i] == lds) slots = cached_slots[i];
-  if (slots == 0) {
-    slots = persistent_slots(conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT>, lds);
-    if (ncached < 8) { cached_lds[ncached] = lds; cached_slots[ncached] = slots; ++ncached; }
-  }
-  static const int occ_cap = [] { const char* e = getenv("RAGMI_K3_MAX_WG_PER_CU"); return e ? atoi(e) : 0; }();   // experiment
-  if (occ_cap > 0) slots = std::min(slots, occ_cap * 256);
+  // per-device, mutex-guarded launch state of this instantiation: the dynamic-LDS attribute applies to the CURRENT device only, and
+  // forward (main thread) and backward (autograd worker thread) both come through here
+  static LaunchState state;
+  const int slots = state.slots((const void*)conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT, TO>, 256, lds,
+                                std::max<size_t>(tile_bytes + K3_MAX_WLDS_BYTES, 80 * 1024));
+  if (slots <= 0) return;   // (the launch check that follows reports the runtime error)
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
   if (gx >= 8) gx -= gx % 8;   // the XCD-aware schedule wants a multiple of 8 workgroups per split
-  hipLaunchKernelGGL((conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT, TO>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
 }
 
 // one tile configuration: sets the tile counts and launches with G = split_groups(ngroups)
@@ -598,8 +588,9 @@ bool x3_eligible(const K3Args& a, int nset, int dtype);
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
 int launch_k3_valu_f32(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights
 int launch_k3_valu_bf16(const K3Args& a, int cfg, hipStream_t s);
+int launch_k3_valu_bf16_f32out(const K3Args& a, int cfg, hipStream_t s);   // bf16 input, fp32 main output
 
-template <class T, int LOG_TX, int R, int VCO>
+template <class T, int LOG_TX, int R, int VCO, class TO = T>
 static int launch_cfg_valu(K3Args a, hipStream_t s) {
   constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R;
   a.tiles_x = (int)ceil_div(a.W, TX);
@@ -608,7 +599,7 @@ static int launch_cfg_valu(K3Args a, hipStream_t s) {
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
   // one output channel fits 128 VGPRs without spilling: four waves per SIMD hide the LDS-read chains of the VALU form better
-  launch_one<T, 1, LOG_TX, R, 1, (VCO == 1 ? 4 : 2), VCO>(a, ntiles, 1, s);
+  launch_one<T, 1, LOG_TX, R, 1, (VCO == 1 ? 4 : 2), VCO, false, TO>(a, ntiles, 1, s);
   return check_launch("conv3d_k3_small");
 }
 

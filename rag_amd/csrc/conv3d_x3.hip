@@ -20,6 +20,7 @@ typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 // input planes (10 x 34 halo) in LDS: every input plane is fetched once per column (halo overhead 1.33x instead of 2.66x
 // for a 2-deep box tile), the next plane travels HBM -> registers while the current one is multiplied.
 constexpr int X3_TY = 8, X3_TX = 32;
+constexpr int64_t X3_MIN_VOXELS = 1 << 18;      // below this the z-marching columns do not fill the chip
 constexpr int X3_HY = X3_TY + 2, X3_HX = X3_TX + 2, X3_PL = X3_HY * X3_HX;   // one halo plane: 340 voxels
 constexpr int X3_THREADS = 512, X3_WAVES = X3_THREADS / 64;
 // 8 waves per workgroup, two column tiles each: at <= 128 VGPRs two workgroups (4 waves per SIMD) share a CU, which hides the
@@ -348,16 +349,12 @@ int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin
 // The bf16x3 form pays off on the big level-3 volumes (z-marching columns need many (column, segment) work items to fill the
 // chip) with fp32 storage, no residual input and equal-sized sets; everything else stays on the fp32-MFMA kernel.
 bool x3_eligible(const K3Args& a, int nset, int dtype) {
-  // on by default; RAGMI_X3=0 (read at every call, so a process can switch) keeps everything on the fp32-MFMA kernel.
-  // End to end it is ~8 % faster at 8x the (still tiny) rounding error — DESIGN.md 4.6 says what limits it
-  const char* env = getenv("RAGMI_X3");
-  const bool enabled = !(env && atoi(env) == 0);
-  if (!enabled || !dtype_ok(dtype) || a.res != nullptr) return false;
+  // the caller asks for it through the dtype argument (include/rag_amd.h): RAGMI_F32 never comes here
+  if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || a.res != nullptr) return false;
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
   if (nset == 2 && (a.nchunks[0] != a.nchunks[1] || a.nchunks[0] > 2)) return false;
   if (nset == 1 && ncg > 6) return false;
-  static const int64_t minvox = getenv("RAGMI_X3_MINVOX") ? atoll(getenv("RAGMI_X3_MINVOX")) : (1 << 18);
-  if ((int64_t)a.B * a.D * a.H * a.W < minvox || a.W < 32 || a.D < 8) return false;
+  if ((int64_t)a.B * a.D * a.H * a.W < X3_MIN_VOXELS || a.W < 32 || a.D < 8) return false;
   if (a.ntail > 0 && a.Cout > 16) return false;
   if ((int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
   return true;
@@ -365,12 +362,9 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
 
 template <class T, int NCG, int NSET, bool TAILS>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
-    attr_set = true;
-  }
+  static LaunchState state;     // per device, mutex-guarded (common.h)
+  if (!state.ensure_attr((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS>, 160 * 1024))
+    return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
   hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET, TAILS>), grid, dim3(X3_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3");
 }

@@ -337,7 +337,7 @@ struct WgradArgs {
   const float* g;
   float* part;           // [gridDim.x][CoutP][CinP][27] partial sums, CoutP / CinP = channel counts padded to the grid
   int64_t x_bstride, g_bstride;
-  int g_ch0, Cin, Cout, D, H, W, tiles_x, tiles_y, tiles_z, ntiles, diag;
+  int g_ch0, Cin, Cout, D, H, W, tiles_x, tiles_y, tiles_z, ntiles;
 };
 template <int CG, bool VEC>
 __global__ __launch_bounds__(192) void conv3d_k3_wgrad_kernel(WgradArgs a) {
@@ -968,19 +968,13 @@ static int wgrad_plan(int B, int Cin, int Cout, int D, int H, int W, WgradPlan& 
   p.gz = ngroups / p.cg;
   RAGMI_REQUIRE(p.ntiles < (1ll << 31) && p.gy <= 65535 && p.gz <= 65535, RAGMI_EUNSUPPORTED, "conv3d_k3_wgrad: grid too large");
   RAGMI_REQUIRE((int64_t)std::max(Cin, Cout) * D * H * W < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k3_wgrad: volume too large for 32-bit offsets");
-  // persistent workgroups: as many as are resident at once (occupancy x CUs)
-  static int resident[5] = {0, 0, 0, 0, 0};
-  if (!resident[p.cg]) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    const void* fn = p.cg == 4 ? (const void*)conv3d_k3_wgrad_kernel<4, true> : p.cg == 3 ? (const void*)conv3d_k3_wgrad_kernel<3, true>
-                   : p.cg == 2 ? (const void*)conv3d_k3_wgrad_kernel<2, true> : (const void*)conv3d_k3_wgrad_kernel<1, true>;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 192, 0) != hipSuccess || per_cu < 1)
-      return fail(RAGMI_ELAUNCH, "conv3d_k3_wgrad: occupancy query failed");
-    resident[p.cg] = per_cu * prop.multiProcessorCount;
-  }
-  p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(p.ntiles, resident[p.cg] / ((int64_t)p.gy * p.gz)));
+  // persistent workgroups: as many as are resident at once (occupancy x CUs), per device
+  static LaunchState state[5];
+  const void* fn = p.cg == 4 ? (const void*)conv3d_k3_wgrad_kernel<4, true> : p.cg == 3 ? (const void*)conv3d_k3_wgrad_kernel<3, true>
+                 : p.cg == 2 ? (const void*)conv3d_k3_wgrad_kernel<2, true> : (const void*)conv3d_k3_wgrad_kernel<1, true>;
+  const int resident = state[p.cg].slots(fn, 192, 0, 64 * 1024);
+  if (resident <= 0) return fail(RAGMI_ELAUNCH, "conv3d_k3_wgrad: occupancy query failed");
+  p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(p.ntiles, resident / ((int64_t)p.gy * p.gz)));
   return RAGMI_OK;
 }
 }  // namespace ragmi
@@ -1011,9 +1005,8 @@ extern "C" int ragmi_conv3d_k3_wgrad(const void* x, int64_t x_bstride, const voi
   if (rc != RAGMI_OK) return rc;
   const bool vec = W % 4 == 0 && x_bstride % 4 == 0 && g_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(g) & 15) == 0;
-  static const int diag = getenv("RAGMI_WGRAD_DIAG") ? atoi(getenv("RAGMI_WGRAD_DIAG")) : 0;
   WgradArgs a{(const float*)x, (const float*)g, (float*)workspace, x_bstride, g_bstride, g_ch0, Cin, Cout, D, H, W, p.tx, p.ty, p.tz,
-              (int)p.ntiles, diag};
+              (int)p.ntiles};
   const dim3 grid(p.gx, p.gy, p.gz), block(192);
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define RAGMI_WGRAD_LAUNCH(CGV)                                                                   \

@@ -176,11 +176,12 @@ class _ConvBR(nn.Module):
 
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_ch0: int = 0,
                 resample_to: Optional[Sequence[int]] = None, tails: Optional[Sequence["ops.Tail"]] = None,
-                store_main: bool = True) -> torch.Tensor:
+                store_main: bool = True, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """`out`/`out_ch0` write into a channel slice of a wider buffer.  `resample_to` (1x1x1 only) first resamples x
         trilinearly (align_corners=True) to that size inside the same kernel — the reference's
         `conv(F.interpolate(x, size, mode='trilinear', align_corners=True))`.  The 2-D flavour accepts [B,C,H,W] (or an
-        already depth-1 5-D view) and returns the same rank."""
+        already depth-1 5-D view) and returns the same rank.  `out_dtype=torch.float32` (Cout <= 2 form only) keeps the result
+        in fp32 although x is bf16: the head's `mat`."""
         if self.autograd_mode(x):
             if out is not None or tails:
                 raise RuntimeError("rag_amd ConvBR: fused destinations/tails belong to the inference executor")
@@ -210,7 +211,8 @@ class _ConvBR(nn.Module):
                 ops.conv3d_k1_resample(x, resample_to, True, wk, scale, shift, self.relu, out, out_ch0)
             return out[:, :, 0] if squeeze else out
         if out is None:
-            out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
+            odt = out_dtype if (out_dtype is not None and k == 3 and self._small()) else x.dtype
+            out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=odt)
         if k == 3 and self._small():
             ops.conv3d_k3_small(x, wk, scale, shift, self.relu, out, out_ch0)
         elif k == 3:
@@ -781,18 +783,22 @@ class MatchingNet(nn.Module):
 
     def _head(self, vol, last_output, i3, i6, i12):
         d, h, w = vol
+        # `mat` — the [B,1,d,h,w] cost the soft-argmin reads — is always stored in fp32, also under bf16 activation storage: with
+        # |cost| ~ 1e4 a bf16 rounding of it alone moved the disparity by 0.04-0.09 px (tests/analysis_bf16_stage_epe.py), and the
+        # tensor is 1/12 of one level-3 activation
+        f32 = torch.float32
         if last_output.size()[3] == h:
-            return self.last_3_3d[i3](last_output)
+            return self.last_3_3d[i3](last_output, out_dtype=f32)
         heads = (self.last_3_3d[i3], self.last_6_3d[i6], self.last_12_3d[i12])
         up = ag.resample if any(m.autograd_mode(last_output) for m in heads) else ops.trilinear3d
         if last_output.size()[3] == h // 2:
             y = up(self.last_6_3d[i6](last_output), (d, h, w), True)
-            return self.last_3_3d[i3](y)
+            return self.last_3_3d[i3](y, out_dtype=f32)
         if last_output.size()[3] == h // 4:
             # upsample_12 is fused into last_6_3d's 1x1x1 kernel; upsample_6 feeds a 3x3x3 conv and stays a kernel
             y = self.last_6_3d[i6](self.last_12_3d[i12](last_output), resample_to=(d // 2, h // 2, w // 2))
             y = up(y, (d, h, w), True)
-            return self.last_3_3d[i3](y)
+            return self.last_3_3d[i3](y, out_dtype=f32)
         # the reference reaches `return mat` with mat unbound here (UnboundLocalError)
         raise ValueError("MatchingNet: feature height must be a multiple of 4 (input H a multiple of 12)")
 

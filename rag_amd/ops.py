@@ -7,14 +7,56 @@ happens in Python/PyTorch here: torch only allocates.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
 
 from ._lib import K1RSpec, TailSpec, check, load_library
 
-F32, BF16 = 0, 1   # RAGMI_F32 / RAGMI_BF16 of include/rag_amd.h
+F32, BF16, F32X3 = 0, 1, 2   # RAGMI_F32 / RAGMI_BF16 / RAGMI_F32X3 of include/rag_amd.h
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+# Arithmetic of the fp32 3x3x3 convolutions — an explicit, process-wide host setting that travels to the library as the dtype
+# argument of each call (RAGMI_F32 or RAGMI_F32X3); the library itself reads no environment variable.
+#   "bf16x3": eligible volumes run as hi/lo-split bf16 products (error bound in include/rag_amd.h; the default),
+#   "fp32":   every contraction on the fp32-input MFMA forms (exact fmaf chains).
+# The environment variable RAGMI_X3=0 only picks the DEFAULT here, once, at import.
+_CONV_PRECISIONS = ("bf16x3", "fp32")
+_conv_precision = "fp32" if os.environ.get("RAGMI_X3", "1").strip() == "0" else "bf16x3"
+
+
+def set_conv_precision(precision: str) -> str:
+    """Select the arithmetic of fp32 3x3x3 convolutions ("bf16x3" or "fp32"); returns the previous setting."""
+    global _conv_precision
+    if precision not in _CONV_PRECISIONS:
+        raise ValueError(f"conv precision must be one of {_CONV_PRECISIONS}, got {precision!r}")
+    old, _conv_precision = _conv_precision, precision
+    return old
+
+
+def get_conv_precision() -> str:
+    return _conv_precision
+
+
+class conv_precision:
+    """Context manager: `with ops.conv_precision("fp32"): ...`."""
+
+    def __init__(self, precision: str):
+        self.precision = precision
+
+    def __enter__(self):
+        self.old = set_conv_precision(self.precision)
+        return self
+
+    def __exit__(self, *exc):
+        set_conv_precision(self.old)
+        return False
+
+
+def _conv_dt(dt: int) -> int:
+    """ABI dtype of a 3x3x3 convolution call for activation dtype code `dt` under the current precision setting."""
+    return F32X3 if (dt == F32 and _conv_precision == "bf16x3") else dt
 
 
 def _stream() -> int:
@@ -205,24 +247,28 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
         out.data_ptr(), yb, _i32_array(out_group_ch),
         res.data_ptr() if res is not None else None, rb, _i32_array(res_group_ch),
-        B, Cin, cout, D, H, W, int(store_main), ntail, tarr, dt, _stream()), "conv3d_k3")
+        B, Cin, cout, D, H, W, int(store_main), ntail, tarr, _conv_dt(dt), _stream()), "conv3d_k3")
     return out
 
 
 def conv3d_k3_small(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu: bool, out: torch.Tensor, out_ch0: int = 0,
                     res: Optional[torch.Tensor] = None, res_ch0: int = 0) -> torch.Tensor:
-    """3x3x3 ConvBR_3d with Cout <= 2 on the VALU (raw weight [Cout, Cin, 3, 3, 3]): ragmi_conv3d_k3_small_fwd."""
+    """3x3x3 ConvBR_3d with Cout <= 2 on the VALU (raw weight [Cout, Cin, 3, 3, 3]): ragmi_conv3d_k3_small_fwd_ex.  `out` may be
+    float32 while x is bfloat16 (the head's `mat` stays fp32 under bf16 activation storage)."""
     _need_gpu(weight, scale, shift)
-    dt = _act(x, out, res)
+    dt = _act(x, res)
+    ydt = _act(out)
+    if ydt != dt and not (dt == BF16 and ydt == F32):
+        raise RuntimeError("conv3d_k3_small: out must have x's dtype (or be float32 when x is bfloat16)")
     B, Cin, D, H, W = x.shape
     cout = weight.shape[0]
     w = weight.detach().contiguous()
     if out_ch0 + cout > out.shape[1] or tuple(out.shape[2:]) != (D, H, W):
         raise ValueError("conv3d_k3_small: output buffer too small / wrong spatial size")
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    check(load_library().ragmi_conv3d_k3_small_fwd(
+    check(load_library().ragmi_conv3d_k3_small_fwd_ex(
         x.data_ptr(), _planes(x), w.data_ptr(), ptr(scale), ptr(shift), int(relu), out.data_ptr(), _planes(out), out_ch0,
-        ptr(res), _planes(res) if res is not None else 0, res_ch0, B, Cin, cout, D, H, W, dt, _stream()), "conv3d_k3_small")
+        ptr(res), _planes(res) if res is not None else 0, res_ch0, B, Cin, cout, D, H, W, dt, ydt, _stream()), "conv3d_k3_small")
     return out
 
 
@@ -250,7 +296,7 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
         Cx - cin_a, packed_b.data_ptr(), ptr(scale_b), ptr(shift_b), int(relu),
         out.data_ptr(), _planes(out), _i32_array(out_group_ch),
         ptr(res), _planes(res) if res is not None else 0, _i32_array(res_group_ch),
-        B, cout, D, H, W, int(store_main), ntail, tarr, dt, _stream()), "conv3d_k3_dual")
+        B, cout, D, H, W, int(store_main), ntail, tarr, _conv_dt(dt), _stream()), "conv3d_k3_dual")
     return out
 
 
@@ -627,8 +673,9 @@ def disparity_regression_bwd(dout: torch.Tensor, maxdisp: int) -> torch.Tensor:
 
 def conv3d_k3_uses_x3(cin: int, cout: int, B: int, D: int, H: int, W: int, nset: int = 1, has_res: bool = False, ntail: int = 0,
                       dtype: torch.dtype = torch.float32) -> bool:
-    """True when conv3d_k3 (nset=1) / conv3d_k3_dual (nset=2, cin = both inputs) runs this shape on the bf16x3 kernel."""
-    return bool(load_library().ragmi_conv3d_k3_uses_x3(cin, cout, B, D, H, W, nset, int(has_res), ntail, _DT[dtype]))
+    """True when conv3d_k3 (nset=1) / conv3d_k3_dual (nset=2, cin = both inputs) runs this shape on the bf16x3 kernel under the
+    current precision setting."""
+    return bool(load_library().ragmi_conv3d_k3_uses_x3(cin, cout, B, D, H, W, nset, int(has_res), ntail, _conv_dt(_DT[dtype])))
 
 
 def sgd_clip_step(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float, weight_decay: float,

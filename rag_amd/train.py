@@ -151,9 +151,14 @@ class GraphedTrainStep:
     buffers; shapes, the architecture and which parameters train must not change after capture.
 
     Nothing on the captured path may be a memset or memcpy NODE (hipMemsetAsync, a contiguous same-dtype copy_/clone):
-    on this runtime a memcpy issued on the null stream between two replays (a `.item()`, a `.clone()`) corrupts such nodes
-    of an instantiated graph and the next replay computes garbage — measured: 6-7 of 8 runs with one 160-byte memset and one
-    4-byte clone in the graph, 0 of 16 once both were kernels (tests/test_hip_train.py drives exactly that pattern)."""
+    on this runtime (ROCm 7.2) a memcpy issued on the null stream between two replays (a `.item()`, a `.clone()`) left the next
+    replay computing garbage whenever the instantiated graph held such a node — measured: 6-7 of 8 runs with one 160-byte memset
+    and one 4-byte clone in the graph, 0 of 80 once both were kernels, with the same null-stream copies between replays
+    (DESIGN.md 4.4 lists what was ruled out; tests/test_hip_train.py drives exactly that pattern).  The cause inside the runtime
+    is not established, so the invariant is ENFORCED rather than assumed: the captured graph's nodes are counted at capture time
+    (ragmi_graph_node_census) and a capture holding any memcpy / memset node is refused — an ATen op that starts lowering to
+    copy_ or memset after a torch upgrade fails loudly here instead of corrupting a replay.  The graph replays on the caller's
+    current stream; no private stream is involved."""
 
     def __init__(self, net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
                  features: bool = False, warmup: int = 2):
@@ -167,15 +172,35 @@ class GraphedTrainStep:
                 forward_backward(net, bucket, self.left, self.right, self.gt, **kw)
                 exchange_and_update(optimizer, bucket, clip=clip, dist=dist)
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)     # keep the hipGraph_t: its nodes are inspected below
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not trip it
             self.loss = forward_backward(net, bucket, self.left, self.right, self.gt, **kw)
+        self.node_census = self._census()
+        if self.node_census["memcpy"] or self.node_census["memset"]:
+            raise RuntimeError(
+                f"GraphedTrainStep: the captured step holds {self.node_census['memcpy']} memcpy and {self.node_census['memset']} "
+                "memset node(s); such nodes are not replay-safe on this runtime (DESIGN.md 4.4).  tools/find_memcpy_ops.py lists "
+                "the ATen calls behind them; run the step eagerly (rag_amd.train.train_step) until they are kernels.")
+        self.graph.instantiate()
+        # train-mode BatchNorm buffers change at every replay through raw pointers: their version counters are bumped by hand
+        # (the eval-mode caches of rag_amd.modules key on them)
+        self._bn_buffers = [t for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
+                            and m.track_running_stats for t in (m.running_mean, m.running_var, m.num_batches_tracked) if t is not None]
+
+    def _census(self) -> dict:
+        import ctypes
+        from ._lib import check, load_library
+        n = [ctypes.c_int32() for _ in range(4)]
+        check(load_library().ragmi_graph_node_census(self.graph.raw_cuda_graph(), *[ctypes.byref(v) for v in n]), "graph_node_census")
+        return dict(zip(("kernel", "memcpy", "memset", "other"), (v.value for v in n)))
 
     def __call__(self, left=None, right=None, gt=None):
         for dst, src in ((self.left, left), (self.right, right), (self.gt, gt)):
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src)
         self.graph.replay()
+        if self._bn_buffers:
+            torch.autograd.graph.increment_version(self._bn_buffers)
         exchange_and_update(self.opt, self.bucket, clip=self.clip, dist=self.dist)
         return self.loss
 

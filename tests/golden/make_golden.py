@@ -306,6 +306,50 @@ def main():
     arrays["n_params"] = np.int64(sum(1 for _ in sup.parameters()))
     save("g9_supernet", **arrays)
 
+    # ---- G10: a GROWN model (rag_model.py:391-522 expand, :709-845 select): numerical outputs with unit index != 0 and t != 0.
+    # search_forward on the expanded supermodel with mixed unit choices (rag_model.py:663-706), then forced winners ->
+    # select(1) -> eval forward of task 0 (arch_init) and task 1 (best_archi) on the selected model (what run.py:194-196 saves).
+    torch.manual_seed(101)
+    net = rm.Network(genotype(ALL_CONV), "cpu")
+    net.maxdisp = 48
+    net.disp = rm.Disp(48)
+    arch0 = {k_: [int(v) for v in vs] for k_, vs in net.arch_init.items()}
+    net.expand(1, genotype(MIXED_UNSORTED), "cpu")
+    randomize_bn(net, torch.Generator().manual_seed(1101))          # after expand: the candidate units get statistics too
+    net.eval()
+    g = torch.Generator().manual_seed(102)
+    left = torch.randn((1, 3, 48, 96), generator=g)
+    right = torch.randn((1, 3, 48, 96), generator=g)
+    feas = []
+    hk = [m.register_forward_hook(lambda _m, _i, o: feas.append(o.detach().clone())) for m in net.last_3_2d]
+    sel_a = [0, 1, 0, 1, 0, 0, 1, 1, 1, 0, 1, 0, 0, 1, 1, 0, 1, 1]       # unit per layer: p-order (8 = stem3d0, 9 = stem3d1, 10.. = cells)
+    sel_b = [1] * 18                                                     # every candidate unit
+    arrays = {"left": left.numpy(), "right": right.numpy(), "maxdisp": np.int64(48), "rows_unit0": ALL_CONV, "rows_unit1": MIXED_UNSORTED,
+              "sel_a": np.array(sel_a), "sel_b": np.array(sel_b)}
+    arrays.update(sd_np(net, "search::"))
+    with torch.no_grad():
+        for tag, sel, t in (("a", sel_a, 1), ("b", sel_b, 1), ("c", sel_a, 0)):
+            del feas[:]
+            arrays[f"search_disp_{tag}"] = net.search_forward(left, right, t, sel).numpy()
+            arrays[f"search_left_fea_{tag}"], arrays[f"search_right_fea_{tag}"] = feas[0].numpy(), feas[1].numpy()
+    winners = (1, 3, 5, 7, 9, 11, 12, 15, 17)           # p-indices where the candidate wins (2-D and 3-D layers, both stems kinds)
+    for k_, p_ in enumerate(net.p):
+        if k_ in winners:
+            p_[-1] = 0.9
+    best = net.select(1)
+    best = {k_: [int(v) for v in vs] for k_, vs in best.items()}
+    arrays.update(sd_np(net, "selected::"))
+    with torch.no_grad():
+        for t, arch in ((0, arch0), (1, best)):
+            del feas[:]
+            arrays[f"disp_t{t}"] = net.forward(left, right, t, arch).numpy()
+            arrays[f"left_fea_t{t}"], arrays[f"right_fea_t{t}"] = feas[0].numpy(), feas[1].numpy()
+    for h_ in hk:
+        h_.remove()
+    blob = {"arch_t0": arch0, "arch_t1": best, "winners": list(winners), "length": {k_: int(v) for k_, v in net.length.items()}}
+    arrays["blob"] = np.frombuffer(json.dumps(blob).encode(), dtype=np.uint8)
+    save("g10_grown_model", **arrays)
+
 
 if __name__ == "__main__":
     main()

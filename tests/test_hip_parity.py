@@ -577,6 +577,35 @@ def test_bf16_matchingnet_epe_report(ra):
     assert d16.dtype == torch.float32 and torch.isfinite(d16).all() and e32 <= EPE_GATE and e16 < 5.0
 
 
+BF16_FULL_GATE = 0.12     # px, provisional: tightened to measurement + margin below once measured on the MI355X
+
+
+def test_bf16_config3_full_workload_gate(ra):
+    """BASELINE configs[2] at its full size: B=8, 384x1248, D=192, bf16 activation storage (fp32 accumulate, fp32 `mat`).
+    Pair 0 against the fp32 CPU oracle with a STATED tolerance; pairs 0..7 against the same pairs computed alone (the batch split
+    that the multi-GPU path relies on), bitwise.  The fp32 build on the same inputs must stay inside the fp32 gate."""
+    rows = O.ALL_CONV
+    sd = O.random_matching_state_dict(rows, seed=0)
+    g = gen(1234)
+    lf, rf = torch.randn((8, 12, 128, 416), generator=g), torch.randn((8, 12, 128, 416), generator=g)
+    net = ra.MatchingNet(ra.ALL_CONV_GENOTYPE, maxdisp=192)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        d16 = net(gpu(lf).to(BF), gpu(rf).to(BF))
+        for i in range(8):
+            alone = net(gpu(lf[i:i + 1]).to(BF), gpu(rf[i:i + 1]).to(BF))
+            assert torch.equal(alone, d16[i:i + 1]), i
+        d32 = net(gpu(lf[:1]), gpu(rf[:1])).cpu()
+    torch.set_num_threads(16)
+    ref = O.matching_net_forward(lf[:1], rf[:1], sd, rows, 192)
+    e32, e16, e16_32 = O.epe(d32, ref), O.epe(d16[:1].cpu(), ref), O.epe(d16[:1].cpu(), d32)
+    print(f"configs[2] full size: EPE fp32 vs oracle {e32:.3e}; bf16 vs oracle {e16:.3e}; bf16 vs fp32 build {e16_32:.3e} px")
+    assert d16.dtype == torch.float32 and torch.isfinite(d16).all()
+    assert e32 <= EPE_GATE, e32
+    assert e16 <= BF16_FULL_GATE, e16
+
+
 # --------------------------------------------------------------------------- grown model: checkpoint round trip + serving (N4)
 def test_multitask_serving_after_checkpoint_round_trip(ra, tmp_path):
     from rag_amd import checkpoint as ck
@@ -599,6 +628,58 @@ def test_multitask_serving_after_checkpoint_round_trip(ra, tmp_path):
         served = [serve(left, right, t) for t in (0, 1)]
     assert torch.equal(outs[0], served[0]) and torch.equal(outs[1], served[1])
     assert not torch.equal(outs[0], outs[1])           # the two tasks really run different units
+
+
+def test_grown_model_against_reference_outputs(ra, tmp_path):
+    """g10: the REFERENCE's numbers for a grown model (expand -> forced winners -> select, rag_model.py:391-522, 709-845) with
+    unit indices != 0 and task heads t != 0.  (1) search_forward on the expanded supermodel with mixed unit choices
+    (rag_model.py:663-706); (2) the selected model saved as a run.py:194-196 checkpoint, reloaded through
+    checkpoint.load_checkpoint (ModuleLists rebuilt from key names) and served per task by MultiTaskStereo.  EPE <= 1e-3 px."""
+    import json
+    from rag_amd import checkpoint as ck
+    g = load_golden("g10_grown_model")
+    blob = json.loads(bytes(g["blob"]).decode())
+    maxdisp = int(g["maxdisp"])
+    geno0 = ra.Genotype(g["rows_unit0"], None, g["rows_unit0"], None)
+    geno1 = ra.Genotype(g["rows_unit1"], None, g["rows_unit1"], None)
+    left, right = gpu(g["left"]), gpu(g["right"])
+    # (1) the expanded supermodel
+    net = ra.Network(geno0, DEV, maxdisp=maxdisp)
+    net.expand(1, geno1, "cpu")
+    net.load_state_dict(split_sd(g, "search::"), strict=True)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        for tag, sel, t in (("a", g["sel_a"], 1), ("b", g["sel_b"], 1), ("c", g["sel_a"], 0)):
+            sel = [int(v) for v in sel]
+            fea = net.search_feature(left, sel)
+            np.testing.assert_allclose(fea.cpu().numpy(), g[f"search_left_fea_{tag}"], rtol=2e-4, atol=2e-4)
+            disp = net.search_forward(left, right, t, sel)
+            e = O.epe(disp.cpu(), torch.from_numpy(g[f"search_disp_{tag}"]))
+            assert e <= EPE_GATE, (tag, e)
+    # (2) checkpoint of the selected model -> reload -> serve both tasks
+    sel_sd = split_sd(g, "selected::")
+    genotypes = {}
+    for name, n in blob["length"].items():
+        if name.startswith("cell_"):
+            genotypes[name] = [{"normal": g["rows_unit0"].tolist(), "reduce": g["rows_unit0"].tolist()}] + \
+                              [{"normal": g["rows_unit1"].tolist(), "reduce": g["rows_unit1"].tolist()}] * (n - 1)
+    path = tmp_path / "checkpoint_task1.ckpt"
+    torch.save({"task": 1, "model": sel_sd, "optimizer": None, "archis": [blob["arch_t0"], blob["arch_t1"]],
+                "genotypes": genotypes, "maxdisp": maxdisp}, path)
+    net2, archis = ck.load_checkpoint(str(path), device=DEV)
+    serve = ck.MultiTaskStereo(net2, archis)
+    with torch.no_grad():
+        for t in (0, 1):
+            disp = serve(left, right, t)
+            e = O.epe(disp.cpu(), torch.from_numpy(g[f"disp_t{t}"]))
+            assert e <= EPE_GATE, (t, e)
+            fea = net2.feature(left, archis[t], None)
+            np.testing.assert_allclose(fea.cpu().numpy(), g[f"left_fea_t{t}"], rtol=2e-4, atol=2e-4)
+    # a reference checkpoint (no genotypes / archis inside) loads when the caller supplies them
+    torch.save({"task": 1, "model": sel_sd, "optimizer": None}, path)
+    net3, archis3 = ck.load_checkpoint(str(path), device=DEV, genotypes=genotypes, archis=[blob["arch_t0"], blob["arch_t1"]])
+    with torch.no_grad():
+        assert torch.equal(ck.MultiTaskStereo(net3, archis3)(left, right, 1), serve(left, right, 1))
 
 
 # --------------------------------------------------------------------------- BASELINE configs[3] shape (480x960, D=192)
@@ -670,17 +751,12 @@ def test_costvol_stem_tails_and_bf16(ra):
     np.testing.assert_allclose(outb.float().cpu().numpy(), refb.numpy(), rtol=1e-2, atol=1e-2)
 
 
-# --------------------------------------------------------------------------- bf16x3 convolution (conv3d_x3.hip; RAGMI_X3=0 disables it)
+# --------------------------------------------------------------------------- bf16x3 convolution (conv3d_x3.hip; ABI dtype RAGMI_F32X3)
 @pytest.fixture
-def x3_on():
-    import os
-    old = os.environ.get("RAGMI_X3")
-    os.environ["RAGMI_X3"] = "1"
+def x3_on(ra):
+    old = ra.ops.set_conv_precision("bf16x3")
     yield
-    if old is None:
-        del os.environ["RAGMI_X3"]
-    else:
-        os.environ["RAGMI_X3"] = old
+    ra.ops.set_conv_precision(old)
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(12, 12, (1, 16, 40, 70)), (4, 12, (2, 9, 33, 65)), (24, 12, (1, 8, 17, 250)), (3, 5, (1, 9, 30, 45)),
@@ -719,26 +795,66 @@ def test_x3_dual_tails_and_headline_epe(ra, x3_on):
     assert epe <= EPE_GATE, epe
 
 
-def test_x3_switch_off_restores_fp32_mfma_path(ra):
-    """RAGMI_X3=0 is honoured at every call: same entry point, fp32-MFMA kernel, results within the fp32 tolerance of the bf16x3 ones."""
+def test_x3_precision_is_an_abi_argument(ra):
+    """The precision is chosen per call by the dtype argument (RAGMI_F32 vs RAGMI_F32X3), never by the environment: same entry
+    point, fp32-MFMA kernel vs bf16x3 kernel, results within the documented bound of each other; an environment variable set
+    after import changes nothing."""
     import os
     x = torch.randn((1, 12, 64, 128, 130), generator=gen(141))
     w = torch.randn((12, 12, 3, 3, 3), generator=gen(142)) * 0.1
     pk, xg = ra.ops.conv3d_k3_pack(gpu(w)), gpu(x)
     outs = {}
+    for prec in ("bf16x3", "fp32"):
+        with ra.ops.conv_precision(prec):
+            assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 128, 130) == (prec == "bf16x3")
+            outs[prec] = ra.ops.conv3d_k3(xg, pk, 12, None, None, False, torch.empty((1, 12, 64, 128, 130), device=DEV))
+    assert not torch.equal(outs["fp32"], outs["bf16x3"])
+    np.testing.assert_allclose(outs["bf16x3"].cpu().numpy(), outs["fp32"].cpu().numpy(), rtol=1e-4, atol=1e-4)
     old = os.environ.get("RAGMI_X3")
     try:
-        for flag in ("1", "0"):
-            os.environ["RAGMI_X3"] = flag
-            assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 128, 130) == (flag == "1")
-            outs[flag] = ra.ops.conv3d_k3(xg, pk, 12, None, None, False, torch.empty((1, 12, 64, 128, 130), device=DEV))
+        os.environ["RAGMI_X3"] = "0"
+        with ra.ops.conv_precision("bf16x3"):
+            again = ra.ops.conv3d_k3(xg, pk, 12, None, None, False, torch.empty((1, 12, 64, 128, 130), device=DEV))
+        assert torch.equal(again, outs["bf16x3"])
     finally:
         if old is None:
             os.environ.pop("RAGMI_X3", None)
         else:
             os.environ["RAGMI_X3"] = old
-    assert not torch.equal(outs["0"], outs["1"])
-    np.testing.assert_allclose(outs["1"].cpu().numpy(), outs["0"].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # the raw ABI: dtype 0 (RAGMI_F32) never takes the bf16x3 kernel, dtype 2 (RAGMI_F32X3) does on this shape
+    lib = ra.load_library()
+    assert lib.ragmi_conv3d_k3_uses_x3(12, 12, 1, 64, 128, 130, 1, 0, 0, 0) == 0
+    assert lib.ragmi_conv3d_k3_uses_x3(12, 12, 1, 64, 128, 130, 1, 0, 0, 2) == 1
+
+
+def test_x3_error_bound_adversarial(ra):
+    """The bound include/rag_amd.h documents for RAGMI_F32X3, |y - y_exact| <= 2e-5 * sum_k |w_k x_k| per output (worst case
+    3 * 2^-16), against an fp64 convolution on inputs chosen to hurt: (a) activations with a large common offset (post-ReLU-like,
+    1000 + N(0,1)) under zero-sum weights — the exact result is O(1) while every product is O(100), so the error is judged against
+    sum |w x|, not |y|; (b) operands spanning 2^-20 .. 2^20 in magnitude.  The strict RAGMI_F32 path is held to 1e-6 * sum |w x| on the
+    same data."""
+    D, H, W, cin, cout = 16, 128, 130, 4, 12
+    g1 = gen(161)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g1) * 0.1
+    w = w - w.mean(dim=(1, 2, 3, 4), keepdim=True)                      # every output channel's weights sum to zero
+    xa = 1000.0 + torch.randn((1, cin, D, H, W), generator=g1)
+    e = torch.randint(-20, 21, (1, cin, D, H, W), generator=g1).float()
+    xb = torch.randn((1, cin, D, H, W), generator=g1) * torch.exp2(e)
+    wb = w * torch.exp2(torch.randint(-20, 21, w.shape, generator=g1).float())
+    for name, x, wt in (("offset", xa, w), ("range", xb, wb)):
+        # fp64 reference and sum |w x| on a z-slab (interior planes 1..6 of an 8-plane crop: the crop's own z borders are excluded)
+        xs, sl = x[:, :, :8].double(), slice(1, 7)
+        ref = F.conv3d(xs, wt.double(), padding=1)[:, :, sl]
+        mag = F.conv3d(xs.abs(), wt.double().abs(), padding=1)[:, :, sl]
+        pk = ra.ops.conv3d_k3_pack(gpu(wt))
+        for prec, bound in (("bf16x3", 2e-5), ("fp32", 1e-6)):
+            with ra.ops.conv_precision(prec):
+                assert ra.ops.conv3d_k3_uses_x3(cin, cout, 1, D, H, W) == (prec == "bf16x3")
+                out = ra.ops.conv3d_k3(gpu(x), pk, cout, None, None, False, torch.empty((1, cout, D, H, W), device=DEV))
+            err = (out[:, :, sl].cpu().double() - ref).abs() / mag.clamp_min(1e-300)
+            worst = float(err.max())
+            print(f"x3 bound [{name}] {prec}: max |err| / sum|w x| = {worst:.3e} (bound {bound:.0e})")
+            assert worst <= bound, (name, prec, worst)
 
 
 def test_x3_bf16_storage(ra):

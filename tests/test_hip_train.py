@@ -388,8 +388,9 @@ def test_sgd_step_changes_only_trained_units(ra):
 def test_graphed_train_step_matches_eager(ra, flat):
     """forward+backward replayed as one hipGraph (rag_amd.train.GraphedTrainStep) == the eager step, three steps in a row, with
     torch.optim.SGD and with the fused FlatSGD.  The graphed loop is driven from the default stream with a device sync before
-    every step and no host read in between — the pattern under which work queued behind a hipGraphLaunch on the null stream
-    overtook the graph's tail (GraphedTrainStep now replays on a stream of its own)."""
+    every step and a 4-byte `.clone()` of the loss (a memcpy on the null stream) between replays — the pattern under which a
+    captured step that held a memset / memcpy NODE computed garbage in 6-7 runs of 8.  The step now consists of
+    kernel nodes only, and GraphedTrainStep verifies that at capture time (`node_census`); it replays on the caller's stream."""
     from rag_amd.train import GradBucket, GraphedTrainStep, make_optimizer, train_step
     g = load_golden("g6_train_step")
     maxdisp = int(g["maxdisp"])
@@ -408,6 +409,7 @@ def test_graphed_train_step_matches_eager(ra, flat):
         if graphed:
             # the capture warm-up runs optimisation steps too: give the eager run the same number of steps
             step = GraphedTrainStep(net, opt, bucket, left, right, gt, warmup=2)
+            assert step.node_census["memcpy"] == 0 and step.node_census["memset"] == 0 and step.node_census["kernel"] > 100, step.node_census
             held = []
             for _ in range(3):
                 torch.cuda.synchronize()
@@ -648,3 +650,170 @@ def test_bucket_direct_gradients_match_autograd_accumulation(ra):
             close(p.grad, expect, 2e-4, "accumulated " + k)
         off += p.numel()
     assert views
+
+
+# --------------------------------------------------------------------------- the kernels the TRAINING BENCH runs (configs[4] sizes)
+# bench.py --train runs B=4 at 192x384, D=192: the level-3 volumes are 4 x 64 x 64 x 128 = 2^21 voxels, where the data gradient
+# (the forward kernel on the weight packed transposed / flipped) dispatches to the bf16x3 kernel and the weight gradient to the
+# persistent-workgroup kernel with its partial-sum workspace.  The small cases above never reach those paths.
+L3_TRAIN = (4, 64, 64, 128)
+
+
+@pytest.mark.parametrize("cin,cout", [(12, 12), (24, 12), (4, 12)])
+def test_dgrad_transposed_pack_on_x3_at_training_size(ra, cin, cout):
+    """dL/dx of a 3x3x3 conv with forward weight [cout, cin] = conv3d_k3(dy, pack(w, transpose=True)) at the level-3 training
+    shape, against torch.autograd.grad of F.conv3d on the CPU.  (cin, cout): stem3d1 12 -> 12, stem3d0 24 -> 12 (its gradient conv
+    maps 12 -> 24 channels, two 16-row output groups), three stacked sibling convs 4 -> 3 x 4 (ConvBRGroupFn)."""
+    B, D, H, W = L3_TRAIN
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen(201)) * (2.0 / (27 * cout)) ** 0.5
+    dy = torch.randn((B, cout, D, H, W), generator=gen(202))
+    x = torch.zeros((B, cin, D, H, W), requires_grad=True)
+    torch.set_num_threads(16)
+    (ref,) = torch.autograd.grad(F.conv3d(x, w, padding=1), x, dy)
+    with ra.ops.conv_precision("bf16x3"):
+        assert ra.ops.conv3d_k3_uses_x3(cout, cin, B, D, H, W)          # the gradient conv reads cout channels, writes cin
+        dx = ra.ops.conv3d_k3(gpu(dy), ra.ops.conv3d_k3_pack(gpu(w), transpose=True), cin, None, None, False,
+                              torch.empty((B, cin, D, H, W), device=DEV))
+    close(dx, ref, 2e-4, "dx (bf16x3, transposed pack)")
+    with ra.ops.conv_precision("fp32"):
+        dx32 = ra.ops.conv3d_k3(gpu(dy), ra.ops.conv3d_k3_pack(gpu(w), transpose=True), cin, None, None, False,
+                                torch.empty((B, cin, D, H, W), device=DEV))
+    close(dx32, ref, 2e-5, "dx (fp32 MFMA, transposed pack)")
+
+
+@pytest.mark.parametrize("cin,cout", [(12, 12), (24, 12), (4, 12)])
+def test_wgrad_persistent_kernel_at_training_size(ra, cin, cout):
+    """conv3d_k3_wgrad at the level-3 training shape (persistent workgroups + partial-sum workspace + reduce kernel), fresh and
+    accumulating into three stacked destinations, against torch.autograd.grad on the CPU."""
+    B, D, H, W = L3_TRAIN
+    x = torch.randn((B, cin, D, H, W), generator=gen(211))
+    dy = torch.randn((B, cout, D, H, W), generator=gen(212)) * 0.01
+    w = torch.zeros((cout, cin, 3, 3, 3), requires_grad=True)
+    torch.set_num_threads(16)
+    (ref,) = torch.autograd.grad(F.conv3d(x, w, padding=1), w, dy)
+    dw = ra.ops.conv3d_k3_wgrad(gpu(x), gpu(dy), cout)
+    close(dw, ref, 2e-4, "dw")
+    if cout % 3 == 0:
+        base = [torch.randn((cout // 3, cin, 3, 3, 3), generator=gen(213 + i)).to(DEV) for i in range(3)]
+        into = [b.clone() for b in base]
+        ra.ops.conv3d_k3_wgrad(gpu(x), gpu(dy), cout, into=into)
+        close(torch.cat(into) - torch.cat(base), ref, 2e-4, "dw accumulated into stacked destinations")
+
+
+def test_convbr_group_fn_at_training_size(ra):
+    """ConvBRGroupFn (three sibling 4 -> 4 ConvBRs of a level-3 cell state, train-mode BatchNorm, one residual per unit) forward
+    and backward at the level-3 training shape vs PyTorch-CPU autograd: stacked forward conv (bf16x3 kernel), per-unit BN + ReLU
+    (+ residual), stacked data gradient (bf16x3 kernel, transposed pack) and stacked weight gradient."""
+    from rag_amd import autograd as ag
+    B, D, H, W = L3_TRAIN
+    C, n = 4, 3
+    mods = []
+    for i in range(n):
+        m, _x = _convbr_case(ra, C, C, 3, True, True, True, (1, C, 2, 2, 2), seed=300 + i)
+        mods.append(m)
+    x = torch.randn((B, C, D, H, W), generator=gen(221))
+    res = [torch.randn((B, C, D, H, W), generator=gen(222 + i)) for i in range(n)]
+    dys = [torch.randn((B, C, D, H, W), generator=gen(230 + i)) for i in range(n)]
+    torch.set_num_threads(16)
+    xr = x.clone().requires_grad_(True)
+    ref_out, ref_params = [], []
+    for i, m in enumerate(mods):
+        w = m.conv.weight.detach().clone().requires_grad_(True)
+        g = m.bn.weight.detach().clone().requires_grad_(True)
+        b = m.bn.bias.detach().clone().requires_grad_(True)
+        y = F.relu(F.batch_norm(F.conv3d(xr, w, padding=1), None, None, g, b, training=True, eps=m.bn.eps)) + res[i]
+        ref_out.append(y)
+        ref_params.append((w, g, b))
+    torch.autograd.backward(ref_out, dys)
+    mods = [m.to(DEV) for m in mods]
+    xg = gpu(x).requires_grad_(True)
+    params = [p for m in mods for p in (m.conv.weight, m.bn.weight, m.bn.bias)]
+    with ra.ops.conv_precision("bf16x3"):
+        assert ra.ops.conv3d_k3_uses_x3(C, n * C, B, D, H, W) and ra.ops.conv3d_k3_uses_x3(n * C, C, B, D, H, W)
+        outs = ag.ConvBRGroupFn.apply(xg, tuple(mods), *params, *[gpu(r) for r in res])
+        torch.autograd.backward(outs, [gpu(d) for d in dys])
+    for i in range(n):
+        close(outs[i], ref_out[i], 2e-4, f"y{i}")
+        close(mods[i].conv.weight.grad, ref_params[i][0].grad, 5e-4, f"dw{i}")
+        close(mods[i].bn.weight.grad, ref_params[i][1].grad, 5e-4, f"dgamma{i}")
+        close(mods[i].bn.bias.grad, ref_params[i][2].grad, 5e-4, f"dbeta{i}")
+    close(xg.grad, xr.grad, 5e-4, "dx")
+
+
+def test_matchingnet_train_step_at_reference_crop(ra):
+    """One training step of the Matching Net at the reference's own crop (192x384, stereo_dataset.py:59-62; D = 192; one pair of
+    run_rag.sh:17's batch of four) against the CPU oracle + PyTorch autograd: disparity, loss, feature gradients and the
+    gradients of the stems, cell 0 and cell 7 — the sizes at which bench.py --train's kernels are selected (level-3 volumes of
+    2^19 voxels: bf16x3 forward and data-gradient convolutions, persistent weight-gradient kernel).  approaches/rag.py:204-216."""
+    from test_oracle_golden import oracle_train_step
+    rows = O.ALL_CONV
+    maxdisp = 192
+    sd = O.random_matching_state_dict(rows, seed=21)
+    gq = gen(241)
+    g = {"left_fea": torch.randn((1, 12, 64, 128), generator=gq).numpy(), "right_fea": torch.randn((1, 12, 64, 128), generator=gq).numpy(),
+         "gt": (torch.rand((1, 192, 384), generator=gq) * 200.0).numpy(), "rows": rows, "maxdisp": maxdisp}
+    torch.set_num_threads(16)
+    ref_disp, ref_loss, ref_grads = oracle_train_step(g, sd)
+    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=maxdisp)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    net.stem3d0[0].eval()                                 # a reused unit, as in the oracle helper (rag.py:159-200)
+    lf, rf = gpu(g["left_fea"]).requires_grad_(True), gpu(g["right_fea"]).requires_grad_(True)
+    with ra.ops.conv_precision("bf16x3"):
+        assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 64, 128)
+        disp = net(lf, rf)
+        loss = _smooth_l1_step(disp, gpu(g["gt"]), maxdisp)
+        loss.backward()
+    epe = O.epe(disp.detach().cpu(), ref_disp)
+    named = dict(net.named_parameters())
+    worst = {}
+    for k, ref in ref_grads.items():
+        got = lf.grad if k == "left_fea" else rf.grad if k == "right_fea" else named[k].grad
+        worst[k] = float((got.cpu().double() - ref.double()).abs().max()) / max(1.0, float(ref.abs().max()))
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print(f"train step at 192x384: EPE {epe:.3e} px, loss {loss.item():.6f} vs {ref_loss:.6f}, worst gradient errors {top}")
+    assert epe <= 1e-3, epe
+    assert abs(loss.item() - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
+    checked = 0
+    for k, err in worst.items():
+        if k in ("left_fea", "right_fea") or k.startswith(("stem3d0.", "stem3d1.", "cells_3d.0.", "cells_3d.7.", "last_3_3d.")):
+            assert err <= 1e-3, (k, err)
+            checked += 1
+    assert checked > 25 and max(worst.values()) <= 5e-3, top
+
+
+def test_eval_after_train_forward_without_weight_update_sees_new_running_stats(ra):
+    """The eval-mode caches (folded scale / shift, fused sibling weights) key on tensor versions; the train-mode BatchNorm kernels
+    update running_mean / running_var through raw pointers.  eval forward -> train forward under no_grad (BN re-estimation: no
+    parameter update follows) -> eval forward must use the NEW statistics, for a lone ConvBR and for a cell's fused siblings."""
+    m, x = _convbr_case(ra, 12, 12, 3, True, True, False, (2, 12, 5, 9, 33), seed=41)
+    ref = ra.ConvBR_3d(12, 12, 3, 1, 1)
+    ref.load_state_dict(m.state_dict())
+    torch_m = torch.nn.Sequential(ref.conv, ref.bn, torch.nn.ReLU())       # plain PyTorch modules on the CPU
+    m = m.to(DEV)
+    xg = gpu(x)
+    with torch.no_grad():
+        for mode in ("eval", "train", "eval"):
+            m.train(mode == "train")
+            torch_m.train(mode == "train")
+            y, yr = m(xg), torch_m(x)
+            close(y, yr, 2e-4, f"ConvBR {mode} forward")
+    close(m.bn.running_mean, ref.bn.running_mean, 1e-5, "running_mean")
+    # a whole cell: the dual launch's stacked scale / shift live in Cell._fused_cache
+    g = load_golden("g4_cell3d")
+    pp, p, fm, du = [int(v) for v in g["same_conv::cfg"]]
+    rows = g["same_conv::rows"]
+    cell = ra.Cell_3d(3, 3, pp, p, ra.Genotype(rows, None, rows, None), fm, du)
+    cell.load_state_dict(split_sd(g, "same_conv::sd::"))
+    cell = cell.to(DEV).eval()
+    s0, s1 = gpu(g["same_conv::s0"]), gpu(g["same_conv::s1"])
+    with torch.no_grad():
+        first = cell(s0, s1)[1].clone()
+        cell.train()
+        cell(s0 * 2 + 1, s1 * 2 - 1)                       # moves every running statistic
+        cell.eval()
+        second = cell(s0, s1)[1]
+        sd_now = {k: v.detach().cpu() for k, v in cell.state_dict().items()}
+    want = O.cell_3d(torch.from_numpy(g["same_conv::s0"]), torch.from_numpy(g["same_conv::s1"]), sd_now, "", rows, fm, du)[1]
+    assert not torch.allclose(first, second)
+    close(second, want, 2e-4, "cell eval forward after a train-mode pass")

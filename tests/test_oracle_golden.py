@@ -155,6 +155,28 @@ def test_g6_train_step():
     assert checked > 40
 
 
+def _g10_rows(g):
+    return lambda _layer, unit: g["rows_unit0"] if unit == 0 else g["rows_unit1"]
+
+
+def test_g10_grown_model():
+    """A grown model (expand -> select, rag_model.py:391-522, 709-845): the Matching-Net half of task 0 / task 1 on the
+    selected model and of search_forward on the expanded supermodel with non-zero unit and head indices (rag_model.py:663-706)."""
+    import json
+    g = load_golden("g10_grown_model")
+    blob = json.loads(bytes(g["blob"]).decode())
+    maxdisp = int(g["maxdisp"])
+    sel_sd, search_sd = split_sd(g, "selected::"), split_sd(g, "search::")
+    for t in (0, 1):
+        disp = O.matching_net_forward(torch.from_numpy(g[f"left_fea_t{t}"]), torch.from_numpy(g[f"right_fea_t{t}"]), sel_sd,
+                                      _g10_rows(g), maxdisp, task_arch=blob[f"arch_t{t}"])
+        np.testing.assert_allclose(disp.numpy(), g[f"disp_t{t}"], rtol=1e-4, atol=1e-4)
+    for tag, sel, t in (("a", g["sel_a"], 1), ("b", g["sel_b"], 1), ("c", g["sel_a"], 0)):
+        disp = O.matching_net_forward(torch.from_numpy(g[f"search_left_fea_{tag}"]), torch.from_numpy(g[f"search_right_fea_{tag}"]),
+                                      search_sd, _g10_rows(g), maxdisp, selected_ops=sel, head_index=t)
+        np.testing.assert_allclose(disp.numpy(), g[f"search_disp_{tag}"], rtol=1e-4, atol=1e-4)
+
+
 def test_stereo_metrics_known_answer():
     """Hand-computed case for the metrics restatement (utilstool/metrics.py:21-65 is not importable here: torchvision)."""
     gt = torch.tensor([[[10.0, 20.0, 0.0, 200.0]], [[300.0, 250.0, 5.0, 0.0]]])          # B=2, H=1, W=4, maxdisp 192
