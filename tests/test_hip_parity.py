@@ -676,7 +676,7 @@ def test_grown_model_against_reference_outputs(ra, tmp_path):
             fea = net2.feature(left, archis[t], None)
             np.testing.assert_allclose(fea.cpu().numpy(), g[f"left_fea_t{t}"], rtol=2e-4, atol=2e-4)
     # a reference checkpoint (no genotypes / archis inside) loads when the caller supplies them
-    torch.save({"task": 1, "model": sel_sd, "optimizer": None}, path)
+    torch.save({"task": 1, "model": sel_sd, "optimizer": None, "maxdisp": maxdisp}, path)   # (the reference hard-codes 192)
     net3, archis3 = ck.load_checkpoint(str(path), device=DEV, genotypes=genotypes, archis=[blob["arch_t0"], blob["arch_t1"]])
     with torch.no_grad():
         assert torch.equal(ck.MultiTaskStereo(net3, archis3)(left, right, 1), serve(left, right, 1))
@@ -828,8 +828,8 @@ def test_x3_precision_is_an_abi_argument(ra):
 
 
 def test_x3_error_bound_adversarial(ra):
-    """The bound include/rag_amd.h documents for RAGMI_F32X3, |y - y_exact| <= 2e-5 * sum_k |w_k x_k| per output (worst case
-    3 * 2^-16), against an fp64 convolution on inputs chosen to hurt: (a) activations with a large common offset (post-ReLU-like,
+    """The bound include/rag_amd.h documents for RAGMI_F32X3, |y - y_exact| <= 5e-5 * sum_k |w_k x_k| per output (3 * 2^-16 from
+    the dropped terms + fp32 accumulation), against an fp64 convolution on inputs chosen to hurt: (a) activations with a large common offset (post-ReLU-like,
     1000 + N(0,1)) under zero-sum weights — the exact result is O(1) while every product is O(100), so the error is judged against
     sum |w x|, not |y|; (b) operands spanning 2^-20 .. 2^20 in magnitude.  The strict RAGMI_F32 path is held to 1e-6 * sum |w x| on the
     same data."""
@@ -847,7 +847,7 @@ def test_x3_error_bound_adversarial(ra):
         ref = F.conv3d(xs, wt.double(), padding=1)[:, :, sl]
         mag = F.conv3d(xs.abs(), wt.double().abs(), padding=1)[:, :, sl]
         pk = ra.ops.conv3d_k3_pack(gpu(wt))
-        for prec, bound in (("bf16x3", 2e-5), ("fp32", 1e-6)):
+        for prec, bound in (("bf16x3", 5e-5), ("fp32", 1e-6)):
             with ra.ops.conv_precision(prec):
                 assert ra.ops.conv3d_k3_uses_x3(cin, cout, 1, D, H, W) == (prec == "bf16x3")
                 out = ra.ops.conv3d_k3(gpu(x), pk, cout, None, None, False, torch.empty((1, cout, D, H, W), device=DEV))

@@ -700,10 +700,24 @@ def test_wgrad_persistent_kernel_at_training_size(ra, cin, cout):
         close(torch.cat(into) - torch.cat(base), ref, 2e-4, "dw accumulated into stacked destinations")
 
 
+def _rel_err(got, ref64):
+    got, ref64 = got.detach().cpu().double(), ref64.detach().cpu().double()
+    assert got.shape == ref64.shape, (got.shape, ref64.shape)
+    return float((got - ref64).abs().max()) / max(1.0, float(ref64.abs().max()))
+
+
+# Sums over 2^21 voxels (and, end to end, a soft-argmin over costs of 1e3-1e4) are ill-conditioned in fp32: the CPU reference's OWN
+# fp32 results differ from an fp64 evaluation by up to 5e-3 of a tensor's largest gradient.  These tests therefore measure every
+# path against the fp64 evaluation and bound the GPU's error by a multiple of the error the reference's fp32 arithmetic makes on the
+# same inputs (floor: the tolerance of the small-shape tests): strict fp32 (RAGMI_F32) must sit in the same noise class, bf16x3
+# (RAGMI_F32X3: ~30x the per-product rounding of fp32, include/rag_amd.h) may amplify it by the stated factor.
+NOISE_FACTOR = {"fp32": 3.0, "bf16x3": 12.0}
+
+
 def test_convbr_group_fn_at_training_size(ra):
     """ConvBRGroupFn (three sibling 4 -> 4 ConvBRs of a level-3 cell state, train-mode BatchNorm, one residual per unit) forward
-    and backward at the level-3 training shape vs PyTorch-CPU autograd: stacked forward conv (bf16x3 kernel), per-unit BN + ReLU
-    (+ residual), stacked data gradient (bf16x3 kernel, transposed pack) and stacked weight gradient."""
+    and backward at the level-3 training shape: stacked forward conv, per-unit BN + ReLU (+ residual), stacked data gradient
+    (transposed pack) and stacked weight gradient (persistent kernel), under both arithmetic contracts, against fp64 autograd."""
     from rag_amd import autograd as ag
     B, D, H, W = L3_TRAIN
     C, n = 4, 3
@@ -715,36 +729,49 @@ def test_convbr_group_fn_at_training_size(ra):
     res = [torch.randn((B, C, D, H, W), generator=gen(222 + i)) for i in range(n)]
     dys = [torch.randn((B, C, D, H, W), generator=gen(230 + i)) for i in range(n)]
     torch.set_num_threads(16)
-    xr = x.clone().requires_grad_(True)
-    ref_out, ref_params = [], []
-    for i, m in enumerate(mods):
-        w = m.conv.weight.detach().clone().requires_grad_(True)
-        g = m.bn.weight.detach().clone().requires_grad_(True)
-        b = m.bn.bias.detach().clone().requires_grad_(True)
-        y = F.relu(F.batch_norm(F.conv3d(xr, w, padding=1), None, None, g, b, training=True, eps=m.bn.eps)) + res[i]
-        ref_out.append(y)
-        ref_params.append((w, g, b))
-    torch.autograd.backward(ref_out, dys)
-    mods = [m.to(DEV) for m in mods]
-    xg = gpu(x).requires_grad_(True)
-    params = [p for m in mods for p in (m.conv.weight, m.bn.weight, m.bn.bias)]
-    with ra.ops.conv_precision("bf16x3"):
-        assert ra.ops.conv3d_k3_uses_x3(C, n * C, B, D, H, W) and ra.ops.conv3d_k3_uses_x3(n * C, C, B, D, H, W)
-        outs = ag.ConvBRGroupFn.apply(xg, tuple(mods), *params, *[gpu(r) for r in res])
-        torch.autograd.backward(outs, [gpu(d) for d in dys])
-    for i in range(n):
-        close(outs[i], ref_out[i], 2e-4, f"y{i}")
-        close(mods[i].conv.weight.grad, ref_params[i][0].grad, 5e-4, f"dw{i}")
-        close(mods[i].bn.weight.grad, ref_params[i][1].grad, 5e-4, f"dgamma{i}")
-        close(mods[i].bn.bias.grad, ref_params[i][2].grad, 5e-4, f"dbeta{i}")
-    close(xg.grad, xr.grad, 5e-4, "dx")
+
+    def reference(dt):
+        xr = x.to(dt).requires_grad_(True)
+        outs, ps = [], []
+        for i, m in enumerate(mods):
+            w = m.conv.weight.detach().cpu().to(dt).requires_grad_(True)
+            g = m.bn.weight.detach().cpu().to(dt).requires_grad_(True)
+            b = m.bn.bias.detach().cpu().to(dt).requires_grad_(True)
+            outs.append(F.relu(F.batch_norm(F.conv3d(xr, w, padding=1), None, None, g, b, training=True, eps=m.bn.eps)) + res[i].to(dt))
+            ps += [w, g, b]
+        torch.autograd.backward(outs, [d.to(dt) for d in dys])
+        return [o.detach() for o in outs] + [xr.grad] + [p.grad for p in ps]
+
+    names = [f"y{i}" for i in range(n)] + ["dx"] + [f"{k}{i}" for i in range(n) for k in ("dw", "dgamma", "dbeta")]
+    ref64, ref32 = reference(torch.float64), reference(torch.float32)
+    noise = {k: _rel_err(r32, r64) for k, r32, r64 in zip(names, ref32, ref64)}
+    for prec in ("fp32", "bf16x3"):
+        gm = [type(m)(C, C, 3, 1, 1) for m in mods]
+        for a_, b_ in zip(gm, mods):
+            a_.load_state_dict(b_.state_dict())
+            a_.train()
+        gm = [m.to(DEV) for m in gm]
+        xg = gpu(x).requires_grad_(True)
+        params = [p for m in gm for p in (m.conv.weight, m.bn.weight, m.bn.bias)]
+        with ra.ops.conv_precision(prec):
+            assert ra.ops.conv3d_k3_uses_x3(C, n * C, B, D, H, W) == (prec == "bf16x3")
+            outs = ag.ConvBRGroupFn.apply(xg, tuple(gm), *params, *[gpu(r) for r in res])
+            torch.autograd.backward(outs, [gpu(d) for d in dys])
+        got = list(outs) + [xg.grad] + [p.grad for p in params]
+        errs = {k: _rel_err(t, r64) for k, t, r64 in zip(names, got, ref64)}
+        worst = max(errs, key=lambda k: errs[k] / max(noise[k], 2e-5))
+        print(f"ConvBRGroupFn at {L3_TRAIN} [{prec}]: worst {worst}: err {errs[worst]:.2e} vs CPU-fp32 noise {noise[worst]:.2e}; "
+              f"max err {max(errs.values()):.2e}, max noise {max(noise.values()):.2e}")
+        for k in names:
+            assert errs[k] <= max(2e-4, NOISE_FACTOR[prec] * noise[k]), (prec, k, errs[k], noise[k])
 
 
 def test_matchingnet_train_step_at_reference_crop(ra):
     """One training step of the Matching Net at the reference's own crop (192x384, stereo_dataset.py:59-62; D = 192; one pair of
-    run_rag.sh:17's batch of four) against the CPU oracle + PyTorch autograd: disparity, loss, feature gradients and the
-    gradients of the stems, cell 0 and cell 7 — the sizes at which bench.py --train's kernels are selected (level-3 volumes of
-    2^19 voxels: bf16x3 forward and data-gradient convolutions, persistent weight-gradient kernel).  approaches/rag.py:204-216."""
+    run_rag.sh:17's batch of four): disparity, loss, feature gradients and every parameter gradient — at the sizes at which
+    bench.py --train's kernels are selected (level-3 volumes of 2^19 voxels: bf16x3 or fp32-MFMA forward and data-gradient
+    convolutions, persistent weight-gradient kernel) — against the CPU oracle + PyTorch autograd evaluated in fp64, with the
+    oracle's own fp32 evaluation as the noise yardstick.  approaches/rag.py:204-216."""
     from test_oracle_golden import oracle_train_step
     rows = O.ALL_CONV
     maxdisp = 192
@@ -753,33 +780,39 @@ def test_matchingnet_train_step_at_reference_crop(ra):
     g = {"left_fea": torch.randn((1, 12, 64, 128), generator=gq).numpy(), "right_fea": torch.randn((1, 12, 64, 128), generator=gq).numpy(),
          "gt": (torch.rand((1, 192, 384), generator=gq) * 200.0).numpy(), "rows": rows, "maxdisp": maxdisp}
     torch.set_num_threads(16)
-    ref_disp, ref_loss, ref_grads = oracle_train_step(g, sd)
-    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=maxdisp)
-    net.load_state_dict(sd, strict=True)
-    net = net.to(DEV).train()
-    net.stem3d0[0].eval()                                 # a reused unit, as in the oracle helper (rag.py:159-200)
-    lf, rf = gpu(g["left_fea"]).requires_grad_(True), gpu(g["right_fea"]).requires_grad_(True)
-    with ra.ops.conv_precision("bf16x3"):
-        assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 64, 128)
-        disp = net(lf, rf)
-        loss = _smooth_l1_step(disp, gpu(g["gt"]), maxdisp)
-        loss.backward()
-    epe = O.epe(disp.detach().cpu(), ref_disp)
-    named = dict(net.named_parameters())
-    worst = {}
-    for k, ref in ref_grads.items():
-        got = lf.grad if k == "left_fea" else rf.grad if k == "right_fea" else named[k].grad
-        worst[k] = float((got.cpu().double() - ref.double()).abs().max()) / max(1.0, float(ref.abs().max()))
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
-    print(f"train step at 192x384: EPE {epe:.3e} px, loss {loss.item():.6f} vs {ref_loss:.6f}, worst gradient errors {top}")
-    assert epe <= 1e-3, epe
-    assert abs(loss.item() - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
-    checked = 0
-    for k, err in worst.items():
-        if k in ("left_fea", "right_fea") or k.startswith(("stem3d0.", "stem3d1.", "cells_3d.0.", "cells_3d.7.", "last_3_3d.")):
-            assert err <= 1e-3, (k, err)
-            checked += 1
-    assert checked > 25 and max(worst.values()) <= 5e-3, top
+    d32, l32, g32 = oracle_train_step(g, sd)
+    g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
+    d64, l64, gr64 = oracle_train_step(g64, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+    noise = {k: _rel_err(g32[k], gr64[k]) for k in gr64}
+    epe_noise = O.epe(d32, d64)
+    for prec in ("fp32", "bf16x3"):
+        net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=maxdisp)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(DEV).train()
+        net.stem3d0[0].eval()                                 # a reused unit, as in the oracle helper (rag.py:159-200)
+        lf, rf = gpu(g["left_fea"]).requires_grad_(True), gpu(g["right_fea"]).requires_grad_(True)
+        with ra.ops.conv_precision(prec):
+            assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 64, 128) == (prec == "bf16x3")
+            disp = net(lf, rf)
+            loss = _smooth_l1_step(disp, gpu(g["gt"]), maxdisp)
+            loss.backward()
+        epe = O.epe(disp.detach().cpu(), d64)
+        named = dict(net.named_parameters())
+        errs = {}
+        for k, ref in gr64.items():
+            got = lf.grad if k == "left_fea" else rf.grad if k == "right_fea" else named[k].grad
+            errs[k] = _rel_err(got, ref)
+        top = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+        print(f"train step at 192x384 [{prec}]: EPE vs fp64 {epe:.3e} px (CPU fp32: {epe_noise:.3e}); loss {loss.item():.6f} vs {l64:.6f}; "
+              f"worst gradient errors {top}; CPU-fp32 worst {max(noise.values()):.2e}")
+        f = NOISE_FACTOR[prec]
+        assert epe <= max(1e-3, f * epe_noise), (prec, epe, epe_noise)
+        assert abs(loss.item() - l64) <= 1e-5 * max(1.0, abs(l64))
+        worst_noise = max(noise.values())
+        for k, err in errs.items():
+            # per tensor against its own noise, with the step's worst noise as the floor (tiny tensors have noisy noise estimates)
+            assert err <= f * max(noise[k], 0.5 * worst_noise, 2e-4), (prec, k, err, noise[k])
+        assert len(errs) > 250
 
 
 def test_eval_after_train_forward_without_weight_update_sees_new_running_stats(ra):
