@@ -129,6 +129,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  if (x3d_eligible(a, 1, dtype)) return x3d_launch(a, 1, dtype, s);
   if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, dtype, s);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s1_cfg0_bf16(a, ng, s) : launch_k3_s1_cfg0_f32(a, ng, s);
@@ -205,6 +206,7 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  if (x3d_eligible(a, 2, dtype)) return x3d_launch(a, 2, dtype, s);
   if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, dtype, s);
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s2_cfg0_bf16(a, ng, s) : launch_k3_s2_cfg0_f32(a, ng, s);
@@ -221,7 +223,8 @@ extern "C" int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, i
   a.res = has_res ? (const void*)&a : nullptr;
   if (nset == 2) { if (Cin % (2 * CK)) return 0; a.nchunks[0] = a.nchunks[1] = Cin / (2 * CK); }
   else a.nchunks[0] = (Cin + CK - 1) / CK;
-  return x3_eligible(a, nset, dtype) ? 1 : 0;
+  a.store_main = 1;
+  return (x3d_eligible(a, nset, dtype) || x3_eligible(a, nset, dtype)) ? 1 : 0;
 }
 
 extern "C" int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int nset, int32_t* log_tx,

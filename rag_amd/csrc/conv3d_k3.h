@@ -559,7 +559,8 @@ static int launch_cfg(K3Args a, int ngroups, hipStream_t s) {
   a.tiles_z = (int)ceil_div(a.D, FLAT ? 1 : 4);
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
-  const int G = split_groups(ngroups), nsplits = ngroups / G;
+  const int G = split_groups(ngroups);
+  const int nsplits = ngroups / G;
   switch (G) {
     case 1: launch_one<T, 1, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
     case 2: launch_one<T, 2, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
@@ -586,6 +587,9 @@ int64_t x3_packed_words(int Cout, int Cin);
 int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, hipStream_t s);
 bool x3_eligible(const K3Args& a, int nset, int dtype);
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
+// deep-level bf16x3 form (8 / 16 input channels per set, box tiles): levels 6 and 12
+bool x3d_eligible(const K3Args& a, int nset, int dtype);
+int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st);
 int launch_k3_valu_f32(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights
 int launch_k3_valu_bf16(const K3Args& a, int cfg, hipStream_t s);
 int launch_k3_valu_bf16_f32out(const K3Args& a, int cfg, hipStream_t s);   // bf16 input, fp32 main output

