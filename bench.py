@@ -518,7 +518,7 @@ def main():
             "value": round(n_gpus * B * args.steps / dt, 3), "unit": "disparity maps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (RAGMI_F32X3: level-3/6 3x3x3 convolutions with fp32 operands split into bf16 hi+lo on the bf16 matrix cores, "
+            "dtype": ("f32 (RAGMI_F32X3: level-3/6/12 3x3x3 convolutions with fp32 operands split into bf16 hi+lo on the bf16 matrix cores, "
                       "fp32 accumulate; strict_fp32 holds the RAGMI_F32 number)"
                       if (args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "bf16x3") else
                       "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate"), "data": "synthetic",

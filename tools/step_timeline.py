@@ -28,7 +28,7 @@ def main(root: str, first: str = "costvol_stem_planes_kernel") -> None:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     starts = [i for i, r in enumerate(rows) if first in r[2]]
-    ends = [i for i, r in enumerate(rows) if "disp_softargmin_kernel" in r[2]]
+    ends = [i for i, r in enumerate(rows) if "disp_softargmin" in r[2]]
     if not starts or not ends:
         raise SystemExit("no forward pass found")
     # the last complete pass that belongs to the Matching-Net bench (planes ... disp with no other planes in between)
