@@ -263,7 +263,9 @@ def test_conv3d_k1_vs_oracle(ra, cin, cout, shape):
 @pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("shape,size", [((2, 3, 8, 12, 20), (4, 6, 10)), ((1, 2, 7, 9, 13), (4, 5, 7)),
                                         ((1, 2, 3, 4, 5), (6, 8, 10)), ((1, 12, 16, 32, 26), (32, 64, 52)),
-                                        ((1, 4, 5, 5, 5), (5, 5, 5)), ((1, 2, 64, 32, 104), (32, 16, 52))])
+                                        ((1, 4, 5, 5, 5), (5, 5, 5)), ((1, 2, 64, 32, 104), (32, 16, 52)),
+                                        # the tiled up-sampling kernel (every scale <= 0.5): ragged tiles, ratios above two, two batches
+                                        ((2, 3, 5, 7, 9), (13, 17, 40)), ((1, 5, 9, 6, 33), (18, 12, 67))])
 def test_trilinear_vs_aten(ra, align, shape, size):
     x = torch.randn(shape, generator=gen(17))
     ref = F.interpolate(x, size, mode="trilinear", align_corners=align)
@@ -452,9 +454,10 @@ def test_matchingnet_golden(ra, name, prec):
     epe = O.epe(disp.cpu(), torch.from_numpy(g["disp"]))
     assert epe <= EPE_GATE, epe
     # random weights drive |cost| to 1e4-1e5, so softmin is almost an argmin: a few near-tie pixels may move
-    # by a fraction of a pixel under fp32 reordering; the gate is EPE, the per-pixel check is a quantile bound
+    # by a fraction of a pixel under fp32 reordering; the gate is EPE, the per-pixel check is a quantile bound and a cap at three
+    # times the largest move measured (0.083 px on conv_48x96_d48)
     err = (disp.cpu() - torch.from_numpy(g["disp"])).abs()
-    assert float((err > 2e-3).float().mean()) < 5e-3 and float(err.max()) < 1.0, (float(err.max()), float((err > 2e-3).float().mean()))
+    assert float((err > 2e-3).float().mean()) < 5e-3 and float(err.max()) < 0.25, (float(err.max()), float((err > 2e-3).float().mean()))
 
 
 def test_matchingnet_plumbing_config_golden(ra):
@@ -594,10 +597,13 @@ def test_bf16_matchingnet_epe_report(ra):
     ref = O.matching_net_forward(lf, rf, sd, rows, 96)
     e32, e16, e16_32 = O.epe(d32, ref), O.epe(d16, ref), O.epe(d16, d32)
     print(f"EPE fp32 vs oracle {e32:.3e}; bf16 vs oracle {e16:.3e}; bf16 vs fp32 build {e16_32:.3e} px (maxdisp 96)")
-    assert d16.dtype == torch.float32 and torch.isfinite(d16).all() and e32 <= EPE_GATE and e16 < 5.0
+    # bf16 storage at this reduced size: measured 0.219 / 0.221 px (two boxes); the bound is the measurement + 50 %.  The stated
+    # tolerance of the bf16 configuration is enforced on the full workload below (BF16_FULL_GATE).
+    assert d16.dtype == torch.float32 and torch.isfinite(d16).all() and e32 <= EPE_GATE and e16 < 0.33
 
 
-BF16_FULL_GATE = 0.12     # px, provisional: tightened to measurement + margin below once measured on the MI355X
+BF16_FULL_GATE = 0.12     # px: measured 0.0993 / 0.0973 at the full configs[2] workload (two runs); the analysis of where it comes from is
+                          # tests/analysis_bf16_stage_epe.py + DESIGN.md 4.2 (every bf16-stored stage contributes; fp32 `mat` is already kept)
 
 
 def test_bf16_config3_full_workload_gate(ra):

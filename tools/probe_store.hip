@@ -71,6 +71,20 @@ int main() {
   printf("quad x 12 planes, 2048 persistent WGs           : %7.1f us  %5.2f TB/s\n", t, mb / t);
   t = time_us([&] { hipLaunchKernelGGL(k_plane_major, dim3(256, C), dim3(256), 0, 0, out, nq); });
   printf("plane-major (blockIdx.y = channel)              : %7.1f us  %5.2f TB/s\n", t, mb / t);
+  // the same patterns over EIGHT buffers in rotation (1.3 GB: nothing written is still in the 256 MB infinity cache when it is
+  // written again) — what a layer's output write looks like inside a forward pass
+  float* bufs[8];
+  for (int i = 0; i < 8; ++i) hipMalloc(&bufs[i], n * sizeof(float));
+  int r = 0;
+  t = time_us([&] { hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (float4*)bufs[r++ & 7], n / 4); }, 24);
+  printf("cold: fill                                      : %7.1f us  %5.2f TB/s\n", t, mb / t);
+  t = time_us([&] { hipLaunchKernelGGL(k_quad12, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, bufs[r++ & 7], nq); }, 24);
+  printf("cold: quad x 12 planes (float4 stores)          : %7.1f us  %5.2f TB/s\n", t, mb / t);
+  t = time_us([&] { hipLaunchKernelGGL(k_vox12, dim3((unsigned)((DHW + 255) / 256)), dim3(256), 0, 0, bufs[r++ & 7], DHW); }, 24);
+  printf("cold: voxel x 12 planes (dword stores)          : %7.1f us  %5.2f TB/s\n", t, mb / t);
+  t = time_us([&] { hipLaunchKernelGGL(k_plane_major, dim3(256, C), dim3(256), 0, 0, bufs[r++ & 7], nq); }, 24);
+  printf("cold: plane-major                               : %7.1f us  %5.2f TB/s\n", t, mb / t);
+  for (int i = 0; i < 8; ++i) hipFree(bufs[i]);
   hipFree(out);
   return 0;
 }
