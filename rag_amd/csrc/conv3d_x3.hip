@@ -333,15 +333,17 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 //  * One SET (input tensor) per stage: the box of set 0 is multiplied while set 1's travels HBM/L2 -> registers, and the LDS holds
 //    one set's box (24-49 KB) next to the workgroup's weight fragments, which stay resident for the whole launch (persistent
 //    workgroups; fragments are gathered from the z-marching layout of ragmi_conv3d_k3_pack at start, so the packed format is shared).
-//  * COGS output-channel blocks of 16 per workgroup share every operand read (level 6: 24 outputs = 2 blocks).
-constexpr int XD_TZ = 2, XD_TY = 8, XD_TX = 16;
-constexpr int XD_HZ = XD_TZ + 2, XD_HY = XD_TY + 2, XD_HX = XD_TX + 3;
-constexpr int XD_PL = XD_HZ * XD_HY * XD_HX;           // 760 halo voxels per box
+//  * Output-channel blocks of 16 ride blockIdx.y.  (Two blocks per workgroup sharing the operand reads were measured at level 6:
+//    64 us against 58 — their weights push the workgroup to 98 KB of LDS, one per CU, and the stages serialise.)
+constexpr int XD_TY = 8, XD_TX = 16;
+constexpr int XD_HY = XD_TY + 2, XD_HX = XD_TX + 3;
 constexpr int64_t XD_MIN_VOXELS = 1 << 14;
-constexpr int XD_THREADS = 512, XD_NT = 2;             // 8 waves x 2 column tiles = the 16 (z, y) rows of a box
+constexpr int XD_THREADS = 512;                        // 8 waves: wave w owns rows (w & 3) * 2, +1 of planes w >> 2 (, + 2)
 
-template <class T, int CH8, int NSET, int COGS>
+// TZ = box depth: 2 (16 column tiles, two per wave; the shipped form) or 4 (32 column tiles, four per wave: see x3d_launch)
+template <class T, int CH8, int NSET, int TZ>
 __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3Extra e) {
+  constexpr int COGS = 1, XD_TZ = TZ, XD_HZ = TZ + 2, XD_PL = XD_HZ * XD_HY * XD_HX, XD_NT = TZ;
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int SPR = CH8;                              // K-slices per (dz, dy) row: 8 ch -> dx 0..3 in one, 16 ch -> {0,1} and {2,3}
   constexpr int NSLS = 9 * SPR;                         // slices per set
@@ -360,23 +362,32 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
   const int64_t DHW = (int64_t)HW * a.D;
   // weight fragments of this workgroup's output blocks: A[row = lane & 15][k = 8 kb + j] = w[co][channel 8 cg8 + j][tap (dz, dy, dx)],
   // (cg8, dx) from the lane quarter and the slice; gathered in 8-byte halves (4 channels of one tap) from the packed fragments
-  for (int i = tid; i < NSET * COGS * NSLS * 2 * 64 * 2; i += XD_THREADS) {
-    const int half = i & 1;
-    int q = i >> 1;
-    const int ln = q & 63; q >>= 6;
-    const int hl = q & 1; q >>= 1;
-    const int sl = q % NSLS; q /= NSLS;
-    const int cl = q % COGS, set = q / COGS;
-    const int m = ln & 15, kq = ln >> 4;
-    const int cg8 = CH8 == 2 ? (kq & 1) : 0, dx = 2 * (sl % SPR) + (CH8 == 2 ? (kq >> 1) : kq);
-    uint2 v = make_uint2(0u, 0u);
-    if (dx < 3 && cog0 + cl < ncog) {
-      const int tap = (sl / SPR) * 3 + dx;              // (dz * 3 + dy) * 3 + dx
+  // (nine gathers in flight per thread: as a plain loop the 18 trips each waited out an L2 round trip — 10 of the 40 us of a
+  // level-12 launch were this prologue)
+  constexpr int NWH = NSET * COGS * NSLS * 2 * 64 * 2, NWB = 9;
+  for (int i0 = tid; i0 < NWH; i0 += NWB * XD_THREADS) {
+    uint2 wv[NWB];
+#pragma unroll
+    for (int u = 0; u < NWB; ++u) {
+      const int i = min(i0 + u * XD_THREADS, NWH - 1);
+      const int half = i & 1;
+      int q = i >> 1;
+      const int ln = q & 63; q >>= 6;
+      const int hl = q & 1; q >>= 1;
+      const int sl = q % NSLS; q /= NSLS;
+      const int cl = q % COGS, set = q / COGS;
+      const int m = ln & 15, kq = ln >> 4;
+      const int cg8 = CH8 == 2 ? (kq & 1) : 0, dx = 2 * (sl % SPR) + (CH8 == 2 ? (kq >> 1) : kq);
+      const bool real = dx < 3 && cog0 + cl < ncog;
+      const int tap = (sl / SPR) * 3 + min(dx, 2);      // (dz * 3 + dy) * 3 + dx
       const int P = (2 * cg8 + half) * 27 + tap;        // pair index of the packed layout: 4-channel group * 27 + tap
-      const uint2* src = reinterpret_cast<const uint2*>(e.wf[set] + ((int64_t)((cog0 + cl) * NSLS_V1 + (P >> 3)) * 2 + hl) * 64 + ((P & 7) >> 1) * 16 + m);
-      v = src[P & 1];
+      const uint2* src = reinterpret_cast<const uint2*>(e.wf[set] + ((int64_t)(min(cog0 + cl, ncog - 1) * NSLS_V1 + (P >> 3)) * 2 + hl) * 64 + ((P & 7) >> 1) * 16 + m);
+      const uint2 v = src[P & 1];                       // unconditional (clamped) load, zeroed below: stays straight-line code
+      wv[u] = real ? v : make_uint2(0u, 0u);
     }
-    reinterpret_cast<uint2*>(lw)[i] = v;
+#pragma unroll
+    for (int u = 0; u < NWB; ++u)
+      if (i0 + u * XD_THREADS < NWH) reinterpret_cast<uint2*>(lw)[i0 + u * XD_THREADS] = wv[u];
   }
   for (int i = tid; i < NSET * COGS * 16; i += XD_THREADS) {
     const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
@@ -386,8 +397,11 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
   float pf[NPF][4];
   unsigned valid = 0;
   const T* const x = static_cast<const T*>(a.x);
-  // loads of one set's halo box: unconditional, addresses clamped into the volume (zeros are substituted at the commit)
-  auto prefetch = [&](const T* xb, int set, int z0, int y0, int x0) {
+  // this thread's halo elements of a box: (4-channel group, voxel) -> element offset from the set's first channel, and whether the
+  // voxel lies inside the volume.  Located once per box and used for every set (the index arithmetic is ~25 VALU instructions per
+  // element: per stage it stood in front of the MFMA block of both waves of a SIMD at once)
+  int offs[NPF];
+  auto locate = [&](int z0, int y0, int x0) {
     valid = 0;
 #pragma unroll
     for (int p = 0; p < NPF; ++p) {
@@ -396,11 +410,16 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
       const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
       const bool ok = cg4 < NCG4 && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
       valid |= (ok ? 1u : 0u) << p;
-      const unsigned off = (unsigned)(min(max(gz, 0), a.D - 1) * HW + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
-      const int c0 = set * (8 * CH8) + min(cg4, NCG4 - 1) * 4;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) pf[p][c] = ld(xb + (int64_t)(c0 + c) * DHW + off);
+      offs[p] = (int)(min(cg4, NCG4 - 1) * 4 * DHW) + min(max(gz, 0), a.D - 1) * HW + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
     }
+  };
+  // loads of one set's halo box: unconditional, addresses clamped into the volume (zeros are substituted at the commit)
+  auto prefetch = [&](const T* xb, int set) {
+    const T* xs = xb + (int64_t)set * (8 * CH8) * DHW;
+#pragma unroll
+    for (int p = 0; p < NPF; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pf[p][c] = ld(xs + c * DHW + offs[p]);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -442,8 +461,14 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
   int b = 0, z0 = 0, y0 = 0, x0 = 0;
   if (j < chunk * 8) {
     decode(work_of(j), b, z0, y0, x0);
-    prefetch(x + b * a.x_bstride, 0, z0, y0, x0);
+    locate(z0, y0, x0);
+    prefetch(x + b * a.x_bstride, 0);
   }
+#ifdef RAGMI_DIAG
+  const bool diag_nostore = (a.relu & 0x100) != 0, diag_nomfma = (a.relu & 0x200) != 0, diag_nostage = (a.relu & 0x400) != 0;
+#else
+  constexpr bool diag_nostore = false, diag_nomfma = false, diag_nostage = false;
+#endif
   while (j < chunk * 8) {
     int jn = j + gridDim.x;
     while (jn < chunk * 8 && work_of(jn) >= e.nwork) jn += gridDim.x;
@@ -459,11 +484,14 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
     static_for<NSET>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
       __syncthreads();                                 // the previous stage's operand reads are done (first pass: the tables are written)
-      commit();
+      if (!diag_nostage) commit();
       __syncthreads();
-      if constexpr (st + 1 < NSET) prefetch(x + b * a.x_bstride, st + 1, z0, y0, x0);
-      else prefetch(x + bn * a.x_bstride, 0, zn, yn, xn);
+      if (!diag_nostage) {
+        if constexpr (st + 1 < NSET) prefetch(x + b * a.x_bstride, st + 1);
+        else { locate(zn, yn, xn); prefetch(x + bn * a.x_bstride, 0); }
+      }
       __builtin_amdgcn_sched_barrier(0);               // the loads stay ahead of the MFMA block
+      if (!diag_nomfma)
 #pragma unroll
       for (int sl = 0; sl < NSLS; ++sl) {
         constexpr int ROWB = XD_HX * (int)sizeof(uint4);
@@ -471,8 +499,9 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
         x3_bf16x8 bh[XD_NT], bl[XD_NT];
 #pragma unroll
         for (int i = 0; i < XD_NT; ++i) {
-          bh[i] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(lbytes + vb0 + off + i * ROWB));
-          if constexpr (!BF) bl[i] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(lbytes + vb0 + off + i * ROWB + LO_BYTES));
+          const int d = (i & 1) * ROWB + (i >> 1) * 2 * XD_HY * ROWB;        // compile time: tile i = row +(i & 1), plane +2 (i >> 1)
+          bh[i] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(lbytes + vb0 + off + d));
+          if constexpr (!BF) bl[i] = __builtin_bit_cast(x3_bf16x8, *reinterpret_cast<const uint4*>(lbytes + vb0 + off + d + LO_BYTES));
         }
 #pragma unroll
         for (int cl = 0; cl < COGS; ++cl) {
@@ -494,7 +523,7 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
       const int g = (cog0 + cl) * 4 + kb;
 #pragma unroll
       for (int i = 0; i < XD_NT; ++i) {
-        const int gz = z0 + tz, gy = y0 + ty0 + i, gx = x0 + n;
+        const int gz = z0 + tz + 2 * (i >> 1), gy = y0 + ty0 + (i & 1), gx = x0 + n;
         const bool inside = gz < a.D && gy < a.H && gx < a.W;
         float v[4];
 #pragma unroll
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
           }
           v[r] = sum;
         }
-        if (inside && g < ngroups) {
+        if (inside && g < ngroups && !(diag_nostore && v[0] != 12345.f)) {
           T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)my_ych[cl] * DHW + ((int64_t)gz * HW + gy * a.W + gx);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -529,44 +558,42 @@ bool x3d_eligible(const K3Args& a, int nset, int dtype) {
   return true;
 }
 
-template <class T, int CH8, int NSET, int COGS>
+template <class T, int CH8, int NSET, int TZ>
 static int x3d_launch_one(K3Args a, X3Extra e, hipStream_t st) {
-  constexpr size_t lds = (size_t)(std::is_same<T, bf16_t>::value ? 1 : 2) * CH8 * XD_PL * sizeof(uint4) +
-                         (size_t)NSET * COGS * 9 * CH8 * 2 * 64 * sizeof(uint4) + (size_t)2 * NSET * COGS * 16 * sizeof(float);
+  constexpr int PL = (TZ + 2) * XD_HY * XD_HX;
+  constexpr size_t lds = (size_t)(std::is_same<T, bf16_t>::value ? 1 : 2) * CH8 * PL * sizeof(uint4) +
+                         (size_t)NSET * 9 * CH8 * 2 * 64 * sizeof(uint4) + (size_t)2 * NSET * 16 * sizeof(float);
   static_assert(lds <= 160 * 1024, "deep-level tile does not fit the LDS");
+  a.tiles_x = (int)ceil_div(a.W, XD_TX); a.tiles_y = (int)ceil_div(a.H, XD_TY); a.tiles_z = (int)ceil_div(a.D, TZ);
+  const int64_t nwork = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  RAGMI_REQUIRE(nwork < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3d: too many tiles");
+  e.nwork = (int)nwork;
   static LaunchState state;
-  const int slots = state.slots((const void*)conv3d_x3d_kernel<T, CH8, NSET, COGS>, XD_THREADS, lds, 160 * 1024);
+  const int slots = state.slots((const void*)conv3d_x3d_kernel<T, CH8, NSET, TZ>, XD_THREADS, lds, 160 * 1024);
   if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_x3d: cannot raise the dynamic LDS limit");
-  const int ny = (int)ceil_div((a.Cout + 15) / 16, COGS);
+  const int ny = (a.Cout + 15) / 16;
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(e.nwork, slots / ny));
   if (gx >= 8) gx -= gx % 8;
-  hipLaunchKernelGGL((conv3d_x3d_kernel<T, CH8, NSET, COGS>), dim3((unsigned)gx, (unsigned)ny), dim3(XD_THREADS), lds, st, a, e);
+  hipLaunchKernelGGL((conv3d_x3d_kernel<T, CH8, NSET, TZ>), dim3((unsigned)gx, (unsigned)ny), dim3(XD_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3d");
 }
 
 int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st) {
+#ifdef RAGMI_DIAG
+  static const int diag_xd = [] { const char* v = getenv("RAGMI_XD_DIAG"); return v ? atoi(v) : 0; }();   // 1 no stores, 2 no MFMA block, 4 no staging
+  a.relu |= diag_xd << 8;
+#endif
   X3Extra e{};
   const int ngroups = (a.Cout + 3) / 4;
   for (int s = 0; s < nset; ++s)
     e.wf[s] = reinterpret_cast<const uint4*>(a.wp[s] + (int64_t)ngroups * a.nchunks[s] * PACK_PER_GC);
-  a.tiles_x = (int)ceil_div(a.W, XD_TX); a.tiles_y = (int)ceil_div(a.H, XD_TY); a.tiles_z = (int)ceil_div(a.D, XD_TZ);
-  const int64_t nwork = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
-  RAGMI_REQUIRE(nwork < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3d: too many tiles");
-  e.nwork = (int)nwork;
   const bool bf = dtype == RAGMI_BF16;
-  const int ch8 = a.nchunks[0] / 2, ncog = (a.Cout + 15) / 16;
-  // two output blocks per workgroup share the operand reads when the weights of both fit next to the box (8 channels per set)
-  int cogs = (ch8 == 1 && ncog >= 2) ? 2 : 1;
-#ifdef RAGMI_DIAG
-  static const int diag_cogs = [] { const char* v = getenv("RAGMI_XD_COGS"); return v ? atoi(v) : 0; }();
-  if (diag_cogs == 1) cogs = 1;
-#endif
-#define RAGMI_XD(CH8_, NSET_, COGS_) (bf ? x3d_launch_one<bf16_t, CH8_, NSET_, COGS_>(a, e, st) : x3d_launch_one<float, CH8_, NSET_, COGS_>(a, e, st))
-  if (ch8 == 1) {
-    if (nset == 2) return cogs == 2 ? RAGMI_XD(1, 2, 2) : RAGMI_XD(1, 2, 1);
-    return cogs == 2 ? RAGMI_XD(1, 1, 2) : RAGMI_XD(1, 1, 1);
-  }
-  return nset == 2 ? RAGMI_XD(2, 2, 1) : RAGMI_XD(2, 1, 1);
+  const int ch8 = a.nchunks[0] / 2;
+  // (boxes of depth 4 — 32 column tiles, four per wave, the K-slice's weight fragments read once per four tiles — were measured
+  // on the 8-channel level: 62.7 us against 58.5; at 164 VGPRs only one workgroup fits a CU and its stages serialise)
+#define RAGMI_XD(CH8_, NSET_, TZ_) (bf ? x3d_launch_one<bf16_t, CH8_, NSET_, TZ_>(a, e, st) : x3d_launch_one<float, CH8_, NSET_, TZ_>(a, e, st))
+  if (ch8 == 1) return nset == 2 ? RAGMI_XD(1, 2, 2) : RAGMI_XD(1, 1, 2);
+  return nset == 2 ? RAGMI_XD(2, 2, 2) : RAGMI_XD(2, 1, 2);
 #undef RAGMI_XD
 }
 
