@@ -264,17 +264,17 @@ class BasicNetwork(nn.Module):
         return self.p
 
     def genotype(self) -> Genotype:
-        def _parse(alphas, steps):
-            gene, start, n = [], 0, 2
-            for _ in range(steps):
-                end = start + n
-                edges = sorted(range(start, end), key=lambda e: -np.max(alphas[e, 1:]))     # ignore the none value
-                for j in edges[:2]:
-                    gene.append([j, int(np.argmax(alphas[j]))])
-                start = end
-                n += 1
-            return np.array(gene)
+        """The discrete architecture the probabilities currently favour (mdenas_basicmodel.py:98-133): per step, the two incoming
+        edges whose strongest non-`none` operation is most probable, each with its most probable operation."""
+        def strongest_two(prob: np.ndarray) -> np.ndarray:
+            rows, first = [], 0
+            for width in range(2, 2 + self._steps):            # step k chooses among its k + 2 candidate edges
+                block = prob[first:first + width]
+                strength = block[:, 1:].max(axis=1)            # column 0 is the `none` operation
+                keep = first + np.argsort(-strength, kind="stable")[:2]
+                rows.extend([int(e), int(prob[e].argmax())] for e in keep)
+                first += width
+            return np.asarray(rows)
 
-        fea = F.softmax(self.p["normal"], dim=-1).numpy()
-        mat = F.softmax(self.p["reduce"], dim=-1).numpy()
-        return Genotype(normal=_parse(fea, self._steps), normal_concat=None, reduce=_parse(mat, self._steps), reduce_concat=None)
+        return Genotype(normal=strongest_two(F.softmax(self.p["normal"], dim=-1).numpy()), normal_concat=None,
+                        reduce=strongest_two(F.softmax(self.p["reduce"], dim=-1).numpy()), reduce_concat=None)
