@@ -156,9 +156,9 @@ extern "C" int ragmi_conv3d_k3_small_fwd_ex(const void* x, int64_t x_bstride, co
   RAGMI_REQUIRE(x && weight && y, RAGMI_EINVAL, "conv3d_k3_small: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k3_small: scale/shift must both be given or both NULL");
   RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k3_small: dtype %d not built", dtype);
-  RAGMI_REQUIRE(Cout >= 1 && Cout <= 2 && Cin % CK == 0 && (size_t)Cout * Cin * 27 * sizeof(float) <= (size_t)K3_MAX_WLDS_BYTES,
+  RAGMI_REQUIRE(Cout >= 1 && Cout <= 2 && Cin % CK == 0 && (size_t)Cout * Cin * 36 * sizeof(float) <= (size_t)K3_MAX_WLDS_BYTES,
                 RAGMI_EUNSUPPORTED, "conv3d_k3_small: needs Cout <= 2 and Cin a multiple of %d, <= %d (use ragmi_conv3d_k3_fwd otherwise)",
-                CK, K3_MAX_WLDS_BYTES / (2 * 27 * 4));
+                CK, K3_MAX_WLDS_BYTES / (2 * 36 * 4));
   K3Args a{};
   const int32_t ych = y_ch0, rch = res_ch0;
   const int rc = fill_common(a, x, x_bstride, y, y_bstride, &ych, res, res_bstride, &rch, B, Cin, Cout, D, H, W, relu);

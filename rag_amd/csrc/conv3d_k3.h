@@ -402,23 +402,26 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
 
   // VALU form of the same block: weights are wave-uniform scalar loads from the raw [Cout][Cin][27] tensor
   auto valu_block = [&](int chunk) {
-    const float* wc = wlds + chunk * NPAIR;      // raw weights cached in LDS: + co * Cin * 27 + (c * 27 + tap)
+    // raw weights cached in LDS, the nine taps of one (channel, dz) padded to twelve floats: + ((co * Cin + c) * 3 + dz) * 12 + tap.
+    // Three 16-byte broadcast reads fetch a (c, dz) row of weights; read one by one they were 9 of the 27 LDS instructions that
+    // feed 36 FMAs
+    const float* wc = wlds + chunk * (CK * 3 * 12);
     float vbuf[2][R + 2][3];
     load_v(vbuf[0], std::integral_constant<int, 0>{});
     static_for<CK * 3>([&](auto blk_) {
       constexpr int blk = decltype(blk_)::value;
-      constexpr int c = blk / 3, dz = blk % 3;
       if constexpr (blk + 1 < CK * 3) load_v(vbuf[(blk + 1) & 1], std::integral_constant<int, blk + 1>{});
-      static_for<9>([&](auto tap_) {
-        constexpr int dy = decltype(tap_)::value / 3, dx = decltype(tap_)::value % 3;
-        constexpr int q = c * 27 + (dz * 3 + dy) * 3 + dx;
 #pragma unroll
-        for (int co = 0; co < (VCO > 0 ? VCO : 1); ++co) {
-          const float w = wc[co * a.Cin * 27 + q];
+      for (int co = 0; co < (VCO > 0 ? VCO : 1); ++co) {
+        const float4* wq = reinterpret_cast<const float4*>(wc + co * a.Cin * 36 + blk * 12);
+        const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
+        const float w9[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
+        static_for<9>([&](auto tap_) {
+          constexpr int dy = decltype(tap_)::value / 3, dx = decltype(tap_)::value % 3;
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc[0][r][0][co] = fmaf(w, vbuf[blk & 1][r + dy][dx], acc[0][r][0][co]);
-        }
-      });
+          for (int r = 0; r < R; ++r) acc[0][r][0][co] = fmaf(w9[dy * 3 + dx], vbuf[blk & 1][r + dy][dx], acc[0][r][0][co]);
+        });
+      }
     });
   };
 
@@ -448,8 +451,11 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   if constexpr (VCO > 0) {
     // VALU form: the whole raw weight tensor [Cout][Cin][27] (<= a few KB) lives in LDS for the kernel's lifetime;
     // global loads of it inside the loop could not be scalar (stores may alias) and would stall every 16 weights
-    const int n = a.Cout * a.Cin * 27;
-    for (int i = tid; i < n; i += 256) wlds[i] = a.wp[0][i];
+    const int n = a.Cout * a.Cin * 36;         // [co][c][dz][12]: nine taps + three pad floats
+    for (int i = tid; i < n; i += 256) {
+      const int k = i % 12, row = i / 12;        // row = (co * Cin + c) * 3 + dz
+      wlds[i] = k < 9 ? a.wp[0][row * 9 + k] : 0.f;
+    }
   } else if (a.w_in_lds) {
     // the G groups of this workgroup are one contiguous block per set in the packed array
 #pragma unroll
@@ -538,7 +544,7 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   // for them drains the prefetch that should fly under the MFMAs)
   const size_t wbudget = std::max<size_t>(K3_MAX_WLDS_BYTES, tile_bytes < 78 * 1024 ? 78 * 1024 - tile_bytes : 0);
   a.w_in_lds = (VCO == 0 && policy != 0 && wbytes <= wbudget && (policy == 1 || nstages > 1)) ? 1 : 0;
-  const size_t lds = tile_bytes + (VCO > 0 ? (size_t)a.Cout * a.Cin * 27 * sizeof(float) : (a.w_in_lds ? wbytes : 0));
+  const size_t lds = tile_bytes + (VCO > 0 ? (size_t)a.Cout * a.Cin * 36 * sizeof(float) : (a.w_in_lds ? wbytes : 0));
   // per-device, mutex-guarded launch state of this instantiation: the dynamic-LDS attribute applies to the CURRENT device only, and
   // forward (main thread) and backward (autograd worker thread) both come through here
   static LaunchState state;

@@ -554,7 +554,8 @@ bool x3d_eligible(const K3Args& a, int nset, int dtype) {
   if ((nc != 2 && nc != 4) || (nset == 2 && a.nchunks[1] != nc) || a.Cin != nset * nc * 4) return false;
   // volumes only (the depth-1 Feature-Net convolutions would idle half of every 2-deep box), and big enough that the persistent
   // grid has boxes to walk: below 2^14 voxels (128 boxes) the fp32 kernel's latency is the same and its arithmetic exact
-  if (a.D < 2 || a.W < 8 || (int64_t)a.B * a.D * a.H * a.W < XD_MIN_VOXELS || (int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
+  // (per SAMPLE, not per batch: which kernel a pair runs on must not depend on how the batch is split over ranks)
+  if (a.D < 2 || a.W < 8 || (int64_t)a.D * a.H * a.W < XD_MIN_VOXELS || (int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
   return true;
 }
 
@@ -631,7 +632,8 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
   if (nset == 2 && (a.nchunks[0] != a.nchunks[1] || a.nchunks[0] > 2)) return false;
   if (nset == 1 && ncg > 6) return false;
-  if ((int64_t)a.B * a.D * a.H * a.W < X3_MIN_VOXELS || a.W < 32 || a.D < 8) return false;
+  // voxels per SAMPLE: the choice of kernel (hence the rounding) must not depend on how a batch is split over ranks
+  if ((int64_t)a.D * a.H * a.W < X3_MIN_VOXELS || a.W < 32 || a.D < 8) return false;
   if (a.ntail > 0 && a.Cout > 16) return false;
   if ((int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
   return true;
