@@ -6,6 +6,8 @@
 // voxels (one 16-B column of every channel plane), streams the Cin planes once with
 // coalesced dwordx4 loads, keeps all NCO outputs in registers, and writes NCO coalesced
 // dwordx4 stores.  Weights/scale/shift are wave-uniform -> scalar (SGPR) loads.
+#include <algorithm>
+
 #include "common.h"
 
 namespace ragmi {
@@ -28,10 +30,17 @@ struct K1Args {
 template <class T, int NCO, bool VEC>
 __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
   constexpr int V = VEC ? 4 : 1;
+  // this slab's weights [ci][NCO] through LDS (broadcast 16-byte reads) instead of NCO scalar loads per input channel
+  extern __shared__ __attribute__((aligned(16))) float k1_w[];
+  a.co0 = blockIdx.z * NCO;   // output-channel slab of this block
+  for (int i = threadIdx.x; i < a.Cin * NCO; i += 256) {
+    const int ci = i / NCO, co = a.co0 + i % NCO;
+    k1_w[i] = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
+  }
+  __syncthreads();
   const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= a.dhw) return;
   const int b = blockIdx.y;
-  a.co0 = blockIdx.z * NCO;   // output-channel slab of this block
   const T* xp = static_cast<const T*>(a.x) + b * a.x_bstride + p;
   float acc[NCO][V];
 #pragma unroll
@@ -47,13 +56,16 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
     } else {
       xv[0] = ld(xp + (int64_t)ci * a.dhw);
     }
+    float wv[NCO];
 #pragma unroll
-    for (int j = 0; j < NCO; ++j) {
-      const int co = a.co0 + j;
-      const float wv = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
-#pragma unroll
-      for (int k = 0; k < V; ++k) acc[j][k] = fmaf(wv, xv[k], acc[j][k]);
+    for (int j = 0; j < NCO; j += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(k1_w + ci * NCO + j);
+      wv[j] = q.x; wv[j + 1] = q.y; wv[j + 2] = q.z; wv[j + 3] = q.w;
     }
+#pragma unroll
+    for (int j = 0; j < NCO; ++j)
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[j][k] = fmaf(wv[j], xv[k], acc[j][k]);
   }
   T* yp = static_cast<T*>(a.y) + b * a.y_bstride + p;
 #pragma unroll
@@ -95,14 +107,23 @@ struct K1RPair {
 
 template <class T, int NCO>
 __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
+  // this slab's weights, [ci][NCO], staged once per workgroup and read back as broadcast 16-byte LDS reads.  Read straight from
+  // global memory they are NCO scalar loads per input channel, each behind its own branch and wait: on the small (level-12)
+  // launches that scalar traffic, not the gathers, was the kernel
+  extern __shared__ __attribute__((aligned(16))) float k1r_w[];
   const int which = (int)blockIdx.z >= pr.splits[0] ? 1 : 0;
   K1RArgs& r = pr.c[which];
   K1Args& a = r.k;
   const int64_t ovol = (int64_t)r.Do * r.Ho * r.Wo;
+  a.co0 = ((int)blockIdx.z - (which ? pr.splits[0] : 0)) * NCO;
+  for (int i = threadIdx.x; i < a.Cin * NCO; i += 256) {
+    const int ci = i / NCO, co = a.co0 + i % NCO;
+    k1r_w[i] = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
+  }
+  __syncthreads();
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= ovol) return;
   const int b = blockIdx.y;
-  a.co0 = ((int)blockIdx.z - (which ? pr.splits[0] : 0)) * NCO;
   const int ox = (int)(o % r.Wo);
   const int64_t t = o / r.Wo;
   const int oy = (int)(t % r.Ho), oz = (int)(t / r.Ho);
@@ -131,12 +152,14 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
       for (int u = 0; u < UI; ++u) {
         if (c0 + u >= a.Cin) break;
         const int ci = c0 + u;
+        float wv[NCO];
 #pragma unroll
-        for (int j = 0; j < NCO; ++j) {
-          const int co = a.co0 + j;
-          const float wv = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
-          acc[j] = fmaf(wv, xv[u], acc[j]);
+        for (int j = 0; j < NCO; j += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(k1r_w + ci * NCO + j);
+          wv[j] = q.x; wv[j + 1] = q.y; wv[j + 2] = q.z; wv[j + 3] = q.w;
         }
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) acc[j] = fmaf(wv[j], xv[u], acc[j]);
       }
     }
   } else {
@@ -168,12 +191,14 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
         const float a0 = ly.w0 * (lx.w0 * tap[u][0] + lx.w1 * tap[u][1]) + ly.w1 * (lx.w0 * tap[u][2] + lx.w1 * tap[u][3]);
         const float a1 = ly.w0 * (lx.w0 * tap[u][4] + lx.w1 * tap[u][5]) + ly.w1 * (lx.w0 * tap[u][6] + lx.w1 * tap[u][7]);
         const float xv = lz.w0 * a0 + lz.w1 * a1;
+        float wv[NCO];
 #pragma unroll
-        for (int j = 0; j < NCO; ++j) {
-          const int co = a.co0 + j;
-          const float wv = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
-          acc[j] = fmaf(wv, xv, acc[j]);
+        for (int j = 0; j < NCO; j += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(k1r_w + ci * NCO + j);
+          wv[j] = q.x; wv[j + 1] = q.y; wv[j + 2] = q.z; wv[j + 3] = q.w;
         }
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) acc[j] = fmaf(wv[j], xv, acc[j]);
       }
     }
   }
@@ -196,7 +221,8 @@ static void launch_k1r_nco(const K1RArgs* r, int n, int B, hipStream_t s) {
   pr.splits[0] = (int)ceil_div(r[0].k.Cout, NCO);
   pr.splits[1] = n == 2 ? (int)ceil_div(r[1].k.Cout, NCO) : 0;
   dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)(pr.splits[0] + pr.splits[1]));
-  hipLaunchKernelGGL((conv_k1_resample_kernel<T, NCO>), grid, dim3(256), 0, s, pr);
+  const size_t wlds = (size_t)std::max(r[0].k.Cin, r[n - 1].k.Cin) * NCO * sizeof(float);
+  hipLaunchKernelGGL((conv_k1_resample_kernel<T, NCO>), grid, dim3(256), wlds, s, pr);
 }
 
 static int fill_k1r(K1RArgs& r, const void* x, int64_t x_bstride, int Di, int Hi, int Wi, const void* weight, const void* scale,
@@ -206,7 +232,7 @@ static int fill_k1r(K1RArgs& r, const void* x, int64_t x_bstride, int Di, int Hi
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1_resample: scale/shift must both be given or both NULL");
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && y_ch0 >= 0, RAGMI_EINVAL,
                 "conv3d_k1_resample: bad size");
-  RAGMI_REQUIRE(B <= 65535 && (int64_t)Di * Hi * Wi < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: size too large");
+  RAGMI_REQUIRE(B <= 65535 && (int64_t)Di * Hi * Wi < (1ll << 31) && Cin <= 512, RAGMI_EUNSUPPORTED, "conv3d_k1_resample: size too large");
   r.k = K1Args{x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
                y, y_bstride, y_ch0, Cin, Cout, 0, (int64_t)Do * Ho * Wo, relu, Cin, 1};
   r.Di = Di; r.Hi = Hi; r.Wi = Wi; r.Do = Do; r.Ho = Ho; r.Wo = Wo;
@@ -269,7 +295,7 @@ template <class T, int NCO, bool VEC>
 static void launch_k1_nco(const K1Args& a, int B, hipStream_t s) {
   constexpr int V = VEC ? 4 : 1;
   dim3 grid((unsigned)ceil_div(ceil_div(a.dhw, V), 256), B, (unsigned)ceil_div(a.Cout, NCO));
-  hipLaunchKernelGGL((conv_k1_kernel<T, NCO, VEC>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_k1_kernel<T, NCO, VEC>), grid, dim3(256), (size_t)a.Cin * NCO * sizeof(float), s, a);
 }
 
 // Pick the widest output slab per thread that still leaves enough threads to fill the chip:
@@ -316,7 +342,7 @@ extern "C" int ragmi_conv3d_k1_fwd_ex(const void* x, int64_t x_bstride, const vo
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "conv3d_k1: scale/shift must both be given or both NULL");
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && DHW > 0 && y_ch0 >= 0, RAGMI_EINVAL, "conv3d_k1: bad size");
   RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1: dtype %d not built", dtype);
-  RAGMI_REQUIRE(B <= 65535 && Cout <= 4 * 65535, RAGMI_EUNSUPPORTED, "conv3d_k1: B or Cout too large");
+  RAGMI_REQUIRE(B <= 65535 && Cout <= 4 * 65535 && Cin <= 512, RAGMI_EUNSUPPORTED, "conv3d_k1: B, Cin or Cout too large");
   K1Args a{x, x_bstride, (const float*)weight, (const float*)scale, (const float*)shift,
            y, y_bstride, y_ch0, Cin, Cout, 0, DHW, relu, w_transposed ? 1 : Cin, w_transposed ? Cout : 1};
   // 16-B columns need alignment; small volumes use one voxel per thread for 4x the parallelism
