@@ -191,17 +191,20 @@ constexpr int CB_NI = 4;              // measured at the headline shape: 1 -> 59
 // lanes where W is not a multiple of the workgroup).  Headline shape, no tails: 80 us -> 53 us.  (A row form with the B rows in
 // LDS, A in registers and 16-byte stores was built and measured first: 56 us for the interior + 29 us for the band / border voxels
 // in a second launch — latency-bound workgroups, not store-bound: pure stores of this layout reach 6.7 TB/s, tools/probe_store.hip.)
-template <class T>
+// NC = Cout as a compile-time constant (4, 8, 12, 16: exact register tiles, no per-channel bound checks) or 0 = any Cout <= CS_MAXC
+template <class T, int NC>
 __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a) {
+  constexpr int MC = NC > 0 ? NC : CS_MAXC;
+  const int Cout = NC > 0 ? NC : a.Cout;
   __shared__ float par[2 * CS_MAXC + 2 * (4 * CS_MAXC + 8)];      // scale | shift | per tail: w[4][Cout] scale[4] shift[4]
-  for (int e = threadIdx.x; e < a.Cout; e += 256) {
+  for (int e = threadIdx.x; e < Cout; e += 256) {
     par[e] = a.scale ? a.scale[e] : 1.f;
     par[CS_MAXC + e] = a.shift ? a.shift[e] : 0.f;
   }
   for (int t = 0; t < a.ntail; ++t) {
     float* p = par + 2 * CS_MAXC + t * (4 * CS_MAXC + 8);
     const ragmi_tail_t& tl = a.tail[t];
-    for (int e = threadIdx.x; e < tl.cout * a.Cout; e += 256) p[e] = static_cast<const float*>(tl.weight)[e];
+    for (int e = threadIdx.x; e < tl.cout * Cout; e += 256) p[e] = static_cast<const float*>(tl.weight)[e];
     for (int e = threadIdx.x; e < tl.cout; e += 256) {
       p[4 * CS_MAXC + e] = tl.scale ? static_cast<const float*>(tl.scale)[e] : 1.f;
       p[4 * CS_MAXC + 4 + e] = tl.shift ? static_cast<const float*>(tl.shift)[e] : 0.f;
@@ -215,9 +218,9 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
   const float* ws = a.ws + b * a.ws_bstride;
   const int xr = x == a.W - 1 ? 1 : 0;
   const int64_t HW = (int64_t)a.H * a.W, DHW = HW * a.D;
-  float av[CS_MAXC];
+  float av[MC];
 #pragma unroll
-  for (int co = 0; co < CS_MAXC; ++co) av[co] = 0.f;
+  for (int co = 0; co < MC; ++co) av[co] = 0.f;
   int key = -1;                                                   // (cls, tc) the registers in av belong to
 #pragma unroll 2
   for (int i = i0; i < i1; ++i) {
@@ -229,9 +232,9 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
       const float* pa = nullptr;
       int64_t sa = 0;
       if (tc == 2) { pa = ws + a.off_afull[cls] + (int64_t)y * a.W + x; sa = HW; }
-      else if (tc > -3) { pa = ws + a.off_aband[cls] + (int64_t)(tc + 2) * a.Cout * a.H * a.wband + (int64_t)y * a.wband + x; sa = (int64_t)a.H * a.wband; }
+      else if (tc > -3) { pa = ws + a.off_aband[cls] + (int64_t)(tc + 2) * Cout * a.H * a.wband + (int64_t)y * a.wband + x; sa = (int64_t)a.H * a.wband; }
 #pragma unroll
-      for (int co = 0; co < CS_MAXC; ++co) av[co] = (co < a.Cout && pa) ? pa[co * sa] : 0.f;
+      for (int co = 0; co < MC; ++co) av[co] = (co < Cout && pa) ? pa[co * sa] : 0.f;
     }
     // B: indexed by u = x - i (>= -2 to contribute); the right-border variant lives on u in [u1_0, W-1]
     const float* pb = nullptr;
@@ -240,10 +243,10 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
       if (xr) { pb = ws + a.off_b1[cls] + (int64_t)y * a.wb1 + (t - a.u1_0); sb = (int64_t)a.H * a.wb1; }
       else { pb = ws + a.off_b0[cls] + (int64_t)y * (a.W + 2) + (t + 2); sb = (int64_t)a.H * (a.W + 2); }
     }
-    float v[CS_MAXC];
+    float v[MC];
 #pragma unroll
-    for (int co = 0; co < CS_MAXC; ++co) {
-      if (co < a.Cout) {
+    for (int co = 0; co < MC; ++co) {
+      if (co < Cout) {
         float s = av[co] + (pb ? pb[co * sb] : 0.f);
         s = fmaf(s, par[co], par[CS_MAXC + co]);
         v[co] = a.relu ? fmaxf(s, 0.f) : s;
@@ -254,8 +257,8 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
     const int64_t vox = (int64_t)i * HW + pix;
     T* py = static_cast<T*>(a.y) + b * a.y_bstride + vox;
 #pragma unroll
-    for (int co = 0; co < CS_MAXC; ++co)
-      if (co < a.Cout) st(py + co * DHW, v[co]);
+    for (int co = 0; co < MC; ++co)
+      if (co < Cout) st(py + co * DHW, v[co]);
     for (int tl = 0; tl < a.ntail; ++tl) {
       const float* p = par + 2 * CS_MAXC + tl * (4 * CS_MAXC + 8);
       const ragmi_tail_t& td = a.tail[tl];
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
       for (int k = 0; k < td.cout; ++k) {
         float s = 0.f;
 #pragma unroll
-        for (int co = 0; co < CS_MAXC; ++co)
-          if (co < a.Cout) s = fmaf(p[k * a.Cout + co], v[co], s);
+        for (int co = 0; co < MC; ++co)
+          if (co < Cout) s = fmaf(p[k * Cout + co], v[co], s);
         s = fmaf(s, p[4 * CS_MAXC + k], p[4 * CS_MAXC + 4 + k]);
         st(pt + k * DHW, td.relu ? fmaxf(s, 0.f) : s);
       }
@@ -392,7 +395,15 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
   ca.ni = ni;
   RAGMI_REQUIRE((int64_t)H * W < (1ll << 31) && ceil_div(D, ni) <= 65535, RAGMI_EUNSUPPORTED, "costvol_stem: volume exceeds the grid limit");
   const dim3 cgrid((unsigned)ceil_div((int64_t)H * W, 256), (unsigned)ceil_div(D, ni), (unsigned)B);
-  if (dtype == RAGMI_BF16) hipLaunchKernelGGL(costvol_stem_combine_kernel<bf16_t>, cgrid, dim3(256), 0, st, ca);
-  else hipLaunchKernelGGL(costvol_stem_combine_kernel<float>, cgrid, dim3(256), 0, st, ca);
+#define RAGMI_CS_COMBINE(TT)                                                                                    \
+  switch (Cout) {                                                                                               \
+    case 4: hipLaunchKernelGGL((costvol_stem_combine_kernel<TT, 4>), cgrid, dim3(256), 0, st, ca); break;       \
+    case 8: hipLaunchKernelGGL((costvol_stem_combine_kernel<TT, 8>), cgrid, dim3(256), 0, st, ca); break;       \
+    case 12: hipLaunchKernelGGL((costvol_stem_combine_kernel<TT, 12>), cgrid, dim3(256), 0, st, ca); break;     \
+    case 16: hipLaunchKernelGGL((costvol_stem_combine_kernel<TT, 16>), cgrid, dim3(256), 0, st, ca); break;     \
+    default: hipLaunchKernelGGL((costvol_stem_combine_kernel<TT, 0>), cgrid, dim3(256), 0, st, ca); break;      \
+  }
+  if (dtype == RAGMI_BF16) { RAGMI_CS_COMBINE(bf16_t) } else { RAGMI_CS_COMBINE(float) }
+#undef RAGMI_CS_COMBINE
   return check_launch("costvol_stem");
 }
