@@ -163,21 +163,34 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   float pf[NPF][4];
   unsigned valid = 0;
   const T* const x = static_cast<const T*>(a.x);
-  // issue the loads of input plane gz of the column at (y0, x0): unconditional, addresses clamped into the volume
-  auto prefetch = [&](const T* xb, int gz, int y0, int x0) {
-    valid = 0;
-    const bool zok = (unsigned)gz < (unsigned)a.D;
-    const int cz = min(max(gz, 0), a.D - 1);
+  // this thread's halo elements of a column, located ONCE per column: element offset of each of the four channels inside the
+  // plane (channel clamp and (y, x) clamp folded in) and whether the voxel lies inside the plane.  Per plane only the wave-uniform
+  // plane base changes, so the loads are `uniform base + lane offset` with no address arithmetic left in the z loop (per plane it
+  // was ~100 VALU instructions per wave next to 48 MFMAs, and VALU issue is additive to MFMA issue on this chip)
+  int voff[NPF];
+  unsigned vmask = 0;
+  auto locate = [&](int y0, int x0) {
+    vmask = 0;
 #pragma unroll
     for (int p = 0; p < NPF; ++p) {
       const int el = p * X3_THREADS + tid, cg = el / X3_PL, r = el % X3_PL;
       const int xx = r % X3_HX, yy = r / X3_HX;
       const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
-      const bool ok = zok && cg < NCG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      valid |= (ok ? 1u : 0u) << p;
-      const unsigned off = (unsigned)(cz * HW + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
+      const bool ok = cg < NCG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      vmask |= (ok ? 1u : 0u) << p;
+      // whole 4-channel groups only (x3_eligible): the group's channels are c * DHW apart, a wave-uniform step.  Cin * DHW < 2^31.
+      voff[p] = (int)(min(cg, NCG - 1) * 4 * DHW) + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
+    }
+  };
+  // issue the loads of input plane gz of the located column: unconditional, the plane index clamped into the volume
+  auto prefetch = [&](const T* xb, int gz) {
+    valid = (unsigned)gz < (unsigned)a.D ? vmask : 0u;
+    const T* const pb = xb + (int64_t)min(max(gz, 0), a.D - 1) * HW;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pf[p][c] = ld(xb + (int64_t)min(cg * 4 + c, a.Cin - 1) * DHW + off);
+    for (int c = 0; c < 4; ++c) {
+      const T* const pc = pb + c * DHW;            // wave-uniform
+#pragma unroll
+      for (int p = 0; p < NPF; ++p) pf[p][c] = ld(pc + voff[p]);
     }
   };
   auto commit = [&](int slot) {          // registers -> ring plane `slot` (bf16 hi / lo), zeros outside the volume / past Cin
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const int cg = el / X3_PL, r = el % X3_PL;
       float v[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = (((valid >> p) & 1u) && cg * 4 + c < a.Cin) ? pf[p][c] : 0.f;
+      for (int c = 0; c < 4; ++c) v[c] = ((valid >> p) & 1u) ? pf[p][c] : 0.f;
       unsigned l01, l23;
       const unsigned h01 = x3_split2(v[0], v[1], l01), h23 = x3_split2(v[2], v[3], l23);
       const int d = (cg * 3 + slot) * X3_PL + r;
@@ -200,6 +213,12 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // sits a compile-time distance behind tile 0 (an immediate offset of the LDS read)
   static_assert(X3_NT % 2 == 0, "tile deltas below assume an even number of column tiles per wave");
   const int vb0 = ((wave * X3_NT >> 1) * X3_HX + n) * (int)sizeof(uint2);
+  int vbt[X3_NT];                                      // byte base of each of this wave's column tiles (see the K loop)
+#pragma unroll
+  for (int i = 0; i < X3_NT; ++i) {
+    vbt[i] = vb0 + ((i >> 1) * X3_HX + (i & 1) * 16) * (int)sizeof(uint2);
+    asm volatile("" : "+v"(vbt[i]));
+  }
   const char* const lbytes = reinterpret_cast<const char*>(x3_lds);
   constexpr int LO_BYTES = NCG * 3 * X3_PL * (int)sizeof(uint2);
   const int g = cog * 4 + kb, ngroups = (a.Cout + 3) >> 2;
@@ -220,16 +239,17 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     const int zs = seg * e.seg_len, ze = min(a.D, zs + e.seg_len);
     const T* xb = x + b * a.x_bstride;
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
-    prefetch(xb, zs - 1, y0, x0); commit((zs - 1 + 3) % 3);
-    prefetch(xb, zs, y0, x0); commit(zs % 3);
-    prefetch(xb, zs + 1, y0, x0);
+    locate(y0, x0);
+    prefetch(xb, zs - 1); commit((zs - 1 + 3) % 3);
+    prefetch(xb, zs); commit(zs % 3);
+    prefetch(xb, zs + 1);
     for (int z = zs; z < ze; ++z) {
       __syncthreads();                                 // plane z-2 (same ring slot as z+1) is no longer read
       commit((z + 1) % 3);
       __syncthreads();
       // unconditional (also past the segment end: the addresses are clamped): the loads stay straight-line code ahead of the
       // MFMA block, a branch here made the compiler drain them (s_waitcnt vmcnt(0)) before the first LDS read
-      prefetch(xb, z + 2, y0, x0);
+      prefetch(xb, z + 2);
       __builtin_amdgcn_sched_barrier(0);               // ...and the scheduler must not sink them below the MFMAs either
       f32x4 acc[NSET][X3_NT];
 #pragma unroll
@@ -244,17 +264,18 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         const x3_bf16x8 ah = __builtin_bit_cast(x3_bf16x8, lw[(s * 2 + 0) * 64 + lane]);
         const x3_bf16x8 al = __builtin_bit_cast(x3_bf16x8, lw[(s * 2 + 1) * 64 + lane]);
         const int2 po = lo_r[s * 4];
-        const char* const a0 = lbytes + vb0 + po.x;
-        const char* const a1 = lbytes + vb0 + po.y;
         x3_bf16x8 bh[X3_NT], bl[X3_NT];
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) {
-          constexpr int ROWB = X3_HX * (int)sizeof(uint2), HALFB = 16 * (int)sizeof(uint2);
-          const int d = (i >> 1) * ROWB + (i & 1) * HALFB;          // compile time: tile i relative to tile 0
-          const uint2 h0 = *reinterpret_cast<const uint2*>(a0 + d), h1 = *reinterpret_cast<const uint2*>(a1 + d);
+          // per-tile base registers whose relation the compiler cannot see (vbt): at a visible constant distance it fuses the
+          // SAME pair of two tiles into one ds_read2_b64 — half rate, and its result lands as (tile 0, tile 1) where the MFMA
+          // operand wants (pair 0, pair 1) of ONE tile: 96 of the 258 VALU instructions of a plane were the v_movs that undo it
+          const char* const a0 = lbytes + vbt[i] + po.x;
+          const char* const a1 = lbytes + vbt[i] + po.y;
+          const uint2 h0 = *reinterpret_cast<const uint2*>(a0), h1 = *reinterpret_cast<const uint2*>(a1);
           bh[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
           if constexpr (!BF) {
-            const uint2 l0 = *reinterpret_cast<const uint2*>(a0 + d + LO_BYTES), l1 = *reinterpret_cast<const uint2*>(a1 + d + LO_BYTES);
+            const uint2 l0 = *reinterpret_cast<const uint2*>(a0 + LO_BYTES), l1 = *reinterpret_cast<const uint2*>(a1 + LO_BYTES);
             bl[i] = __builtin_bit_cast(x3_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
           }
         }
@@ -629,6 +650,7 @@ int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin
 bool x3_eligible(const K3Args& a, int nset, int dtype) {
   // the caller asks for it through the dtype argument (include/rag_amd.h): RAGMI_F32 never comes here
   if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || a.res != nullptr) return false;
+  if (a.Cin % 4 != 0) return false;              // whole 4-channel operand groups (the reference's channel counts all are)
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
   if (nset == 2 && (a.nchunks[0] != a.nchunks[1] || a.nchunks[0] > 2)) return false;
   if (nset == 1 && ncg > 6) return false;
