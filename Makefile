@@ -14,6 +14,11 @@ endif
 
 all: $(LIB)
 
+# Per-file code generation choices, each measured on the MI355X with both builds on the same box (tools/ab_bench.sh, rocprofv3):
+# the SLP vectorizer packs the soft-argmin's independent fp32 chains into v_pk_* pairs and pays for it in v_mov shuffles
+# (57 -> 47 us with it off); the cost-volume planes kernel gains from the same packing (54 us with, 60 without), so it stays on elsewhere.
+$(CSRC)/disp.o: CXXFLAGS += -fno-slp-vectorize
+
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv3d_k3.h include/rag_amd.h
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
