@@ -107,6 +107,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog = blockIdx.y;
   const int HW = a.H * a.W;
+  const float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
   const int64_t DHW = (int64_t)HW * a.D;
   for (int i = tid; i < NSL * 2 * 64; i += X3_THREADS) {
     const int set = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 #pragma unroll
           for (int st = 0; st < NSET; ++st) {
             float u = fmaf(acc[st][i][r], par[st * 16 + 4 * kb + r], par[32 + st * 16 + 4 * kb + r]);
-            sum += a.relu ? fmaxf(u, 0.f) : u;
+            sum += fmaxf(u, act_floor);                  // ReLU, or the identity (floor = NaN): one instruction either way
           }
           v[r] = sum;
         }
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog0 = blockIdx.y * COGS, ncog = (a.Cout + 15) >> 4;
   const int HW = a.H * a.W;
+  const float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
   const int64_t DHW = (int64_t)HW * a.D;
   // weight fragments of this workgroup's output blocks: A[row = lane & 15][k = 8 kb + j] = w[co][channel 8 cg8 + j][tap (dz, dy, dx)],
   // (cg8, dx) from the lane quarter and the slice; gathered in 8-byte halves (4 channels of one tap) from the packed fragments
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
 #pragma unroll
           for (int st = 0; st < NSET; ++st) {
             const float u = fmaf(acc[st][cl][i][r], par[(st * COGS + cl) * 16 + 4 * kb + r], par[NSET * COGS * 16 + (st * COGS + cl) * 16 + 4 * kb + r]);
-            sum += a.relu ? fmaxf(u, 0.f) : u;
+            sum += fmaxf(u, act_floor);                  // ReLU, or the identity (floor = NaN): one instruction either way
           }
           v[r] = sum;
         }
