@@ -362,10 +362,13 @@ constexpr int XD_HY = XD_TY + 2, XD_HX = XD_TX + 3;
 constexpr int64_t XD_MIN_VOXELS = 1 << 14;
 constexpr int XD_THREADS = 512;                        // 8 waves: wave w owns rows (w & 3) * 2, +1 of planes w >> 2 (, + 2)
 
-// TZ = box depth: 2 (16 column tiles, two per wave; the shipped form) or 4 (32 column tiles, four per wave: see x3d_launch)
-template <class T, int CH8, int NSET, int TZ>
-__global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3Extra e) {
-  constexpr int COGS = 1, XD_TZ = TZ, XD_HZ = TZ + 2, XD_PL = XD_HZ * XD_HY * XD_HX, XD_NT = TZ;
+// COGS = output-channel blocks of 16 per workgroup (they share every operand read).  WS = the weight fragments of ONE set live in
+// LDS and are re-staged with every stage's box (from L2, 37 KB) instead of all sets' staying resident: what lets two blocks
+// per workgroup (8 channels per set) still fit two workgroups per CU.
+template <class T, int CH8, int NSET, int COGS, bool WS>
+__global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Args a, X3Extra e) {
+  static_assert(!WS || NSET == 2, "per-stage weights only pay with two sets");
+  constexpr int XD_TZ = 2, XD_HZ = XD_TZ + 2, XD_PL = XD_HZ * XD_HY * XD_HX, XD_NT = XD_TZ;
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int SPR = CH8;                              // K-slices per (dz, dy) row: 8 ch -> dx 0..3 in one, 16 ch -> {0,1} and {2,3}
   constexpr int NSLS = 9 * SPR;                         // slices per set
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
   constexpr int REC = CH8 * XD_PL;                      // 16-byte records per copy (hi or lo)
   extern __shared__ __attribute__((aligned(16))) uint4 xd_lds[];
   uint4* const lw = xd_lds + (BF ? 1 : 2) * REC;        // [set][block][slice][hi/lo][64 lanes]
-  float* const par = reinterpret_cast<float*>(lw + NSET * COGS * NSLS * 2 * 64);   // scale[set][block][16] | shift[...]
+  float* const par = reinterpret_cast<float*>(lw + (WS ? 1 : NSET) * COGS * NSLS * 2 * 64);   // scale[set][block][16] | shift[...]
   uint2* const lhi2 = reinterpret_cast<uint2*>(xd_lds);
   uint2* const llo2 = reinterpret_cast<uint2*>(xd_lds + REC);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
@@ -387,30 +390,39 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
   // (cg8, dx) from the lane quarter and the slice; gathered in 8-byte halves (4 channels of one tap) from the packed fragments
   // (nine gathers in flight per thread: as a plain loop the 18 trips each waited out an L2 round trip — 10 of the 40 us of a
   // level-12 launch were this prologue)
-  constexpr int NWH = NSET * COGS * NSLS * 2 * 64 * 2, NWB = 9;
-  for (int i0 = tid; i0 < NWH; i0 += NWB * XD_THREADS) {
-    uint2 wv[NWB];
+  constexpr int NWS = COGS * NSLS * 2 * 64 * 2;          // 8-byte halves of one set's fragments
+  constexpr int NWT = (NWS + XD_THREADS - 1) / XD_THREADS;   // ... per thread (9 for 18 K-slices x 1 block or 9 x 2)
+  int wsrc[NWT];                                         // source (in 8-byte units from e.wf[set]) of this thread's halves, -1: a zero
 #pragma unroll
-    for (int u = 0; u < NWB; ++u) {
-      const int i = min(i0 + u * XD_THREADS, NWH - 1);
-      const int half = i & 1;
-      int q = i >> 1;
-      const int ln = q & 63; q >>= 6;
-      const int hl = q & 1; q >>= 1;
-      const int sl = q % NSLS; q /= NSLS;
-      const int cl = q % COGS, set = q / COGS;
-      const int m = ln & 15, kq = ln >> 4;
-      const int cg8 = CH8 == 2 ? (kq & 1) : 0, dx = 2 * (sl % SPR) + (CH8 == 2 ? (kq >> 1) : kq);
-      const bool real = dx < 3 && cog0 + cl < ncog;
-      const int tap = (sl / SPR) * 3 + min(dx, 2);      // (dz * 3 + dy) * 3 + dx
-      const int P = (2 * cg8 + half) * 27 + tap;        // pair index of the packed layout: 4-channel group * 27 + tap
-      const uint2* src = reinterpret_cast<const uint2*>(e.wf[set] + ((int64_t)(min(cog0 + cl, ncog - 1) * NSLS_V1 + (P >> 3)) * 2 + hl) * 64 + ((P & 7) >> 1) * 16 + m);
-      const uint2 v = src[P & 1];                       // unconditional (clamped) load, zeroed below: stays straight-line code
-      wv[u] = real ? v : make_uint2(0u, 0u);
-    }
+  for (int u = 0; u < NWT; ++u) {
+    const int i = min(tid + u * XD_THREADS, NWS - 1);
+    const int half = i & 1;
+    int q = i >> 1;
+    const int ln = q & 63; q >>= 6;
+    const int hl = q & 1; q >>= 1;
+    const int sl = q % NSLS, cl = q / NSLS;
+    const int m = ln & 15, kq = ln >> 4;
+    const int cg8 = CH8 == 2 ? (kq & 1) : 0, dx = 2 * (sl % SPR) + (CH8 == 2 ? (kq >> 1) : kq);
+    const int tap = (sl / SPR) * 3 + min(dx, 2);        // (dz * 3 + dy) * 3 + dx
+    const int P = (2 * cg8 + half) * 27 + tap;          // pair index of the packed layout: 4-channel group * 27 + tap
+    const int src = ((((min(cog0 + cl, ncog - 1) * NSLS_V1 + (P >> 3)) * 2 + hl) * 64 + ((P & 7) >> 1) * 16 + m) << 1) + (P & 1);
+    wsrc[u] = (dx < 3 && cog0 + cl < ncog) ? src : -1;
+  }
+  uint2 wv[NWT];
+  auto wfetch = [&](int set) {                           // unconditional (clamped) loads, zeroed at the commit: straight-line code
+    const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set]);
 #pragma unroll
-    for (int u = 0; u < NWB; ++u)
-      if (i0 + u * XD_THREADS < NWH) reinterpret_cast<uint2*>(lw)[i0 + u * XD_THREADS] = wv[u];
+    for (int u = 0; u < NWT; ++u) wv[u] = src[max(wsrc[u], 0)];
+  };
+  auto wcommit = [&](int region) {
+    uint2* const dst = reinterpret_cast<uint2*>(lw) + region * NWS;
+#pragma unroll
+    for (int u = 0; u < NWT; ++u)
+      if (tid + u * XD_THREADS < NWS) dst[tid + u * XD_THREADS] = wsrc[u] >= 0 ? wv[u] : make_uint2(0u, 0u);
+  };
+  if constexpr (!WS) {
+#pragma unroll
+    for (int set = 0; set < NSET; ++set) { wfetch(set); wcommit(set); }
   }
   for (int i = tid; i < NSET * COGS * 16; i += XD_THREADS) {
     const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
@@ -486,6 +498,7 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
     decode(work_of(j), b, z0, y0, x0);
     locate(z0, y0, x0);
     prefetch(x + b * a.x_bstride, 0);
+    if constexpr (WS) wfetch(0);
   }
 #ifdef RAGMI_DIAG
   const bool diag_nostore = (a.relu & 0x100) != 0, diag_nomfma = (a.relu & 0x200) != 0, diag_nostage = (a.relu & 0x400) != 0;
@@ -508,11 +521,13 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
       constexpr int st = decltype(st_)::value;
       __syncthreads();                                 // the previous stage's operand reads are done (first pass: the tables are written)
       if (!diag_nostage) commit();
+      if constexpr (WS) wcommit(0);
       __syncthreads();
       if (!diag_nostage) {
         if constexpr (st + 1 < NSET) prefetch(x + b * a.x_bstride, st + 1);
         else { locate(zn, yn, xn); prefetch(x + bn * a.x_bstride, 0); }
       }
+      if constexpr (WS) wfetch((st + 1) % NSET);
       __builtin_amdgcn_sched_barrier(0);               // the loads stay ahead of the MFMA block
       if (!diag_nomfma)
 #pragma unroll
@@ -528,8 +543,9 @@ __global__ __launch_bounds__(XD_THREADS, 2) void conv3d_x3d_kernel(K3Args a, X3E
         }
 #pragma unroll
         for (int cl = 0; cl < COGS; ++cl) {
-          const x3_bf16x8 ah = __builtin_bit_cast(x3_bf16x8, lw[(((st * COGS + cl) * NSLS + sl) * 2 + 0) * 64 + lane]);
-          const x3_bf16x8 al = __builtin_bit_cast(x3_bf16x8, lw[(((st * COGS + cl) * NSLS + sl) * 2 + 1) * 64 + lane]);
+          constexpr int wr = WS ? 0 : st;           // LDS region of this stage's set
+          const x3_bf16x8 ah = __builtin_bit_cast(x3_bf16x8, lw[(((wr * COGS + cl) * NSLS + sl) * 2 + 0) * 64 + lane]);
+          const x3_bf16x8 al = __builtin_bit_cast(x3_bf16x8, lw[(((wr * COGS + cl) * NSLS + sl) * 2 + 1) * 64 + lane]);
 #pragma unroll
           for (int i = 0; i < XD_NT; ++i) acc[st][cl][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[i], acc[st][cl][i], 0, 0, 0);
           if constexpr (!BF)
@@ -582,23 +598,23 @@ bool x3d_eligible(const K3Args& a, int nset, int dtype) {
   return true;
 }
 
-template <class T, int CH8, int NSET, int TZ>
+template <class T, int CH8, int NSET, int COGS, bool WS>
 static int x3d_launch_one(K3Args a, X3Extra e, hipStream_t st) {
-  constexpr int PL = (TZ + 2) * XD_HY * XD_HX;
+  constexpr int PL = 4 * XD_HY * XD_HX;
   constexpr size_t lds = (size_t)(std::is_same<T, bf16_t>::value ? 1 : 2) * CH8 * PL * sizeof(uint4) +
-                         (size_t)NSET * 9 * CH8 * 2 * 64 * sizeof(uint4) + (size_t)2 * NSET * 16 * sizeof(float);
+                         (size_t)(WS ? 1 : NSET) * COGS * 9 * CH8 * 2 * 64 * sizeof(uint4) + (size_t)2 * NSET * COGS * 16 * sizeof(float);
   static_assert(lds <= 160 * 1024, "deep-level tile does not fit the LDS");
-  a.tiles_x = (int)ceil_div(a.W, XD_TX); a.tiles_y = (int)ceil_div(a.H, XD_TY); a.tiles_z = (int)ceil_div(a.D, TZ);
+  a.tiles_x = (int)ceil_div(a.W, XD_TX); a.tiles_y = (int)ceil_div(a.H, XD_TY); a.tiles_z = (int)ceil_div(a.D, 2);
   const int64_t nwork = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
   RAGMI_REQUIRE(nwork < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3d: too many tiles");
   e.nwork = (int)nwork;
   static LaunchState state;
-  const int slots = state.slots((const void*)conv3d_x3d_kernel<T, CH8, NSET, TZ>, XD_THREADS, lds, 160 * 1024);
+  const int slots = state.slots((const void*)conv3d_x3d_kernel<T, CH8, NSET, COGS, WS>, XD_THREADS, lds, 160 * 1024);
   if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_x3d: cannot raise the dynamic LDS limit");
-  const int ny = (a.Cout + 15) / 16;
+  const int ny = (int)ceil_div((a.Cout + 15) / 16, COGS);
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(e.nwork, slots / ny));
   if (gx >= 8) gx -= gx % 8;
-  hipLaunchKernelGGL((conv3d_x3d_kernel<T, CH8, NSET, TZ>), dim3((unsigned)gx, (unsigned)ny), dim3(XD_THREADS), lds, st, a, e);
+  hipLaunchKernelGGL((conv3d_x3d_kernel<T, CH8, NSET, COGS, WS>), dim3((unsigned)gx, (unsigned)ny), dim3(XD_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3d");
 }
 
@@ -613,11 +629,13 @@ int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st) {
     e.wf[s] = reinterpret_cast<const uint4*>(a.wp[s] + (int64_t)ngroups * a.nchunks[s] * PACK_PER_GC);
   const bool bf = dtype == RAGMI_BF16;
   const int ch8 = a.nchunks[0] / 2;
-  // (boxes of depth 4 — 32 column tiles, four per wave, the K-slice's weight fragments read once per four tiles — were measured
-  // on the 8-channel level: 62.7 us against 58.5; at 164 VGPRs only one workgroup fits a CU and its stages serialise)
-#define RAGMI_XD(CH8_, NSET_, TZ_) (bf ? x3d_launch_one<bf16_t, CH8_, NSET_, TZ_>(a, e, st) : x3d_launch_one<float, CH8_, NSET_, TZ_>(a, e, st))
-  if (ch8 == 1) return nset == 2 ? RAGMI_XD(1, 2, 2) : RAGMI_XD(1, 1, 2);
-  return nset == 2 ? RAGMI_XD(2, 2, 2) : RAGMI_XD(2, 1, 2);
+  // Measured and not shipped (same box, tools/ab_bench.sh): for 8 channels per set and two sets, TWO output blocks per workgroup
+  // sharing every operand read (a third fewer LDS bytes per MFMA) with one set's weights at a time in LDS (WS = true: re-staged
+  // from L2 with every box, so that two workgroups still fit a CU): 72.8 us against 57.5 for the level-6 launch — at the 128-VGPR
+  // cap of four waves per SIMD the kernel spills 37 registers, and the per-stage weight loads sit in front of every stage.
+#define RAGMI_XD(CH8_, NSET_, COGS_, WS_) (bf ? x3d_launch_one<bf16_t, CH8_, NSET_, COGS_, WS_>(a, e, st) : x3d_launch_one<float, CH8_, NSET_, COGS_, WS_>(a, e, st))
+  if (ch8 == 1) return nset == 2 ? RAGMI_XD(1, 2, 1, false) : RAGMI_XD(1, 1, 1, false);
+  return nset == 2 ? RAGMI_XD(2, 2, 1, false) : RAGMI_XD(2, 1, 1, false);
 #undef RAGMI_XD
 }
 
