@@ -299,8 +299,11 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
                            int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
 
 /* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) called with this
- * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the bf16 matrix cores (conv3d_x3.hip: volumes >= 2^18 voxels, W >= 32,
- * D >= 8, no residual input, <= 24 input channels), 0 when it runs on the fp32-MFMA kernel.  Always 0 for RAGMI_F32. */
+ * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the bf16 matrix cores, 0 when it runs on the fp32-MFMA kernel.  Two forms
+ * (conv3d_x3.hip), both without a residual input and with whole 4-channel input groups (Cin % 4 == 0): the z-marching form for
+ * D*H*W >= 2^18 voxels PER SAMPLE, W >= 32, D >= 8, <= 24 input channels; the deep-level form for 8 or 16 input channels per
+ * set, no fused tails, D >= 2 and D*H*W >= 2^14 voxels per sample.  B never enters: the kernel (hence the rounding) a sample gets
+ * does not depend on how a batch is split over ranks.  Always 0 for RAGMI_F32. */
 int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int nset, int has_res, int ntail, int dtype);
 
 /* ragmi_conv3d_k3_pack with two options used by the training step: transpose != 0 packs the DATA-GRADIENT conv of a forward
