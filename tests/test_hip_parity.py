@@ -265,7 +265,9 @@ def test_conv3d_k1_vs_oracle(ra, cin, cout, shape):
                                         ((1, 2, 3, 4, 5), (6, 8, 10)), ((1, 12, 16, 32, 26), (32, 64, 52)),
                                         ((1, 4, 5, 5, 5), (5, 5, 5)), ((1, 2, 64, 32, 104), (32, 16, 52)),
                                         # the tiled up-sampling kernel (every scale <= 0.5): ragged tiles, ratios above two, two batches
-                                        ((2, 3, 5, 7, 9), (13, 17, 40)), ((1, 5, 9, 6, 33), (18, 12, 67))])
+                                        ((2, 3, 5, 7, 9), (13, 17, 40)), ((1, 5, 9, 6, 33), (18, 12, 67)),
+                                        # degenerate extents (a single input plane / row) and one channel
+                                        ((1, 2, 1, 3, 4), (2, 6, 8)), ((1, 1, 4, 1, 40), (8, 2, 80))])
 def test_trilinear_vs_aten(ra, align, shape, size):
     x = torch.randn(shape, generator=gen(17))
     ref = F.interpolate(x, size, mode="trilinear", align_corners=align)
