@@ -22,6 +22,12 @@ typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int X3_TY = 8, X3_TX = 32;
 constexpr int64_t X3_MIN_VOXELS = 1 << 18;      // below this the z-marching columns do not fill the chip
 constexpr int X3_HY = X3_TY + 2, X3_HX = X3_TX + 2, X3_PL = X3_HY * X3_HX;   // one halo plane: 340 voxels
+// LDS row stride of a halo plane, in 8-byte records.  The two lane quarters of a 32-lane half read operand pairs two taps apart:
+// in the same halo row their addresses overlap (broadcast), but two of three such pairs wrap to the next row, a distance of
+// RS - 1 records — with RS = 34 that is 8 bytes mod 256: the same banks, different addresses, a 2-way conflict on every such read
+// (22 % of the LDS-active cycles of the dual launch, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  (RS - 1) * 8 = 128 mod 256
+// puts the two quarters on opposite bank halves: RS = 49.  Affordable where it leaves two workgroups per CU (<= 2 channel groups).
+constexpr int x3_row_stride(int ncg) { return ncg <= 2 ? 49 : X3_HX; }
 constexpr int X3_THREADS = 512, X3_WAVES = X3_THREADS / 64;
 // 8 waves per workgroup, two column tiles each: at <= 128 VGPRs two workgroups (4 waves per SIMD) share a CU, which hides the
 // LDS-read latency in front of every MFMA group far better than 4 waves x 4 tiles at 248 VGPRs did (557 -> 601 maps/s)
@@ -93,11 +99,12 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
+  constexpr int RS = x3_row_stride(NCG), PLS = X3_HY * RS;       // LDS row stride / plane size in records (staging still enumerates X3_PL voxels)
   static_assert(NCG % NSET == 0 && NPF <= 32, "bad instantiation");
   extern __shared__ __attribute__((aligned(16))) uint2 x3_lds[];       // hi[NCG][3][PL] | lo[NCG][3][PL] (uint2 = 4 bf16) | weights | offsets | params
   uint2* const lhi = x3_lds;
-  uint2* const llo = x3_lds + NCG * 3 * X3_PL;                                          // absent for bf16 storage
-  uint4* const lw = reinterpret_cast<uint4*>(x3_lds + (BF ? 1 : 2) * NCG * 3 * X3_PL);  // [set][slice][hi/lo][64 lanes]
+  uint2* const llo = x3_lds + NCG * 3 * PLS;                                            // absent for bf16 storage
+  uint4* const lw = reinterpret_cast<uint4*>(x3_lds + (BF ? 1 : 2) * NCG * 3 * PLS);    // [set][slice][hi/lo][64 lanes]
   // operand byte offsets, ready to use: [ring phase 0..2][slice][lane quarter kb] -> (pair 2kb, pair 2kb+1) of that slice with the ring
   // rotation already applied, so the K loop spends no VALU work on addresses (one 8-byte table read per slice instead of two
   // plus ~8 instructions of mod-3 arithmetic)
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     for (int j = 0; j < 2; ++j) {
       const int P = (q % (NSLS * 4)) * 2 + j, cgl = P / 27, tap = P % 27;
       const int slot = (ring + tap / 9) % 3;          // plane z+dz-1 sits in slot (ring + dz) % 3
-      o[j] = cgl < NCGS ? (((set * NCGS + cgl) * 3 + slot) * X3_PL + ((tap / 3) % 3) * X3_HX + tap % 3) * (int)sizeof(uint2) : 0;
+      o[j] = cgl < NCGS ? (((set * NCGS + cgl) * 3 + slot) * PLS + ((tap / 3) % 3) * RS + tap % 3) * (int)sizeof(uint2) : 0;
     }
     loff[i] = make_int2(o[0], o[1]);
   }
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       for (int c = 0; c < 4; ++c) v[c] = ((valid >> p) & 1u) ? pf[p][c] : 0.f;
       unsigned l01, l23;
       const unsigned h01 = x3_split2(v[0], v[1], l01), h23 = x3_split2(v[2], v[3], l23);
-      const int d = (cg * 3 + slot) * X3_PL + r;
+      const int d = (cg * 3 + slot) * PLS + (r / X3_HX) * RS + r % X3_HX;
       lhi[d] = make_uint2(h01, h23);
       if constexpr (!BF) llo[d] = make_uint2(l01, l23);
     }
@@ -213,15 +220,15 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // this wave's column tiles of a plane: nt = wave * X3_NT + i -> (row y = nt / 2, x half = nt % 2); X3_NT is even, so tile i
   // sits a compile-time distance behind tile 0 (an immediate offset of the LDS read)
   static_assert(X3_NT % 2 == 0, "tile deltas below assume an even number of column tiles per wave");
-  const int vb0 = ((wave * X3_NT >> 1) * X3_HX + n) * (int)sizeof(uint2);
+  const int vb0 = ((wave * X3_NT >> 1) * RS + n) * (int)sizeof(uint2);
   int vbt[X3_NT];                                      // byte base of each of this wave's column tiles (see the K loop)
 #pragma unroll
   for (int i = 0; i < X3_NT; ++i) {
-    vbt[i] = vb0 + ((i >> 1) * X3_HX + (i & 1) * 16) * (int)sizeof(uint2);
+    vbt[i] = vb0 + ((i >> 1) * RS + (i & 1) * 16) * (int)sizeof(uint2);
     asm volatile("" : "+v"(vbt[i]));
   }
   const char* const lbytes = reinterpret_cast<const char*>(x3_lds);
-  constexpr int LO_BYTES = NCG * 3 * X3_PL * (int)sizeof(uint2);
+  constexpr int LO_BYTES = NCG * 3 * PLS * (int)sizeof(uint2);
   const int g = cog * 4 + kb, ngroups = (a.Cout + 3) >> 2;
   // per-lane destinations, read ONCE: indexing the kernel-argument arrays with a lane-dependent index inside the loop is a
   // vector memory load per use, and its s_waitcnt vmcnt drains the prefetch that is supposed to fly under the MFMAs
@@ -718,7 +725,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   RAGMI_REQUIRE(nwork < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
   e.bf16 = dtype == RAGMI_BF16 ? 1 : 0;
-  const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_PL * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
+  const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_HY * x3_row_stride(ncg) * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
                      2 * 64 * sizeof(uint4) + 96 * sizeof(float);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
   const dim3 grid((unsigned)std::min<int64_t>(nwork, 1024), ncog);
