@@ -691,8 +691,11 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
 template <class T, int NCG, int NSET, bool TAILS>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
   static LaunchState state;     // per device, mutex-guarded (common.h)
-  if (!state.ensure_attr((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS>, 160 * 1024))
-    return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
+  // persistent grid = the workgroups the chip holds at once (occupancy x CUs): measured on the level-3 launches (1664 work items)
+  // with both on one box: 512 workgroups 1.219 ms per step, 1024 1.226, 768 1.296, 1536 1.250
+  const int slots = state.slots((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS>, X3_THREADS, lds, 160 * 1024);
+  if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
+  grid.x = (unsigned)std::max<int64_t>(1, std::min<int64_t>(grid.x, std::max(256, slots) / (int)grid.y));
   hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET, TAILS>), grid, dim3(X3_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3");
 }
@@ -715,8 +718,8 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   a.tiles_x = (int)ceil_div(a.W, X3_TX); a.tiles_y = (int)ceil_div(a.H, X3_TY);
   const int ncog = (a.Cout + 15) / 16;
   // depth segments: enough independent (column, segment) work items to fill several workgroups per CU, at least 8 planes each.
-  // (Measured on the level-3 volumes: 2..16 segments and grids of 512 / 1024 / all items are within +-5 %; a model that minimises
-  // rounds x (planes + 2 halo planes) picked 2 segments and was 3-5 % slower than this rule.)
+  // (Measured on the level-3 volumes, round 2, both builds on one box: 8 segments 1.214 ms per step; 4: 1.253, 5: 1.262, 6: 1.213,
+  // 7: 1.256, 10: 1.305, 13: 1.224, 16: 1.299.  A model that minimises rounds x (planes + 2 halo planes) does not predict this.)
   const int64_t cols = (int64_t)a.tiles_x * a.tiles_y * a.B;
   const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(1536, cols * ncog), ceil_div(a.D, 8)));
   e.seg_len = (int)ceil_div(a.D, nseg);
@@ -728,7 +731,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_HY * x3_row_stride(ncg) * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
                      2 * 64 * sizeof(uint4) + 96 * sizeof(float);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
-  const dim3 grid((unsigned)std::min<int64_t>(nwork, 1024), ncog);
+  const dim3 grid((unsigned)std::min<int64_t>(nwork, 1 << 20), ncog);      // x is cut to the resident slots where the kernel is known
   if (nset == 2) {
     switch (ncg) {
       case 2: return x3_launch_one<2, 2>(a, e, grid, lds, st);
