@@ -472,8 +472,8 @@ def main():
                                     f"flops / time against the bf16 dense peak ({ach / PEAK_FP32_MFMA_TFLOPS:.2f} of the fp32 matrix peak 157.3). "
                                     "Measured limits on this chip (DESIGN.md 4.6): one 16x16x32 bf16 MFMA per 8.2 ns per SIMD puts the issue "
                                     "floor of the dual level-3 launch at 51 us; PMC counters put its LDS-active cycles at ~55 % of the launch "
-                                    "and the matrix pipe at about a third: no unit is saturated, the wave's dependency chain (operand reads -> "
-                                    "MFMA triples -> next K-slice, 56 waits per plane) is what four waves per SIMD do not cover")
+                                    "and the matrix pipe at about a third: no unit is saturated; instruction issue is (per plane and wave 48 MFMAs x 16 "
+                                    "cycles + 157 VALU x 4 + 92 LDS reads + scalar work = ~1900 issue cycles, four waves per SIMD)")
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
                 log(f"  conv3d {'x3 (bf16x3) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
