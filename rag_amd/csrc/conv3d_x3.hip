@@ -317,8 +317,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         if (a.store_main && inside && g < ngroups) {
           T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)my_ych * DHW + vox;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * g + r < a.Cout) st(py + r * DHW, v[r]);
+          for (int r = 0; r < 4; ++r) st(py + r * DHW, v[r]);      // whole 4-channel output groups only (x3_eligible)
         }
         if constexpr (TAILS) {
           unsigned l01, l23;
@@ -585,8 +584,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
         if (inside && g < ngroups && !(diag_nostore && v[0] != 12345.f)) {
           T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)my_ych[cl] * DHW + ((int64_t)gz * HW + gy * a.W + gx);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * g + r < a.Cout) st(py + r * DHW, v[r]);
+          for (int r = 0; r < 4; ++r) st(py + r * DHW, v[r]);      // whole 4-channel output groups only (x3d_eligible)
         }
       }
     }
@@ -597,7 +595,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
 bool x3d_eligible(const K3Args& a, int nset, int dtype) {
   if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || a.res != nullptr || a.ntail > 0 || !a.store_main) return false;
   const int nc = a.nchunks[0];
-  if ((nc != 2 && nc != 4) || (nset == 2 && a.nchunks[1] != nc) || a.Cin != nset * nc * 4) return false;
+  if ((nc != 2 && nc != 4) || (nset == 2 && a.nchunks[1] != nc) || a.Cin != nset * nc * 4 || a.Cout % 4 != 0) return false;
   // volumes only (the depth-1 Feature-Net convolutions would idle half of every 2-deep box), and big enough that the persistent
   // grid has boxes to walk: below 2^14 voxels (128 boxes) the fp32 kernel's latency is the same and its arithmetic exact
   // (per SAMPLE, not per batch: which kernel a pair runs on must not depend on how the batch is split over ranks)
@@ -677,7 +675,7 @@ int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin
 bool x3_eligible(const K3Args& a, int nset, int dtype) {
   // the caller asks for it through the dtype argument (include/rag_amd.h): RAGMI_F32 never comes here
   if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || a.res != nullptr) return false;
-  if (a.Cin % 4 != 0) return false;              // whole 4-channel operand groups (the reference's channel counts all are)
+  if (a.Cin % 4 != 0 || a.Cout % 4 != 0) return false;   // whole 4-channel groups in and out (the reference's channel counts all are)
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
   if (nset == 2 && (a.nchunks[0] != a.nchunks[1] || a.nchunks[0] > 2)) return false;
   if (nset == 1 && ncg > 6) return false;
