@@ -114,7 +114,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog = blockIdx.y;
   const int HW = a.H * a.W;
-  const float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
+  float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
+  asm volatile("" : "+v"(act_floor));      // opaque: otherwise the compiler turns max(u, floor) back into max(u, 0) + a select per value
   const int64_t DHW = (int64_t)HW * a.D;
   for (int i = tid; i < NSL * 2 * 64; i += X3_THREADS) {
     const int set = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           float sum = 0.f;
 #pragma unroll
           for (int st = 0; st < NSET; ++st) {
-            float u = fmaf(acc[st][i][r], par[st * 16 + 4 * kb + r], par[32 + st * 16 + 4 * kb + r]);
-            sum += fmaxf(u, act_floor);                  // ReLU, or the identity (floor = NaN): one instruction either way
+            const float u = fmaxf(fmaf(acc[st][i][r], par[st * 16 + 4 * kb + r], par[32 + st * 16 + 4 * kb + r]), act_floor);   // ReLU, or the identity (floor = NaN)
+            sum = st == 0 ? u : sum + u;                 // (no `0 + u`: the compiler keeps that add for the sign of zero)
           }
           v[r] = sum;
         }
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog0 = blockIdx.y * COGS, ncog = (a.Cout + 15) >> 4;
   const int HW = a.H * a.W;
-  const float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
+  float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
+  asm volatile("" : "+v"(act_floor));      // opaque: otherwise the compiler turns max(u, floor) back into max(u, 0) + a select per value
   const int64_t DHW = (int64_t)HW * a.D;
   // weight fragments of this workgroup's output blocks: A[row = lane & 15][k = 8 kb + j] = w[co][channel 8 cg8 + j][tap (dz, dy, dx)],
   // (cg8, dx) from the lane quarter and the slice; gathered in 8-byte halves (4 channels of one tap) from the packed fragments
@@ -576,8 +578,8 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
           float sum = 0.f;
 #pragma unroll
           for (int st = 0; st < NSET; ++st) {
-            const float u = fmaf(acc[st][cl][i][r], par[(st * COGS + cl) * 16 + 4 * kb + r], par[NSET * COGS * 16 + (st * COGS + cl) * 16 + 4 * kb + r]);
-            sum += fmaxf(u, act_floor);                  // ReLU, or the identity (floor = NaN): one instruction either way
+            const float u = fmaxf(fmaf(acc[st][cl][i][r], par[(st * COGS + cl) * 16 + 4 * kb + r], par[NSET * COGS * 16 + (st * COGS + cl) * 16 + 4 * kb + r]), act_floor);
+            sum = st == 0 ? u : sum + u;                 // ReLU, or the identity (floor = NaN); no `0 + u`
           }
           v[r] = sum;
         }
