@@ -300,7 +300,7 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
 
 /* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) called with this
  * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the bf16 matrix cores, 0 when it runs on the fp32-MFMA kernel.  Two forms
- * (conv3d_x3.hip), both without a residual input and with whole 4-channel input groups (Cin % 4 == 0): the z-marching form for
+ * (conv3d_x3.hip), both without a residual input and with whole 4-channel groups in and out (Cin % 4 == 0, Cout % 4 == 0): the z-marching form for
  * D*H*W >= 2^18 voxels PER SAMPLE, W >= 32, D >= 8, <= 24 input channels; the deep-level form for 8 or 16 input channels per
  * set, no fused tails, D >= 2 and D*H*W >= 2^14 voxels per sample.  B never enters: the kernel (hence the rounding) a sample gets
  * does not depend on how a batch is split over ranks.  Always 0 for RAGMI_F32. */
