@@ -24,6 +24,15 @@ Extra objects in that line:
   strict_fp32   (fp32 runs, N=1) the same workload with every contraction on the fp32-input MFMA forms
                 (ops.set_conv_precision("fp32")): value_fp32_mfma and its EPE, so the record carries both arithmetic contracts.
   epe_bf16_vs_fp32  (bf16 runs) EPE of the bf16-storage output against the fp32 build on the same pair.
+  configs       (default fp32 B=1 run on one GPU) the OTHER BASELINE.json configurations, each a few untimed-by-the-headline graph
+                replays after the timed region, so that the driver's one line observes every configuration:
+                config2_bf16_b8 (configs[2]: B=8 bf16 storage; maps/s, EPE vs the fp32 build and vs the CPU oracle on pair 0),
+                config3_480x960_b8 (configs[3]: one GPU's shard of the 64-pair DrivingStereo batch; maps/s),
+                config4_train (configs[4]: training step, B=4 at 192x384; ms/step, pairs/s, conv_precision, roofline of its
+                dominant kernel, cpu_baseline = the oracle's forward + backward of ONE pair timed once),
+                all_skip (SURVEY 8(d)'s lower bound: the all-skip genotype at the headline size; maps/s + EPE vs the oracle).
+  library       the shared object the product path loaded (RAG_AMD_LIB can redirect it: A/B tooling), graph_nodes: node census
+                of the timed hipGraph (a graph holding memcpy / memset nodes is not replayed: DESIGN.md 4.4).
 """
 import argparse
 import json
@@ -47,12 +56,12 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_net(device, seed=0):
+def build_net(device, seed=0, genotype=None):
     """Benchmark protocol of SURVEY.md §8(d): reference init (Kaiming fan_out, done by the module
     ctor), then BN gamma~U(.5,1.5), beta~N(0,.1), running_mean~N(0,.1), running_var~U(.5,1.5)."""
     import rag_amd
     torch.manual_seed(seed)
-    net = rag_amd.MatchingNet(rag_amd.ALL_CONV_GENOTYPE, maxdisp=MAXDISP)
+    net = rag_amd.MatchingNet(genotype if genotype is not None else rag_amd.ALL_CONV_GENOTYPE, maxdisp=MAXDISP)
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for m in net.modules():
@@ -145,14 +154,25 @@ def pmc_traffic_bytes(kernel_name: str):
     return None, None
 
 
-def try_capture(fn):
+def try_capture(fn, census_out=None):
     """Capture fn() into a hipGraph; (graph, result) or (None, None) if the capture is refused.  Thread-local error mode:
     other threads of the process (RCCL's watchdog polls events) must not invalidate the capture.  A failed capture
-    leaves the bench on eager launches instead of killing the run."""
-    graph = torch.cuda.CUDAGraph()
+    leaves the bench on eager launches instead of killing the run.  The captured graph's nodes are counted
+    (rag_amd.train.graph_census): a graph holding memcpy / memset nodes is not replay-safe on this runtime when null-stream
+    copies (.cpu(), .item()) run between replays, so such a capture is dropped for eager launches too."""
+    from rag_amd.train import graph_census
+    graph = torch.cuda.CUDAGraph(keep_graph=True)
     try:
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = fn()
+        census = graph_census(graph)
+        if census_out is not None:
+            census_out.update(census)
+        if census["memcpy"] or census["memset"]:
+            log(f"bench: captured graph holds {census['memcpy']} memcpy / {census['memset']} memset node(s); eager launches instead")
+            torch.cuda.synchronize()
+            return None, None
+        graph.instantiate()
         graph.replay()
         torch.cuda.synchronize()
         return graph, out
@@ -160,6 +180,27 @@ def try_capture(fn):
         log(f"bench: hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
         torch.cuda.synchronize()
         return None, None
+
+
+def measure(step, steps, use_graph=True, warm=2):
+    """(seconds per step, output of the measured launches, 'hipGraph' | 'eager'): `warm` eager passes, capture, `steps` replays
+    bracketed by device syncs.  Used by the legs that ride along after the headline's timed region."""
+    for _ in range(max(warm, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    graph = None
+    if use_graph:
+        graph, cap = try_capture(step)
+        if graph is not None:
+            out = cap
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            out = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out, ("hipGraph" if graph is not None else "eager")
 
 
 def shard_range(n_items: int, world: int, rank: int):
@@ -246,13 +287,83 @@ def randomize_bn(net, seed):
 TRAIN_H, TRAIN_W, TRAIN_B = 192, 384, 4     # reference train crop and per-GPU batch (stereo_dataset.py:59, run_rag.sh)
 
 
-def train_bench(args, device, dist, rank, n_gpus):
+class TrainProfiler:
+    """HIP events around every 3x3x3 weight-gradient and forward / data-gradient convolution call of one eager training step
+    (the two kernel families that carry the step's MFMA work), keyed by (kind, Cin, Cout, B, D, H, W)."""
+
+    def __init__(self, ops):
+        self.ops, self.records, self.enabled = ops, [], False
+        self._wgrad, self._k3 = ops.conv3d_k3_wgrad, ops.conv3d_k3
+
+        def wgrad(x, g, cout, *a, **kw):
+            if not self.enabled:
+                return self._wgrad(x, g, cout, *a, **kw)
+            B, Cin, D, Hh, Ww = x.shape
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._wgrad(x, g, cout, *a, **kw)
+            e1.record()
+            self.records.append((("conv3d_k3_wgrad", Cin, cout, B, D, Hh, Ww), e0, e1))
+            return out
+
+        def k3(x, packed, cout, *a, **kw):
+            if not self.enabled:
+                return self._k3(x, packed, cout, *a, **kw)
+            B, Cin, D, Hh, Ww = x.shape
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._k3(x, packed, cout, *a, **kw)
+            e1.record()
+            self.records.append((("conv3d_k3 (forward / data gradient)", Cin, cout, B, D, Hh, Ww), e0, e1))
+            return out
+
+        ops.conv3d_k3_wgrad, ops.conv3d_k3 = wgrad, k3
+
+    def restore(self):
+        self.ops.conv3d_k3_wgrad, self.ops.conv3d_k3 = self._wgrad, self._k3
+
+    def dominant(self):
+        by = {}
+        for key, e0, e1 in self.records:
+            d = by.setdefault(key, [0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 1
+        if not by:
+            return None
+        key = max(by, key=lambda k: by[k][0])
+        return key, by[key][0], by[key][1], sum(v[0] for v in by.values())
+
+
+def train_cpu_baseline(seed=0):
+    """Oracle leg of the training configuration (checker code, allowed here only): forward + smooth-L1 + backward of ONE pair of
+    the same workload (Matching Net at 192x384, D=192, all-conv, train-mode BN) through the CPU oracle + PyTorch autograd, timed once."""
+    from oracle import matching_oracle as O
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    rows = O.ALL_CONV
+    sd = O.random_matching_state_dict(rows, seed=seed)
+    g = torch.Generator().manual_seed(77)
+    small = [torch.randn((1, FEA_C, 16, 32), generator=g) for _ in range(2)]
+    O.train_step(small[0], small[1], torch.rand((1, 48, 96), generator=g) * 50, sd, rows, 48)          # thread-pool warm-up
+    lf = torch.randn((1, FEA_C, TRAIN_H // 3, TRAIN_W // 3), generator=g)
+    rf = torch.randn((1, FEA_C, TRAIN_H // 3, TRAIN_W // 3), generator=g)
+    gt = torch.rand((1, TRAIN_H, TRAIN_W), generator=g) * 200
+    t0 = time.perf_counter()
+    O.train_step(lf, rf, gt, sd, rows, MAXDISP)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
+            "sample": f"ONE forward + backward of 1 pair ({TRAIN_H}x{TRAIN_W}, D={MAXDISP}, Matching Net from features, train-mode BN, "
+                      f"smooth-L1) through the CPU oracle + PyTorch autograd after a small-shape warm-up ({dt:.2f} s); the GPU step "
+                      "also runs the Feature Net, the all-reduce, clip and SGD"}
+
+
+def train_leg(device, dist, rank, n_gpus, B, steps, warmup, use_graph, precision, with_cpu=False):
     """BASELINE configs[4]: one data-parallel training step per `step` — images -> Feature Net -> cost volume ->
     Matching Net -> Disp -> masked smooth-L1 -> backward -> flat-bucket gradient all-reduce (RCCL) -> clip -> SGD,
-    forward and backward on the HIP kernels (rag_amd.autograd).  All units trainable (task 0 of the growth loop)."""
+    forward and backward on the HIP kernels (rag_amd.autograd).  All units trainable (task 0 of the growth loop).
+    Returns the JSON line (rank 0) or None."""
     import rag_amd
-    from rag_amd.train import GradBucket, GraphedTrainStep, exchange_and_update, make_optimizer, train_step
-    B = args.batch if args.batch > 1 else TRAIN_B
+    from rag_amd.train import GradBucket, GraphedTrainStep, exchange_and_update, forward_backward, make_optimizer, train_step
     torch.manual_seed(0)                                   # identical replicas
     net = rag_amd.Network(rag_amd.ALL_CONV_GENOTYPE, device, maxdisp=MAXDISP)
     randomize_bn(net, 1)
@@ -265,42 +376,63 @@ def train_bench(args, device, dist, rank, n_gpus):
     gt = (torch.rand((B, TRAIN_H, TRAIN_W), generator=g) * 200).to(device)
     losses = []
     graphed = None
-    if args.graph:
+    if use_graph:
         try:
-            graphed = GraphedTrainStep(net, opt, bucket, left, right, gt, clip=5.0, dist=dist)
+            graphed = GraphedTrainStep(net, opt, bucket, left, right, gt, clip=5.0, dist=dist, precision=precision)
         except Exception as exc:  # noqa: BLE001
             log(f"bench: hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); eager launches")
             torch.cuda.synchronize()
 
     def step():
         if graphed is not None:
-            losses.append(graphed().clone())
+            losses.append(graphed() * 1.0)                 # a kernel, not a memcpy node's cousin on the null stream
         else:
-            losses.append(train_step(net, opt, bucket, left, right, gt, clip=5.0, dist=dist))
+            losses.append(train_step(net, opt, bucket, left, right, gt, clip=5.0, dist=dist, precision=precision))
 
-    dt = timed_region(step, args.steps, args.warmup, dist, torch.cuda.synchronize, device)
+    dt = timed_region(step, steps, warmup, dist, torch.cuda.synchronize, device)
     if rank != 0:
-        return
-    # phase split on rank 0 (extra untimed steps): forward / backward / exchange+update, HIP events on the stream
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    from rag_amd.train import masked_smooth_l1
+        return None
+    # rank 0, untimed extra step, eager: phase split + per-call HIP events of the convolution families (roofline of the dominant one)
+    prof = TrainProfiler(rag_amd.ops)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    prof.enabled = True
     ev[0].record()
-    disp = net(left, right, 0, net.arch_init)
-    loss = masked_smooth_l1(disp, gt, MAXDISP)
+    forward_backward(net, bucket, left, right, gt, precision=precision)
     ev[1].record()
-    bucket.zero()
-    loss.backward()
-    ev[2].record()
+    prof.enabled = False
     exchange_and_update(opt, bucket, clip=5.0, dist=dist)
-    ev[3].record()
+    ev[2].record()
     torch.cuda.synchronize()
-    phases = {"forward_ms": round(ev[0].elapsed_time(ev[1]), 3), "backward_ms": round(ev[1].elapsed_time(ev[2]), 3),
-              "allreduce_clip_sgd_ms": round(ev[2].elapsed_time(ev[3]), 3)}
-    ms = dt / args.steps * 1e3
-    line = {
+    prof.restore()
+    phases = {"forward_backward_ms_eager": round(ev[0].elapsed_time(ev[1]), 3), "allreduce_clip_sgd_ms": round(ev[1].elapsed_time(ev[2]), 3)}
+    roofline = None
+    dom = prof.dominant()
+    ms = dt / steps * 1e3
+    if dom is not None:
+        (kind, Cin, Cout, Bk, D, Hh, Ww), secs, nlaunch, conv_secs = dom
+        vox = float(Bk) * D * Hh * Ww
+        flops, nbytes = 2.0 * 27 * Cin * Cout * vox, 4.0 * (Cin + Cout) * vox
+        x3 = kind.startswith("conv3d_k3 (") and precision == "bf16x3" and rag_amd.ops.conv3d_k3_uses_x3(Cin, Cout, Bk, D, Hh, Ww)
+        peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
+        t_hbm, t_mfma = nbytes / (PEAK_HBM_GBS * 1e9), (3.0 if x3 else 1.0) * flops / (peak * 1e12)
+        per = secs / nlaunch
+        common = {"kernel": f"{kind}, Cin={Cin} Cout={Cout} on [{Bk},{D},{Hh},{Ww}] voxels" + (" (conv3d_k3_wgrad_kernel)" if "wgrad" in kind else ""),
+                  "traffic": None, "algorithmic_bytes_per_launch": nbytes, "flops_per_launch": flops, "launches_per_step": nlaunch,
+                  "avg_launch_us": round(per * 1e6, 2),
+                  "avg_launch_us_source": "HIP events around each call in one eager step after the timed region (same kernels, same stream)",
+                  "share_of_step": round(secs / (dt / steps), 3), "conv_families_share_of_step": round(conv_secs / (dt / steps), 3),
+                  "floor_us": {"hbm": round(t_hbm * 1e6, 1), "mfma": round(t_mfma * 1e6, 1)}}
+        if t_hbm >= t_mfma:
+            roofline = {"bound": "hbm", "achieved": round(nbytes / per * 1e-9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(nbytes / per * 1e-9 / PEAK_HBM_GBS, 4), **common}
+        else:
+            roofline = {"bound": "mfma", "achieved": round(flops / per * 1e-12, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(flops / per * 1e-12 / peak, 4), **common}
+    cpu = train_cpu_baseline() if (with_cpu and n_gpus == 1) else None
+    return {
         "metric": "training stereo pairs/sec at 192x384 D=192 (fwd+bwd+grad all-reduce+SGD step)",
-        "value": round(n_gpus * B * args.steps / dt, 3), "unit": "stereo pairs/s",
-        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "value": round(n_gpus * B * steps / dt, 3), "unit": "stereo pairs/s",
+        "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[4]: training step, {B} pairs/GPU at {TRAIN_H}x{TRAIN_W}, D={MAXDISP}, all-conv genotype, "
                                "all units trainable, train-mode BN, SGD(1e-3, 0.9, wd 3e-3), clip 5",
@@ -308,12 +440,11 @@ def train_bench(args, device, dist, rank, n_gpus):
                    "grad_bucket_bytes": int(bucket.flat.numel() * 4),
                    "ranks_seen": dist.get_world_size() if dist is not None else 1,
                    "dist_backend": dist.get_backend() if dist is not None else None,
-                   "conv_precision": rag_amd.ops.get_conv_precision(),
+                   "conv_precision": precision,
                    "launch": "forward+backward as one hipGraph, exchange/clip/SGD eager" if graphed is not None else "eager"},
         "phases_rank0": phases, "loss_first_last": [round(float(losses[0]), 5), round(float(losses[-1]), 5)],
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": cpu,
     }
-    print(json.dumps(line), flush=True)
 
 
 def cpu_baseline(net, lf, rf):
@@ -336,6 +467,71 @@ def cpu_baseline(net, lf, rf):
             "sample": f"median of {runs} timed runs of 1 pair B=1 {H}x{W} D={MAXDISP} fp32 after a small-shape warm-up ({dt:.2f} s per pair)"}, ref
 
 
+def other_configs(net, lf, rf, out_f32, ref, device, use_graph, dist):
+    """The OTHER BASELINE.json configurations, measured after the headline's timed region (few replays each) so that the one line
+    the driver records observes every configuration.  `ref`: the CPU oracle's disparity of the headline pair (or None)."""
+    import rag_amd
+    from oracle import matching_oracle as O
+    res = {}
+    h, w = lf.shape[2:]
+    g = torch.Generator().manual_seed(4321)
+
+    def fwd(n_, a_, b_):
+        def step():
+            with torch.no_grad():
+                return n_(a_, b_)
+        return step
+
+    # configs[2]: B=8, bf16 activation storage / fp32 accumulate; pair 0 = the headline pair
+    lf8 = torch.cat([lf, torch.randn((7, FEA_C, h, w), generator=g).to(device)])
+    rf8 = torch.cat([rf, torch.randn((7, FEA_C, h, w), generator=g).to(device)])
+    dt, out, launch = measure(fwd(net, lf8.bfloat16(), rf8.bfloat16()), 5, use_graph)
+    res["config2_bf16_b8"] = {
+        "value": round(8 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 5, "launch": launch,
+        "workload": f"BASELINE configs[2]: 8 stereo pairs/GPU/step, {H}x{W}, D={MAXDISP}, bf16 storage / f32 accumulate, all-conv genotype",
+        "epe_bf16_vs_fp32_px": float((out[:1].double() - out_f32[:1].double()).abs().flatten(1).mean(dim=1).mean()),
+        "epe_gpu_vs_cpu_px": O.epe(out[:1].float().cpu(), ref) if ref is not None else None,
+        "epe_gate_px": 0.12, "epe_note": "seeded random weights drive |cost| to 1e4-1e5: softmin is nearly an argmin (DESIGN.md 4.2)"}
+    log(f"  configs[2] bf16 B=8: {res['config2_bf16_b8']['value']} maps/s, EPE vs fp32 build {res['config2_bf16_b8']['epe_bf16_vs_fp32_px']:.3e}")
+    del out, lf8, rf8
+    # configs[3]: one GPU's shard (B=8) of the 64-pair DrivingStereo batch at the reference's eval pad 480x960 (stereo_dataset.py:95-96)
+    h3, w3 = 480 // 3, 960 // 3
+    a3 = torch.randn((8, FEA_C, h3, w3), generator=g).to(device)
+    b3 = torch.randn((8, FEA_C, h3, w3), generator=g).to(device)
+    dt, out, launch = measure(fwd(net, a3, b3), 5, use_graph)
+    res["config3_480x960_b8"] = {
+        "value": round(8 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 5, "launch": launch,
+        "workload": f"BASELINE configs[3]: one rank's shard of the 64-pair batch: 8 stereo pairs/GPU/step, 480x960, D={MAXDISP}, f32, all-conv genotype"}
+    log(f"  configs[3] 480x960 B=8: {res['config3_480x960_b8']['value']} maps/s")
+    del out, a3, b3
+    # SURVEY 8(d): the all-skip genotype (what an untrained BasicNetwork.genotype() returns) as the lower bound, headline size
+    skip = build_net(device, genotype=rag_amd.modules.ALL_SKIP_GENOTYPE)
+    dt, out, launch = measure(fwd(skip, lf, rf), 10, use_graph)
+    epe_skip = None
+    if ref is not None:
+        sd = {k: v.detach().cpu() for k, v in skip.state_dict().items()}
+        t0 = time.perf_counter()
+        ref_skip = O.matching_net_forward(lf[:1].cpu(), rf[:1].cpu(), sd, O.ALL_SKIP, MAXDISP)
+        cpu_s = time.perf_counter() - t0
+        epe_skip = O.epe(out[:1].float().cpu(), ref_skip)
+    res["all_skip"] = {
+        "value": round(1 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 10, "launch": launch,
+        "workload": f"all-skip genotype (identity branches only in every cell), 1 stereo pair, {H}x{W}, D={MAXDISP}, f32",
+        "epe_gpu_vs_cpu_px": epe_skip, "cpu_oracle_s_per_pair": round(cpu_s, 2) if ref is not None else None}
+    log(f"  all-skip genotype: {res['all_skip']['value']} maps/s, EPE {epe_skip}")
+    del out, skip
+    torch.cuda.empty_cache()
+    # configs[4]: the training step (B=4 at 192x384), its dominant kernel's roofline and the oracle's fwd+bwd beside it
+    line = train_leg(device, dist, 0, 1, TRAIN_B, 5, 2, use_graph, "fp32", with_cpu=ref is not None)
+    res["config4_train"] = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "phases_rank0", "loss_first_last",
+                                                 "roofline", "cpu_baseline")}
+    res["config4_train"]["workload"] = line["config"]["workload"]
+    res["config4_train"]["conv_precision"] = line["config"]["conv_precision"]
+    res["config4_train"]["launch"] = line["config"]["launch"]
+    log(f"  configs[4] training step: {line['ms_per_step']} ms/step, {line['value']} pairs/s ({line['config']['conv_precision']})")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +544,9 @@ def main():
                     help="activation storage: f32 (configs[1], default) or bf16 storage / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: time the data-parallel training step instead")
+    ap.add_argument("--train-precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="arithmetic of the training step's 3x3x3 convolutions: fp32 (default, the reference's class) or bf16x3 (opt-in)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (configs object)")
     ap.add_argument("--hw", default=None, help="HxW of the stereo pairs, multiples of 12 (default 384x1248 = configs[1]; configs[3]: "
                                                "480x960 with --batch 8)")
     args = ap.parse_args()
@@ -380,7 +579,11 @@ def main():
     import rag_amd
     rag_amd.load_library()          # fail loudly if the HIP extension is missing
     if args.train:
-        train_bench(args, device, dist, rank, n_gpus)
+        line = train_leg(device, dist, rank, n_gpus, args.batch if args.batch > 1 else TRAIN_B, args.steps, args.warmup, bool(args.graph),
+                         args.train_precision, with_cpu=not args.no_cpu_baseline)
+        if line is not None:
+            line["library"] = rag_amd.lib_path()
+            print(json.dumps(line), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -403,8 +606,9 @@ def main():
     torch.cuda.synchronize()
 
     graph = None
+    graph_nodes = {}
     if args.graph:
-        graph, captured = try_capture(step)
+        graph, captured = try_capture(step, graph_nodes)
         if graph is not None:
             out = captured
 
@@ -516,6 +720,9 @@ def main():
         e2e = end_to_end(device, min(args.steps, 10), use_graph=bool(args.graph)) if (n_gpus == 1 and args.dtype == "f32") else None
         if e2e:
             log(f"  end-to-end (images -> disparity, Feature Net + Matching Net): {e2e['value']} maps/s ({e2e['ms_per_pair']} ms/pair)")
+        configs = None
+        if (n_gpus == 1 and args.dtype == "f32" and B == 1 and (H, W) == (384, 1248) and not args.no_configs):
+            configs = other_configs(net, lf, rf, out, ref if cpu is not None else None, device, bool(args.graph), dist)
         ms = dt / args.steps * 1e3
         line = {
             "metric": f"disparity maps/sec at {H}x{W} D=192 (Matching-Net forward)",
@@ -533,6 +740,7 @@ def main():
                        "ranks_seen": dist.get_world_size() if dist is not None else 1,
                        "dist_backend": dist.get_backend() if dist is not None else None},
             "roofline": roofline, "cpu_baseline": cpu, "strict_fp32": strict, "epe_bf16_vs_fp32": epe_bf16_vs_fp32, "end_to_end": e2e,
+            "configs": configs, "library": rag_amd.lib_path(), "graph_nodes": graph_nodes or None,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -244,6 +244,27 @@ def matching_net_forward(left_fea: torch.Tensor, right_fea: torch.Tensor, sd: Di
     return out
 
 
+def train_step(left_fea: torch.Tensor, right_fea: torch.Tensor, gt: torch.Tensor, sd: Dict[str, torch.Tensor],
+               genotype_rows: np.ndarray, maxdisp: int, reused=("stem3d0.",)):
+    """One training step of the Matching Net as approaches/rag.py:208-214 through this oracle + PyTorch-CPU autograd:
+    forward -> smooth-L1 on the mask 0 < gt < maxdisp -> backward.  Units whose key prefix starts with one of `reused` keep their
+    BatchNorm in eval mode (rag.py:159-200).  Returns (disp, loss, gradients by parameter name incl. left_fea / right_fea)."""
+    lf = left_fea.detach().clone().requires_grad_(True)
+    rf = right_fea.detach().clone().requires_grad_(True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k
+              and any(s in k for s in ("stem3d", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d"))}
+    sd2 = dict(sd)
+    sd2.update(params)
+    disp = matching_net_forward(lf, rf, sd2, genotype_rows, maxdisp,
+                                training=lambda prefix: not any(prefix.startswith(r) for r in reused))
+    mask = (gt < maxdisp) & (gt > 0)
+    loss = F.smooth_l1_loss(disp[mask], gt[mask], reduction="mean")
+    loss.backward()
+    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+    grads["left_fea"], grads["right_fea"] = lf.grad, rf.grad
+    return disp.detach(), loss.item(), grads
+
+
 def epe(est: torch.Tensor, ref: torch.Tensor) -> float:
     """EPE_metric with an all-true mask, src/utilstool/metrics.py:63-65: per-image mean |est-gt|, then batch mean."""
     per_image = (est.double() - ref.double()).abs().flatten(1).mean(dim=1)

@@ -71,6 +71,7 @@ class ConvBRFn(torch.autograd.Function):
         n = B * _vol(x)
         y, scale, shift, mean, invstd, training = _bn_forward_act(raw, n, gamma, beta, mod)
         ctx.mod, ctx.k, ctx.n, ctx.training = mod, k, n, training
+        ctx.prec = ops.get_conv_precision()        # the data gradient runs under the forward's arithmetic contract
         ctx.save_for_backward(x, weight, raw, scale, shift, mean, invstd)
         return y
 
@@ -86,7 +87,8 @@ class ConvBRFn(torch.autograd.Function):
         if need_x:
             dx = torch.empty_like(x)
             if k == 3:
-                ops.conv3d_k3(draw, ops.conv3d_k3_pack(w, transpose=True), cin, None, None, False, dx)
+                with ops.conv_precision(ctx.prec):
+                    ops.conv3d_k3(draw, ops.conv3d_k3_pack(w, transpose=True), cin, None, None, False, dx)
             else:
                 ops.conv3d_k1(draw, w.reshape(cout, cin), None, None, False, dx, transposed=True)   # W^T read in place
         if need_w:
@@ -212,6 +214,7 @@ class ConvBRGroupFn(torch.autograd.Function):
             saved += [scale, shift, mean, invstd]
             ctx.training.append(training)
         ctx.mods, ctx.n = mods, nvox
+        ctx.prec = ops.get_conv_precision()
         ctx.save_for_backward(*saved)
         return tuple(outs)
 
@@ -231,7 +234,8 @@ class ConvBRGroupFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            ops.conv3d_k3(draw, ops.conv3d_k3_pack(wcat, transpose=True), x.shape[1], None, None, False, dx)
+            with ops.conv_precision(ctx.prec):
+                ops.conv3d_k3(draw, ops.conv3d_k3_pack(wcat, transpose=True), x.shape[1], None, None, False, dx)
         need_w = [ctx.needs_input_grad[2 + 3 * i] for i in range(n)]
         if any(need_w):
             planar = mods[0].NDIM == 2

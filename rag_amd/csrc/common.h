@@ -86,36 +86,46 @@ struct LaunchState {
   int cached_slots[MAX_DEV][MAX_SIZES] = {};
   int ncached[MAX_DEV] = {};
 
-  // raise the dynamic-LDS limit of `fn` on the current device (once per device); false on a runtime error
-  bool ensure_attr(const void* fn, size_t max_dynamic_lds) {
+  // device slot of the cache, or -1 when the current device cannot be identified or lies past the table: such a device is never
+  // aliased onto another one's entries — its attribute is set and its occupancy queried on every call instead
+  static int device_slot() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (dev >= 0 && dev < MAX_DEV) ? dev : -1;
+  }
+  // raise the dynamic-LDS limit of `fn` on the current device (once per cached device); false on a runtime error
+  bool ensure_attr(const void* fn, size_t max_dynamic_lds) {
+    const int dev = device_slot();
     std::lock_guard<std::mutex> lock(mu);
-    if (attr_done[dev]) return true;
+    if (dev >= 0 && attr_done[dev]) return true;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dynamic_lds) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
-    attr_done[dev] = true;
+    if (dev >= 0) attr_done[dev] = true;
     return true;
   }
   // workgroups of `threads` threads and `lds` dynamic bytes resident on the whole current device (occupancy x CUs); 0 on error
   int slots(const void* fn, int threads, size_t lds, size_t max_dynamic_lds) {
     if (!ensure_attr(fn, max_dynamic_lds)) return 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    const int dev = device_slot();
     std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < ncached[dev]; ++i)
-      if (cached_lds[dev][i] == lds) return cached_slots[dev][i];
-    if (cus[dev] == 0) {
+    if (dev >= 0)
+      for (int i = 0; i < ncached[dev]; ++i)
+        if (cached_lds[dev][i] == lds) return cached_slots[dev][i];
+    int ncu = dev >= 0 ? cus[dev] : 0;
+    if (ncu == 0) {
+      int cur = 0;
       hipDeviceProp_t prop;
-      cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+      ncu = (hipGetDevice(&cur) == hipSuccess && hipGetDeviceProperties(&prop, cur) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+      if (dev >= 0) cus[dev] = ncu;
     }
     int per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     (void)hipGetLastError();
-    const int n = per_cu * cus[dev];
-    if (ncached[dev] < MAX_SIZES) { cached_lds[dev][ncached[dev]] = lds; cached_slots[dev][ncached[dev]] = n; ++ncached[dev]; }
+    const int n = per_cu * ncu;
+    if (dev >= 0 && ncached[dev] < MAX_SIZES) { cached_lds[dev][ncached[dev]] = lds; cached_slots[dev][ncached[dev]] = n; ++ncached[dev]; }
     return n;
   }
 };

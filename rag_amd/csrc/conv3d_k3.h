@@ -524,7 +524,7 @@ inline int split_groups(int ngroups) {
 }
 
 template <class T, int G, int LOG_TX, int R, int NSET, int WPS, int VCO = 0, bool FLAT = false, class TO = T>
-static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
+static int launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   constexpr int TX = 1 << LOG_TX, TY = (64 / TX) * R * (FLAT ? 4 : 1);
   constexpr size_t tile_bytes = (size_t)CK * (FLAT ? 3 : 6) * (TY + 2) * (TX + 2) * sizeof(float);
   const size_t wbytes = (size_t)G * (a.nchunks[0] + (NSET == 2 ? a.nchunks[1] : 0)) * PACK_PER_GC * sizeof(float);
@@ -550,10 +550,11 @@ static void launch_one(K3Args a, int64_t ntiles, int nsplits, hipStream_t s) {
   static LaunchState state;
   const int slots = state.slots((const void*)conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT, TO>, 256, lds,
                                 std::max<size_t>(tile_bytes + K3_MAX_WLDS_BYTES, 80 * 1024));
-  if (slots <= 0) return;   // (the launch check that follows reports the runtime error)
+  if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_k3: cannot raise the dynamic LDS limit");
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ntiles, slots / nsplits));
   if (gx >= 8) gx -= gx % 8;   // the XCD-aware schedule wants a multiple of 8 workgroups per split
   hipLaunchKernelGGL((conv3d_k3_kernel<T, G, LOG_TX, R, NSET, WPS, VCO, FLAT, TO>), dim3((unsigned)gx, (unsigned)nsplits), dim3(256), lds, s, a);
+  return RAGMI_OK;
 }
 
 // one tile configuration: sets the tile counts and launches with G = split_groups(ngroups)
@@ -567,12 +568,14 @@ static int launch_cfg(K3Args a, int ngroups, hipStream_t s) {
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
   const int G = split_groups(ngroups);
   const int nsplits = ngroups / G;
+  int rc;
   switch (G) {
-    case 1: launch_one<T, 1, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
-    case 2: launch_one<T, 2, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
-    case 3: launch_one<T, 3, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
-    default: launch_one<T, 4, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
+    case 1: rc = launch_one<T, 1, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
+    case 2: rc = launch_one<T, 2, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
+    case 3: rc = launch_one<T, 3, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
+    default: rc = launch_one<T, 4, LOG_TX, R, NSET, WPS, 0, FLAT>(a, ntiles, nsplits, s); break;
   }
+  if (rc != RAGMI_OK) return rc;
   return check_launch("conv3d_k3");
 }
 
@@ -609,7 +612,8 @@ static int launch_cfg_valu(K3Args a, hipStream_t s) {
   const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
   if (ntiles > 0x7fffffff) return fail(RAGMI_EUNSUPPORTED, "conv3d_k3: grid too large");
   // one output channel fits 128 VGPRs without spilling: four waves per SIMD hide the LDS-read chains of the VALU form better
-  launch_one<T, 1, LOG_TX, R, 1, (VCO == 1 ? 4 : 2), VCO, false, TO>(a, ntiles, 1, s);
+  const int rc = launch_one<T, 1, LOG_TX, R, 1, (VCO == 1 ? 4 : 2), VCO, false, TO>(a, ntiles, 1, s);
+  if (rc != RAGMI_OK) return rc;
   return check_launch("conv3d_k3_small");
 }
 

@@ -230,19 +230,23 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
       key = cls * 8 + tc + 3;
       // A: full-width plane for tc = 2, band plane (columns 0..wband-1) for tc = -2..1, nothing for tc = -3
       // (plane offsets are 32-bit: a batch item's workspace is < 2^31 floats, checked on the host).  An absent plane is read at
-      // the workspace base with weight 0 — unconditional loads, no branch per channel
+      // the workspace base and DISCARDED by a select (not multiplied by 0: a non-finite value there must not leak into voxels that
+      // have no A term) — unconditional loads, no branch per channel
       int oa = 0, sa = 0;
-      float fa = 0.f;
-      if (tc == 2) { oa = a.off_afull[cls] + y * a.W + x; sa = a.H * a.W; fa = 1.f; }
-      else if (tc > -3) { oa = a.off_aband[cls] + (tc + 2) * Cout * a.H * a.wband + y * a.wband + x; sa = a.H * a.wband; fa = 1.f; }
+      bool ha = false;
+      if (tc == 2) { oa = a.off_afull[cls] + y * a.W + x; sa = a.H * a.W; ha = true; }
+      else if (tc > -3) { oa = a.off_aband[cls] + (tc + 2) * Cout * a.H * a.wband + y * a.wband + x; sa = a.H * a.wband; ha = true; }
 #pragma unroll
-      for (int co = 0; co < MC; ++co) av[co] = co < Cout ? fa * ws[oa + co * sa] : 0.f;
+      for (int co = 0; co < MC; ++co) {
+        const float wa = co < Cout ? ws[oa + co * sa] : 0.f;
+        av[co] = ha ? wa : 0.f;
+      }
     }
     // B: indexed by u = x - i (>= -2 to contribute); the right-border variant lives on u in [u1_0, W-1]
     int ob = 0, sb = 0;
-    float fb = 0.f;
+    bool hb = false;
     if (t >= -2) {
-      fb = 1.f;
+      hb = true;
       if (xr) { ob = a.off_b1[cls] + y * a.wb1 + (t - a.u1_0); sb = a.H * a.wb1; }
       else { ob = a.off_b0[cls] + y * (a.W + 2) + (t + 2); sb = a.H * (a.W + 2); }
     }
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
 #pragma unroll
     for (int co = 0; co < MC; ++co) {
       if (co < Cout) {
-        float s = fmaf(fb, ws[ob + co * sb], av[co]);              // = A + B exactly (the weights are 0 or 1)
+        const float wb = ws[ob + co * sb];
+        float s = (hb ? wb : 0.f) + av[co];                        // A + B; an absent plane's (unconditional) load is discarded
         s = fmaf(s, par[co], par[CS_MAXC + co]);
         v[co] = a.relu ? fmaxf(s, 0.f) : s;
       } else {

@@ -46,10 +46,12 @@ class GradBucket:
             off += p.numel()
 
     def all_reduce_mean(self, dist=None) -> None:
-        """Sum over replicas in one collective, then divide by the world size."""
-        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        """Sum over replicas in one collective, then divide by the world size.  A one-rank group still issues the collective
+        (the identity): a single-GPU run of a distributed job exercises the same RCCL path as the 8-GPU one."""
+        if dist is not None and dist.is_initialized():
             dist.all_reduce(self.flat)
-            self.flat.div_(dist.get_world_size())
+            if dist.get_world_size() > 1:
+                self.flat.div_(dist.get_world_size())
 
     def clip_(self, max_norm: float) -> torch.Tensor:
         """torch.nn.utils.clip_grad_norm_ over the bucket (rag.py:215); returns the total norm."""
@@ -69,13 +71,21 @@ def masked_smooth_l1(disp: torch.Tensor, gt: torch.Tensor, maxdisp: int) -> torc
     return (per * mask).sum() / mask.sum()
 
 
-def forward_backward(net, bucket: GradBucket, left, right, gt, *, task_arch=None, features: bool = False):
+TRAIN_PRECISION = "fp32"     # the reference's training step is fp32 (rag.py:204-216); "bf16x3" is opt-in (~6 % of the step)
+
+
+def forward_backward(net, bucket: GradBucket, left, right, gt, *, task_arch=None, features: bool = False,
+                     precision: Optional[str] = None):
     """forward -> masked smooth-L1 -> zero the bucket -> backward (rag.py:208-214).  `features=True`: `net` is a
-    MatchingNet and left/right are Feature-Net outputs.  Returns the (detached) loss."""
-    disp = net(left, right, task_arch) if features else net(left, right, 0, task_arch if task_arch is not None else net.arch_init)
-    loss = masked_smooth_l1(disp, gt, net.maxdisp)
-    bucket.zero()
-    loss.backward()
+    MatchingNet and left/right are Feature-Net outputs.  `precision`: arithmetic of the 3x3x3 convolutions of the step (forward and
+    data gradient): "fp32" (default, TRAIN_PRECISION: every contraction on the fp32-input MFMA forms, the reference's arithmetic
+    class) or "bf16x3" (opt-in; bound in include/rag_amd.h).  Returns the (detached) loss."""
+    from . import ops
+    with ops.conv_precision(precision or TRAIN_PRECISION):
+        disp = net(left, right, task_arch) if features else net(left, right, 0, task_arch if task_arch is not None else net.arch_init)
+        loss = masked_smooth_l1(disp, gt, net.maxdisp)
+        bucket.zero()
+        loss.backward()
     return loss.detach()
 
 
@@ -137,11 +147,23 @@ def exchange_and_update(optimizer, bucket: GradBucket, *, clip: float = 5.0, dis
 
 
 def train_step(net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
-               features: bool = False):
-    """One optimisation step as in Appr.train_epoch (rag.py:204-216).  Returns the (detached) loss."""
-    loss = forward_backward(net, bucket, left, right, gt, task_arch=task_arch, features=features)
+               features: bool = False, precision: Optional[str] = None):
+    """One optimisation step as in Appr.train_epoch (rag.py:204-216); `precision` as in forward_backward (default fp32).
+    Returns the (detached) loss."""
+    loss = forward_backward(net, bucket, left, right, gt, task_arch=task_arch, features=features, precision=precision)
     exchange_and_update(optimizer, bucket, clip=clip, dist=dist)
     return loss
+
+
+def graph_census(graph: "torch.cuda.CUDAGraph") -> dict:
+    """Node counts {kernel, memcpy, memset, other} of a captured hipGraph (ragmi_graph_node_census: hipGraphGetNodes /
+    hipGraphNodeGetType).  `graph` must have been created with keep_graph=True and not yet released.  A graph that holds memcpy
+    or memset nodes is not replay-safe on this runtime when null-stream copies run between replays."""
+    import ctypes
+    from ._lib import check, load_library
+    n = [ctypes.c_int32() for _ in range(4)]
+    check(load_library().ragmi_graph_node_census(graph.raw_cuda_graph(), *[ctypes.byref(v) for v in n]), "graph_node_census")
+    return dict(zip(("kernel", "memcpy", "memset", "other"), (v.value for v in n)))
 
 
 class GraphedTrainStep:
@@ -161,10 +183,11 @@ class GraphedTrainStep:
     current stream; no private stream is involved."""
 
     def __init__(self, net, optimizer, bucket: GradBucket, left, right, gt, *, task_arch=None, clip: float = 5.0, dist=None,
-                 features: bool = False, warmup: int = 2):
+                 features: bool = False, warmup: int = 2, precision: Optional[str] = None):
         self.net, self.opt, self.bucket, self.clip, self.dist = net, optimizer, bucket, clip, dist
         self.left, self.right, self.gt = left.clone(), right.clone(), gt.clone()
-        kw = dict(task_arch=task_arch, features=features)
+        self.precision = precision or TRAIN_PRECISION
+        kw = dict(task_arch=task_arch, features=features, precision=self.precision)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                  # warm-up on a side stream: lazy state (allocator pools, occupancy
@@ -188,11 +211,7 @@ class GraphedTrainStep:
                             and m.track_running_stats for t in (m.running_mean, m.running_var, m.num_batches_tracked) if t is not None]
 
     def _census(self) -> dict:
-        import ctypes
-        from ._lib import check, load_library
-        n = [ctypes.c_int32() for _ in range(4)]
-        check(load_library().ragmi_graph_node_census(self.graph.raw_cuda_graph(), *[ctypes.byref(v) for v in n]), "graph_node_census")
-        return dict(zip(("kernel", "memcpy", "memset", "other"), (v.value for v in n)))
+        return graph_census(self.graph)
 
     def __call__(self, left=None, right=None, gt=None):
         for dst, src in ((self.left, left), (self.right, right), (self.gt, gt)):

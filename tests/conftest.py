@@ -16,7 +16,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+RCCL_CHILD = None     # (Popen, verdict path, log path) of tests/rccl_child.py, started before this process touches the GPU
+
+
+def _start_rccl_child(config, items):
+    """tests/test_rccl_one_rank.py needs a FRESH process for its 1-rank nccl group: start it now — device_count() does not
+    initialise the GPU in this process, torch.cuda.is_available() below does."""
+    global RCCL_CHILD
+    markexpr = config.getoption("markexpr", "") or ""
+    wanted = any(item.nodeid.startswith("tests/test_rccl_one_rank.py") or "test_rccl_one_rank" in item.nodeid for item in items)
+    if RCCL_CHILD is not None or not wanted or "not gpu" in markexpr or torch.cuda.device_count() < 1:
+        return
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="ragmi_rccl_")
+    out_path, log_path = os.path.join(tmp, "verdict.json"), os.path.join(tmp, "child.log")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    with open(log_path, "w") as logf:
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py"), out_path], stdout=logf,
+                                stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    RCCL_CHILD = (proc, out_path, log_path)
+
+
 def pytest_collection_modifyitems(config, items):
+    _start_rccl_child(config, items)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

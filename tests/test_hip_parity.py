@@ -84,7 +84,9 @@ def test_disp_vs_oracle(ra, B, d, h, w, maxdisp, scale):
         # costs of 1e3-1e4 carry an fp32 rounding of 1e-4..1e-3 into the exponent (the lerp's last bit: fma here, mul + add in
         # ATen), i.e. ~1e-3 relative on the weights of a near-tie between two distant minima: bounded per pixel in proportion to
         # the cost magnitude, gated on average like every end-to-end comparison
-        assert float((out.cpu() - ref).abs().max()) <= 2e-5 * scale
+        worst = float((out.cpu() - ref).abs().max())
+        print(f"disp vs oracle at |cost| ~ {scale:g}: max |err| {worst:.3e} px = {worst / scale:.2e} x scale (bound 5e-6 x scale)")
+        assert worst <= 5e-6 * scale              # measured 2.0e-6 x scale on 2 of 972 pixels at 1e4
     assert O.epe(out.cpu(), ref) < EPE_GATE
 
 
@@ -456,10 +458,10 @@ def test_matchingnet_golden(ra, name, prec):
     epe = O.epe(disp.cpu(), torch.from_numpy(g["disp"]))
     assert epe <= EPE_GATE, epe
     # random weights drive |cost| to 1e4-1e5, so softmin is almost an argmin: a few near-tie pixels may move
-    # by a fraction of a pixel under fp32 reordering; the gate is EPE, the per-pixel check is a quantile bound and a cap at three
-    # times the largest move measured (0.083 px on conv_48x96_d48)
+    # by a fraction of a pixel under fp32 reordering; the gate is EPE, the per-pixel check is a quantile bound and a cap at the
+    # largest move measured + 50 % (0.083 px on conv_48x96_d48)
     err = (disp.cpu() - torch.from_numpy(g["disp"])).abs()
-    assert float((err > 2e-3).float().mean()) < 5e-3 and float(err.max()) < 0.25, (float(err.max()), float((err > 2e-3).float().mean()))
+    assert float((err > 2e-3).float().mean()) < 5e-3 and float(err.max()) < 0.12, (float(err.max()), float((err > 2e-3).float().mean()))
 
 
 def test_matchingnet_plumbing_config_golden(ra):
@@ -523,6 +525,40 @@ def test_matchingnet_headline_config_epe(ra):
     epe = O.epe(out, ref)
     print(f"headline EPE vs CPU oracle: {epe:.3e} px; max abs {float((out - ref).abs().max()):.3e}")
     assert epe <= EPE_GATE, epe
+
+
+MIXED_UNSORTED = np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]])     # SURVEY 8 A6's probe rows
+
+
+def test_x3_margin_over_seeds_and_genotypes_at_headline_size(ra):
+    """The bf16x3 margin as a spread, not a point: B=1, 384x1248, D=192 under the default precision (RAGMI_F32X3) over weight
+    seeds {0, 1, 2} x genotypes {all-conv, all-skip, mixed unsorted rows}, plus the src_self eval shape 576x1248
+    (src_self/dataloaders/stereo_dataset.py:111-112, the provenance of BASELINE's 1248).  Every case must sit inside HALF the
+    EPE budget (5e-4 px) against the CPU oracle; the table is printed."""
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 8 else 16))
+    cases = [(name, rows, seed, (128, 416)) for name, rows in (("all-conv", O.ALL_CONV), ("all-skip", O.ALL_SKIP), ("mixed", MIXED_UNSORTED))
+             for seed in (0, 1, 2)]
+    cases.append(("all-conv", O.ALL_CONV, 0, (192, 416)))                      # 576 x 1248
+    table = []
+    with ra.ops.conv_precision("bf16x3"):
+        for name, rows, seed, (h, w) in cases:
+            sd = O.random_matching_state_dict(rows, seed=seed)
+            g = gen(1234 + seed)
+            lf, rf = torch.randn((1, 12, h, w), generator=g), torch.randn((1, 12, h, w), generator=g)
+            ref = O.matching_net_forward(lf, rf, sd, rows, 192)
+            net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=192)
+            net.load_state_dict(sd, strict=True)
+            net = net.to(DEV).eval()
+            with torch.no_grad():
+                out = net(gpu(lf), gpu(rf)).cpu()
+            del net
+            err = (out - ref).abs()
+            table.append((name, seed, 3 * h, 3 * w, O.epe(out, ref), float(err.max())))
+    print("bf16x3 EPE vs the CPU oracle at D=192 (gate here 5e-4 px, budget 1e-3):")
+    for name, seed, H_, W_, epe, worst in table:
+        print(f"  {name:9s} seed {seed}  {H_}x{W_}: EPE {epe:.3e} px, max |err| {worst:.3e} px")
+    for name, seed, H_, W_, epe, worst in table:
+        assert epe <= 5e-4, (name, seed, H_, W_, epe)
 
 
 # --------------------------------------------------------------------------- bf16 storage / fp32 accumulate (BASELINE config 3)

@@ -711,7 +711,7 @@ def _rel_err(got, ref64):
 # path against the fp64 evaluation and bound the GPU's error by a multiple of the error the reference's fp32 arithmetic makes on the
 # same inputs (floor: the tolerance of the small-shape tests): strict fp32 (RAGMI_F32) must sit in the same noise class, bf16x3
 # (RAGMI_F32X3: ~30x the per-product rounding of fp32, include/rag_amd.h) may amplify it by the stated factor.
-NOISE_FACTOR = {"fp32": 3.0, "bf16x3": 12.0}
+NOISE_FACTOR = {"fp32": 2.5, "bf16x3": 12.0}
 # Parameter gradients are sums over every voxel THROUGH the ReLU mask, and the mask is discontinuous: a pre-activation within the
 # forward error of zero flips it, which moves the sum by a whole |dy|.  With N voxels per channel, a forward error of eps relative
 # to the activation scale flips ~0.4 eps N of them (density of a unit normal at 0): at N = 2^21, fp32 (eps ~ 1e-7) flips < 1
@@ -791,7 +791,21 @@ def test_matchingnet_train_step_at_reference_crop(ra):
     d32, l32, g32 = oracle_train_step(g, sd)
     g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
     d64, l64, gr64 = oracle_train_step(g64, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
-    noise = {k: _rel_err(g32[k], gr64[k]) for k in gr64}
+    noise16 = {k: _rel_err(g32[k], gr64[k]) for k in gr64}
+    # the SAME fp32 arithmetic in another summation order (one thread instead of 16: MKL-DNN blocks its reductions per thread): how
+    # far two legitimate fp32 evaluations sit from fp64 differs per tensor by a factor of ~2 either way, which is what the strict
+    # fp32 GPU path shows against the 16-thread run (measured r02: GPU 1.05e-2 vs CPU-16 5.1e-3 on cells_3d.0.0._ops.4.conv.weight);
+    # the yardstick is therefore the larger of the two CPU evaluations
+    torch.set_num_threads(1)
+    _d1, _l1, g1 = oracle_train_step(g, sd)
+    torch.set_num_threads(16)
+    noise1 = {k: _rel_err(g1[k], gr64[k]) for k in gr64}
+    noise = {k: max(noise16[k], noise1[k]) for k in gr64}
+    kw = max(noise16, key=lambda k: noise16[k])
+    spread = sorted((max(noise16[k], 1e-9) / max(noise1[k], 1e-9) for k in gr64 if max(noise16[k], noise1[k]) > 1e-4))
+    print(f"CPU fp32 vs fp64, 16 threads: worst {noise16[kw]:.2e} ({kw}); 1 thread on the same tensor {noise1[kw]:.2e}; worst 1-thread "
+          f"{max(noise1.values()):.2e}; per-tensor ratio 16-thread / 1-thread error: min {spread[0]:.2f} median {spread[len(spread) // 2]:.2f} "
+          f"max {spread[-1]:.2f} over {len(spread)} tensors")
     epe_noise = O.epe(d32, d64)
     for prec in ("fp32", "bf16x3"):
         net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=maxdisp)
@@ -814,6 +828,10 @@ def test_matchingnet_train_step_at_reference_crop(ra):
         print(f"train step at 192x384 [{prec}]: EPE vs fp64 {epe:.3e} px (CPU fp32: {epe_noise:.3e}); loss {loss.item():.6f} vs {l64:.6f}; "
               f"worst gradient errors {top}; CPU-fp32 worst {max(noise.values()):.2e}")
         f = NOISE_FACTOR[prec]
+        ratios = {k: errs[k] / max(noise[k], 0.5 * max(noise.values()), 2e-4) for k in errs}
+        kr = max(ratios, key=lambda k: ratios[k])
+        print(f"  [{prec}] worst error / yardstick = {ratios[kr]:.2f} ({kr}: err {errs[kr]:.2e}, CPU fp32 16 thr {noise16[kr]:.2e}, 1 thr {noise1[kr]:.2e}); "
+              f"allowed {f}")
         assert epe <= max(1e-3, f * epe_noise), (prec, epe, epe_noise)
         assert abs(loss.item() - l64) <= 1e-5 * max(1.0, abs(l64))
         worst_noise = max(noise.values())

@@ -118,24 +118,11 @@ def test_conv3d_explicit_matches_aten():
 
 
 def oracle_train_step(g, sd=None):
-    """One training step of the Matching Net through the oracle + PyTorch-CPU autograd, as approaches/rag.py:208-214
+    """One training step of the Matching Net through the oracle (O.train_step) on a fixture-style dict of numpy arrays
     (stem3d0 is a 'reused' unit: BN in eval).  Returns (disp, loss, grads by parameter name incl. left_fea/right_fea)."""
     sd = split_sd(g) if sd is None else sd
-    maxdisp = int(g["maxdisp"])
-    lf = torch.from_numpy(g["left_fea"]).requires_grad_(True)
-    rf = torch.from_numpy(g["right_fea"]).requires_grad_(True)
-    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k
-              and any(s in k for s in ("stem3d", "cells_3d", "last_3_3d", "last_6_3d", "last_12_3d"))}
-    sd2 = dict(sd)
-    sd2.update(params)
-    disp = O.matching_net_forward(lf, rf, sd2, g["rows"], maxdisp, training=lambda prefix: not prefix.startswith("stem3d0."))
-    gt = torch.from_numpy(g["gt"])
-    mask = (gt < maxdisp) & (gt > 0)
-    loss = F.smooth_l1_loss(disp[mask], gt[mask], reduction="mean")
-    loss.backward()
-    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
-    grads["left_fea"], grads["right_fea"] = lf.grad, rf.grad
-    return disp.detach(), loss.item(), grads
+    return O.train_step(torch.from_numpy(g["left_fea"]), torch.from_numpy(g["right_fea"]), torch.from_numpy(g["gt"]), sd,
+                        g["rows"], int(g["maxdisp"]))
 
 
 def test_g6_train_step():

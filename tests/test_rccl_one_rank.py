@@ -1,0 +1,37 @@
+"""RCCL on hardware with the rank count a one-GPU box has: the training step's flat-bucket gradient
+all-reduce (rag_amd.train.GradBucket.all_reduce_mean, reference loop approaches/rag.py:204-216) in a 1-rank `nccl` group.
+
+The child (tests/rccl_child.py) is started by conftest.py at collection time, before this pytest process initialises the GPU, so
+it is a fresh process in every sense; this test only joins it and reads its verdict."""
+import json
+
+import pytest
+
+import conftest
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_allreduce_equals_no_dist():
+    child = conftest.RCCL_CHILD
+    assert child is not None, "conftest did not start the RCCL child (no GPU visible at collection time?)"
+    proc, out_path, log_path = child
+    try:
+        rc = proc.wait(timeout=600)
+    except Exception:
+        proc.kill()
+        raise
+    with open(log_path) as f:
+        log = f.read()
+    try:
+        with open(out_path) as f:
+            verdict = json.load(f)
+    except OSError:
+        pytest.fail(f"RCCL child wrote no verdict (exit code {rc}); its output:\n{log[-4000:]}")
+    print("RCCL child verdict:", json.dumps({k: v for k, v in verdict.items() if k != "error"}))
+    assert "error" not in verdict, verdict["error"] + "\n" + log[-2000:]
+    assert verdict["dist_backend"] == "nccl" and verdict["ranks_seen"] == 1
+    assert verdict["probe_ok"]
+    assert verdict["params_differing"] == [] and verdict["momentum_equal"]
+    assert verdict["losses_dist"] == verdict["losses_nodist"] and len(verdict["losses_dist"]) == 4
+    assert verdict["graph_nodes"]["memcpy"] == 0 and verdict["graph_nodes"]["memset"] == 0
+    assert verdict["ok"] and rc == 0
