@@ -24,14 +24,27 @@
  *                   per output (one rounding per product, fp32 accumulate);
  *      RAGMI_F32X3  fp32 storage; accepted by the 3x3x3 convolution entry points only (ragmi_conv3d_k3_fwd(_ex),
  *                   ragmi_conv3d_k3_dual_fwd(_ex)).  On shapes for which ragmi_conv3d_k3_uses_x3() answers 1 every fp32
- *                   operand a is split as a = hi + lo + r with hi = bf16(a), lo = bf16(a - hi), |lo| <= 2^-8 |a|, |r| <= 2^-16 |a|,
- *                   and a product a*b is accumulated in fp32 as hi_a*hi_b + hi_a*lo_b + lo_a*hi_b on the bf16 matrix cores (16x the
- *                   fp32 MFMA rate).  Dropped: lo_a*lo_b, r_a*b and a*r_b, each <= 2^-16 |a b|, so per output
- *                        |y_x3 - y_exact| <= 3 * 2^-16 * sum_k |w_k x_k| + fp32 accumulation error      (worst case)
- *                   i.e. <= 5e-5 * sum_k |w_k x_k| (enforced by the tests; measured 2e-6 .. 2.3e-5: N(0,1) data with a common offset
- *                   .. operands spread over 2^-20..2^20), against ~1e-7 * sum|w x| for RAGMI_F32.  The bound is relative to the sum of |products|, not to |y|: cancelling sums
- *                   (zero-mean weights over a large common offset) lose that many ABSOLUTE digits.  bf16 keeps the fp32
- *                   exponent range, so no overflow is introduced; lo halves below the fp32 subnormal range flush to zero.
+ *                   operand is scaled by a power of two and split into two FP16 halves, a * 2^s = hi + lo + r with hi = fp16(a 2^s),
+ *                   lo = fp16(a 2^s - hi), |lo| <= 2^-11 |hi|, and a product a*b is accumulated in fp32 as hi_a*hi_b + hi_a*lo_b +
+ *                   lo_a*hi_b on the fp16 matrix cores (16x the fp32 MFMA rate).  The scales are exact (powers of two) and chosen by
+ *                   the library: per output channel for the weights (largest |w| of the channel -> [2^9, 2^10]), per workgroup
+ *                   tile for the activations (largest |x| of the tile's halo planes -> at most 2^15, 2^10..2^11 when chosen; a plane
+ *                   that would overflow makes the tile restart with a larger scale — fp16's range is never exceeded).  Dropped per
+ *                   product: lo_a*lo_b and the roundings of the lo halves, each <= 2^-22 |a b|, plus — fp16 has no exponents below
+ *                   2^-24 — an ABSOLUTE 2^-25 of the scaled operand, i.e. 2^-35 of the tile's largest |x| (2^-34 of the channel's
+ *                   largest |w|).  Per output:
+ *                        |y_x3 - y_exact| <= 2^-20 * sum_k |w_k x_k| + 2^-33 * (Xmax * sum_k |w_k| + Wmax * sum_k |x_k|)
+ *                                            + fp32 accumulation error
+ *                   with Xmax the largest |x| in the workgroup's tile and Wmax the largest |w| of the output channel.  On
+ *                   activations of one magnitude class (anything a network produces) the second term vanishes and the error is
+ *                   ~1e-7 * sum |w x| (measured 9e-8 on N(0,1) data with a common offset of 1000: the class of RAGMI_F32 itself, 1.1e-7);
+ *                   it matters only when operands ~2^-25 smaller than their tile's largest carry the sum (measured 1e-3 * sum |w x|
+ *                   on operands spread element by element over 2^-20..2^20).  The bound is relative to the sum of |products|, not to
+ *                   |y|: cancelling sums lose that many ABSOLUTE digits, as in fp32.  Non-finite inputs give non-finite outputs (an
+ *                   Inf may come out as NaN).  Round 2 used bf16 halves (8 bits each, ~2^-17 per product): measured over weight
+ *                   seeds at the headline size that left the EPE against the CPU reference between 1e-5 and 1.4e-3 px; the fp16
+ *                   halves sit on the strict fp32 path's EPE for every seed (tests/test_hip_parity.py::
+ *                   test_x3_margin_over_seeds_and_genotypes_at_headline_size).
  *                   Elsewhere (small volumes, a residual input, unsupported channel counts) the call is computed exactly as
  *                   RAGMI_F32.  tests/test_hip_parity.py::test_x3_error_bound_adversarial enforces the bound.
  *      RAGMI_BF16   bf16 activation storage (BASELINE config 3), fp32 on-chip accumulation, BN and tails; the contraction may run
@@ -55,7 +68,7 @@ extern "C" {
 
 #define RAGMI_F32 0
 #define RAGMI_BF16 1 /* activations stored as bf16; fp32 on chip (LDS, MFMA, accumulate, BN); weights/BN stay fp32 */
-#define RAGMI_F32X3 2 /* fp32 storage, bf16x3 split products in the eligible 3x3x3 convolutions (see the dtype note above) */
+#define RAGMI_F32X3 2 /* fp32 storage, scaled-fp16 split products (hi*hi + hi*lo + lo*hi) in the eligible 3x3x3 convolutions (see the dtype note above) */
 
 #define RAGMI_MAX_GROUPS 16 /* output-channel groups of 4 per conv call */
 
@@ -299,7 +312,7 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
                            int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
 
 /* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) called with this
- * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the bf16 matrix cores, 0 when it runs on the fp32-MFMA kernel.  Two forms
+ * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the 16-bit matrix cores (fp16 / bf16 operands), 0 when it runs on the fp32-MFMA kernel.  Two forms
  * (conv3d_x3.hip), both without a residual input and with whole 4-channel groups in and out (Cin % 4 == 0, Cout % 4 == 0): the z-marching form for
  * D*H*W >= 2^18 voxels PER SAMPLE, W >= 32, D >= 8, <= 24 input channels; the deep-level form for 8 or 16 input channels per
  * set, no fused tails, D >= 2 and D*H*W >= 2^14 voxels per sample.  B never enters: the kernel (hence the rounding) a sample gets

@@ -4,8 +4,10 @@ rag_amd.train, approaches/rag.py:204-216) on RCCL with the rank count one GPU bo
 Started by tests/conftest.py BEFORE the pytest process touches the GPU (a fresh process: library load, communicator setup, the
 collective on the flat bucket, its ordering against FlatSGD on the launch stream, and hipGraph capture with RCCL's watchdog thread
 alive).  Runs two eager train_steps and two GraphedTrainStep replays twice — with dist=torch.distributed (backend nccl = RCCL) and
-with dist=None — from identical seeds and writes a JSON verdict: every parameter, the momentum buffer and the losses must be
-bitwise identical (an all-reduce over one rank is the identity)."""
+with dist=None — from identical seeds and writes a JSON verdict.  An all-reduce over one rank is the identity, so the two must agree
+to the step's own run-to-run noise: the soft-argmin adjoint accumulates tile contributions with float atomics (order not fixed),
+which moves parameters by ~1e-8 between two identical runs; a third run (dist=None again) measures exactly that, and
+dist-vs-no-dist must stay within 10x of it (floor 1e-6)."""
 import json
 import os
 import socket
@@ -64,12 +66,22 @@ def main(out_path):
         verdict["probe_ok"] = bool(torch.equal(probe.cpu(), torch.arange(8, dtype=torch.float32)))
         sd_d, mom_d, loss_d, census = run(True, dist)
         sd_n, mom_n, loss_n, _ = run(False, dist)
+        sd_n2, _m2, loss_n2, _ = run(False, dist)          # run-to-run determinism of the step itself, without the collective
         diff = [k for k in sd_d if not torch.equal(sd_d[k], sd_n[k])]
-        verdict.update(params_compared=len(sd_d), params_differing=diff[:8], momentum_equal=bool(torch.equal(mom_d, mom_n)),
+        diff_nn = {k: float((sd_n[k].double() - sd_n2[k].double()).abs().max()) for k in sd_n if not torch.equal(sd_n[k], sd_n2[k])}
+        dd = {k: float((sd_d[k].double() - sd_n[k].double()).abs().max()) for k in diff}
+        noise = max(diff_nn.values(), default=0.0)
+        worst = max(dd.values(), default=0.0)
+        mom_diff = float((mom_d.double() - mom_n.double()).abs().max())
+        verdict.update(run_to_run_maxdiff_nodist=noise, run_to_run_tensors_differing=len(diff_nn), dist_vs_nodist_maxdiff=worst,
+                       dist_vs_nodist_tensors_differing=len(dd), losses_nodist2=loss_n2, momentum_maxdiff=mom_diff)
+        verdict.update(params_compared=len(sd_d),
                        losses_dist=loss_d, losses_nodist=loss_n, graph_nodes=census,
                        collective="dist.all_reduce on GradBucket.flat (one flat fp32 bucket), then FlatSGD on the same stream")
-        verdict["ok"] = bool(verdict["probe_ok"] and not diff and verdict["momentum_equal"] and loss_d == loss_n
-                             and all(map(lambda v: v == v, loss_d)))
+        tol = max(10.0 * noise, 1e-6)
+        loss_close = all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(loss_d, loss_n))
+        verdict["tolerance"] = tol
+        verdict["ok"] = bool(verdict["probe_ok"] and worst <= tol and mom_diff <= 1e-5 and loss_close and all(map(lambda v: v == v, loss_d)))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001

@@ -934,11 +934,14 @@ def test_x3_precision_is_an_abi_argument(ra):
 
 
 def test_x3_error_bound_adversarial(ra):
-    """The bound include/rag_amd.h documents for RAGMI_F32X3, |y - y_exact| <= 5e-5 * sum_k |w_k x_k| per output (3 * 2^-16 from
-    the dropped terms + fp32 accumulation), against an fp64 convolution on inputs chosen to hurt: (a) activations with a large common offset (post-ReLU-like,
-    1000 + N(0,1)) under zero-sum weights — the exact result is O(1) while every product is O(100), so the error is judged against
-    sum |w x|, not |y|; (b) operands spanning 2^-20 .. 2^20 in magnitude.  The strict RAGMI_F32 path is held to 1e-6 * sum |w x| on the
-    same data."""
+    """The bound include/rag_amd.h documents for RAGMI_F32X3 (scaled fp16 halves), per output
+        |y - y_exact| <= 2^-20 * sum_k |w_k x_k|  +  2^-33 * (Xmax * sum_k |w_k| + Wrow * sum_k |x_k|)
+    (Xmax: largest |x| of the workgroup's column segment, here bounded by the tensor's; Wrow: largest |w| of the output channel)
+    against an fp64 convolution on inputs chosen to hurt: (a) activations with a large common offset (post-ReLU-like, 1000 + N(0,1))
+    under zero-sum weights — the exact result is O(1) while every product is O(100), so the error is judged against sum |w x|, not
+    |y|: the block term is negligible there and the plain relative bound 1e-6 must hold; (b) operands spanning 2^-20 .. 2^20 in
+    magnitude ELEMENT BY ELEMENT, where a block-scaled format loses the small operands next to large ones: the second term.  The strict
+    RAGMI_F32 path is held to 1e-6 * sum |w x| on the same data."""
     D, H, W, cin, cout = 16, 128, 130, 4, 12
     g1 = gen(161)
     w = torch.randn((cout, cin, 3, 3, 3), generator=g1) * 0.1
@@ -952,15 +955,25 @@ def test_x3_error_bound_adversarial(ra):
         xs, sl = x[:, :, :8].double(), slice(1, 7)
         ref = F.conv3d(xs, wt.double(), padding=1)[:, :, sl]
         mag = F.conv3d(xs.abs(), wt.double().abs(), padding=1)[:, :, sl]
+        wrow = wt.double().abs().flatten(1).max(dim=1).values.view(1, -1, 1, 1, 1)
+        sum_w = wt.double().abs().flatten(1).sum(dim=1).view(1, -1, 1, 1, 1)
+        sum_x = F.conv3d(xs.abs(), torch.ones((1, cin, 3, 3, 3), dtype=torch.float64), padding=1)[:, :, sl]
+        block = float(x.abs().max()) * sum_w + wrow * sum_x
         pk = ra.ops.conv3d_k3_pack(gpu(wt))
-        for prec, bound in (("bf16x3", 5e-5), ("fp32", 1e-6)):
+        for prec in ("bf16x3", "fp32"):
             with ra.ops.conv_precision(prec):
                 assert ra.ops.conv3d_k3_uses_x3(cin, cout, 1, D, H, W) == (prec == "bf16x3")
                 out = ra.ops.conv3d_k3(gpu(x), pk, cout, None, None, False, torch.empty((1, cout, D, H, W), device=DEV))
-            err = (out[:, :, sl].cpu().double() - ref).abs() / mag.clamp_min(1e-300)
-            worst = float(err.max())
-            print(f"x3 bound [{name}] {prec}: max |err| / sum|w x| = {worst:.3e} (bound {bound:.0e})")
-            assert worst <= bound, (name, prec, worst)
+            abs_err = (out[:, :, sl].cpu().double() - ref).abs()
+            rel = float((abs_err / mag.clamp_min(1e-300)).max())
+            if prec == "fp32" or name == "offset":
+                print(f"x3 bound [{name}] {prec}: max |err| / sum|w x| = {rel:.3e} (bound 1e-06)")
+                assert rel <= 1e-6, (name, prec, rel)
+            else:
+                bound = 2.0 ** -20 * mag + 2.0 ** -33 * block
+                worst = float((abs_err / bound).max())
+                print(f"x3 bound [{name}] {prec}: max |err| / sum|w x| = {rel:.3e}; max |err| / documented bound = {worst:.3f} (must be <= 1)")
+                assert worst <= 1.0, (name, prec, worst, rel)
 
 
 def test_x3_bf16_storage(ra):

@@ -792,20 +792,26 @@ def test_matchingnet_train_step_at_reference_crop(ra):
     g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
     d64, l64, gr64 = oracle_train_step(g64, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
     noise16 = {k: _rel_err(g32[k], gr64[k]) for k in gr64}
-    # the SAME fp32 arithmetic in another summation order (one thread instead of 16: MKL-DNN blocks its reductions per thread): how
-    # far two legitimate fp32 evaluations sit from fp64 differs per tensor by a factor of ~2 either way, which is what the strict
-    # fp32 GPU path shows against the 16-thread run (measured r02: GPU 1.05e-2 vs CPU-16 5.1e-3 on cells_3d.0.0._ops.4.conv.weight);
-    # the yardstick is therefore the larger of the two CPU evaluations
-    torch.set_num_threads(1)
-    _d1, _l1, g1 = oracle_train_step(g, sd)
-    torch.set_num_threads(16)
+    # A SECOND fp32 evaluation of the same step on the CPU in another summation order: the problem mirrored along H (features, ground
+    # truth and every convolution's kh taps flipped — the cost volume shifts along W only and both trilinear modes are symmetric, so
+    # in exact arithmetic the result is the mirror image).  Each fp32 evaluation moves a different handful of near-tie pixels of the
+    # soft-argmin and of near-zero pre-activations under the ReLU masks, so its gradient error against fp64 is one draw of a
+    # heavy-tailed variable per tensor: two legitimate fp32 evaluations differ from each other by the factors printed below, which is
+    # what the strict-fp32 GPU path shows against the unmirrored run (measured r02: GPU 1.05e-2 vs CPU 5.1e-3 on
+    # cells_3d.0.0._ops.4.conv.weight).  The yardstick is the larger of the two CPU draws per tensor.
+    gm = dict(g, left_fea=np.ascontiguousarray(g["left_fea"][:, :, ::-1]), right_fea=np.ascontiguousarray(g["right_fea"][:, :, ::-1]),
+              gt=np.ascontiguousarray(g["gt"][:, ::-1]))
+    sdm = {k: (v.flip(3).contiguous() if v.dim() == 5 else v) for k, v in sd.items()}
+    _d1, _l1, g1 = oracle_train_step(gm, sdm)
+    _d1 = _d1.flip(1)
+    g1 = {k: (v.flip(3) if v.dim() == 5 else v.flip(2) if k in ("left_fea", "right_fea") else v) for k, v in g1.items()}
     noise1 = {k: _rel_err(g1[k], gr64[k]) for k in gr64}
     noise = {k: max(noise16[k], noise1[k]) for k in gr64}
     kw = max(noise16, key=lambda k: noise16[k])
     spread = sorted((max(noise16[k], 1e-9) / max(noise1[k], 1e-9) for k in gr64 if max(noise16[k], noise1[k]) > 1e-4))
-    print(f"CPU fp32 vs fp64, 16 threads: worst {noise16[kw]:.2e} ({kw}); 1 thread on the same tensor {noise1[kw]:.2e}; worst 1-thread "
-          f"{max(noise1.values()):.2e}; per-tensor ratio 16-thread / 1-thread error: min {spread[0]:.2f} median {spread[len(spread) // 2]:.2f} "
-          f"max {spread[-1]:.2f} over {len(spread)} tensors")
+    print(f"CPU fp32 vs fp64: worst {noise16[kw]:.2e} ({kw}); H-mirrored evaluation on the same tensor {noise1[kw]:.2e}, its worst "
+          f"{max(noise1.values()):.2e}; per-tensor ratio of the two CPU evaluations' errors: min {spread[0]:.2f} median {spread[len(spread) // 2]:.2f} "
+          f"max {spread[-1]:.2f} over {len(spread)} tensors; EPE between the two CPU fp32 evaluations {O.epe(_d1, d32):.3e} px")
     epe_noise = O.epe(d32, d64)
     for prec in ("fp32", "bf16x3"):
         net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=maxdisp)
@@ -830,7 +836,7 @@ def test_matchingnet_train_step_at_reference_crop(ra):
         f = NOISE_FACTOR[prec]
         ratios = {k: errs[k] / max(noise[k], 0.5 * max(noise.values()), 2e-4) for k in errs}
         kr = max(ratios, key=lambda k: ratios[k])
-        print(f"  [{prec}] worst error / yardstick = {ratios[kr]:.2f} ({kr}: err {errs[kr]:.2e}, CPU fp32 16 thr {noise16[kr]:.2e}, 1 thr {noise1[kr]:.2e}); "
+        print(f"  [{prec}] worst error / yardstick = {ratios[kr]:.2f} ({kr}: err {errs[kr]:.2e}, CPU fp32 {noise16[kr]:.2e}, mirrored {noise1[kr]:.2e}); "
               f"allowed {f}")
         assert epe <= max(1e-3, f * epe_noise), (prec, epe, epe_noise)
         assert abs(loss.item() - l64) <= 1e-5 * max(1.0, abs(l64))

