@@ -5,7 +5,7 @@ CSRC  := rag_amd/csrc
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(SRCS:.hip=.o)
 LIB   := rag_amd/lib/librag_amd.so
-CXXFLAGS := -O3 -std=c++20 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+CXXFLAGS := -O3 -std=c++20 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(EXTRA)
 # `make clean && make DIAG=1` builds the profiling library: it honours the RAGMI_K3_DIAG_NOSTORE / RAGMI_K3_WLDS switches that
 # skip stores / the MFMA block / the staging of conv3d_k3 (profiles/README.md).  The default build contains none of them.
 ifeq ($(DIAG),1)
@@ -19,7 +19,7 @@ all: $(LIB)
 # (57 -> 47 us with it off); the cost-volume planes kernel gains from the same packing (54 us with, 60 without), so it stays on elsewhere.
 $(CSRC)/disp.o: CXXFLAGS += -fno-slp-vectorize
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv3d_k3.h include/rag_amd.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv3d_k3.h $(CSRC)/conv3d_x3_common.h include/rag_amd.h
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -1,0 +1,168 @@
+// Shared pieces of the split-operand 3x3x3 convolution kernels (conv3d_x3.hip: z-marching and deep forms; conv3d_x3p.hip: the
+// plane-stationary form): operand splits, the MFMA wrapper, operand-scale helpers, packed-fragment layout and launch extras.
+#pragma once
+#include <cstdlib>
+
+#include "conv3d_k3.h"
+
+namespace ragmi {
+
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
+
+// z-marching: a workgroup owns a (y, x) tile of 8 x 32 voxels and walks a segment of the depth axis keeping a ring of three
+// input planes (10 x 34 halo) in LDS: every input plane is fetched once per column (halo overhead 1.33x instead of 2.66x
+// for a 2-deep box tile), the next plane travels HBM -> registers while the current one is multiplied.
+constexpr int X3_TY = 8, X3_TX = 32;
+constexpr int64_t X3_MIN_VOXELS = 1 << 18;      // below this the z-marching columns do not fill the chip
+constexpr int X3_HY = X3_TY + 2, X3_HX = X3_TX + 2, X3_PL = X3_HY * X3_HX;   // one halo plane: 340 voxels
+// LDS row stride of a halo plane, in 8-byte records.  The two lane quarters of a 32-lane half read operand pairs two taps apart:
+// in the same halo row their addresses overlap (broadcast), but two of three such pairs wrap to the next row, a distance of
+// RS - 1 records — with RS = 34 that is 8 bytes mod 256: the same banks, different addresses, a 2-way conflict on every such read
+// (22 % of the LDS-active cycles of the dual launch, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  (RS - 1) * 8 = 128 mod 256
+// puts the two quarters on opposite bank halves: RS = 49.  Affordable where it leaves two workgroups per CU (<= 2 channel groups).
+constexpr int x3_row_stride(int ncg) { return ncg <= 2 ? 49 : X3_HX; }
+constexpr int X3_THREADS = 512, X3_WAVES = X3_THREADS / 64;
+// 8 waves per workgroup, two column tiles each: at <= 128 VGPRs two workgroups (4 waves per SIMD) share a CU, which hides the
+// LDS-read latency in front of every MFMA group far better than 4 waves x 4 tiles at 248 VGPRs did (557 -> 601 maps/s)
+constexpr int X3_NT = X3_TY * X3_TX / 16 / X3_WAVES;                  // 16-voxel column tiles per wave per plane (2)
+
+__device__ __forceinline__ unsigned short x3_bf16_rn(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void x3_split(float v, unsigned short& hi, unsigned short& lo) {
+  hi = x3_bf16_rn(v);
+  lo = x3_bf16_rn(v - __uint_as_float((unsigned)hi << 16));
+}
+// two values at once through the packed converter (v_cvt_pk_bf16_f32, round to nearest even): returns the packed hi pair,
+// writes the packed lo pair
+typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 x3_f16x2 __attribute__((ext_vector_type(2)));
+typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x3_split2(float v0, float v1, unsigned& lo) {
+  const x3_bf16x2 h = __builtin_convertvector(x3_f32x2{v0, v1}, x3_bf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float r0 = v0 - __uint_as_float(hb << 16), r1 = v1 - __uint_as_float(hb & 0xffff0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{r0, r1}, x3_bf16x2));
+  return hb;
+}
+// three bf16 parts (24 significant bits: exact up to the last fp32 bit) of two values: the fused tails' operand split, which keeps
+// the fp32 exponent range without a scale
+__device__ __forceinline__ unsigned x3_split3(float v0, float v1, unsigned& mid, unsigned& lo) {
+  const x3_bf16x2 h = __builtin_convertvector(x3_f32x2{v0, v1}, x3_bf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float r0 = v0 - __uint_as_float(hb << 16), r1 = v1 - __uint_as_float(hb & 0xffff0000u);
+  const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{r0, r1}, x3_bf16x2));
+  const float q0 = r0 - __uint_as_float(mb << 16), q1 = r1 - __uint_as_float(mb & 0xffff0000u);
+  mid = mb;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{q0, q1}, x3_bf16x2));
+  return hb;
+}
+// fp16 halves of two values scaled by the power of two `mul`: hi = fp16(v * mul), lo = fp16(v * mul - hi) (the difference is exact)
+__device__ __forceinline__ unsigned x3_split2h(float v0, float v1, float mul, unsigned& lo) {
+  const float s0 = v0 * mul, s1 = v1 * mul;
+  const x3_f16x2 h = __builtin_convertvector(x3_f32x2{s0, s1}, x3_f16x2);
+  const float r0 = s0 - (float)h.x, r1 = s1 - (float)h.y;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{r0, r1}, x3_f16x2));
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ unsigned short x3_f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+// one 16x16x32 product on the matrix cores: bf16 operands (bf16 activation storage) or fp16 operands (fp32 storage)
+template <bool BF>
+__device__ __forceinline__ f32x4 x3_mma(const uint4& a, const uint4& b, const f32x4& c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, a), __builtin_bit_cast(x3_bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8, a), __builtin_bit_cast(x3_f16x8, b), c, 0, 0, 0);
+}
+// largest power of two p with p * m <= target (m > 0 finite), clamped to [2^-100, 2^100]: the operand scale
+__device__ __forceinline__ float x3_pow2_scale(float m, float target) {
+  const float q = target / fmaxf(m, 1e-30f);
+  return __uint_as_float(min(max(__float_as_uint(q) & 0x7f800000u, 0x0d000000u), 0x71000000u));
+}
+constexpr float X3_F16_CAP = 60000.f;         // |x| * 2^-e must stay below fp16's 65504
+constexpr float X3_ACT_TARGET = 2048.f;       // 2^11: the largest scaled |x| when a column's scale is chosen (16x headroom)
+constexpr float X3_W_TARGET = 1024.f;         // 2^10: the largest scaled |w| of an output channel
+__device__ __forceinline__ float x3_wave_max(float m) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+
+// packed weight fragments of ONE accumulator set (a conv with Cout outputs and Cin = 4 * ncgs inputs):
+// wf[((cog * nsls + s) * 2 + hl) * 64 + lane] (uint4 = 8 halves): A[row = lane & 15][k = 8 (lane>>4) + j],
+// k -> pair P = 8 s + 2 (lane>>4) + (j>>2) = cg * 27 + tap, channel 4 cg + (j&3).  The source is indexed like the fp32
+// pack (transpose / planar options of ragmi_conv3d_k3_pack_ex).  Two sections: bf16 halves of w (bf16 activation storage),
+// then fp16 halves of w * 2^k[co] followed by the per-output-channel multipliers 2^-k[co] (fp32 storage, RAGMI_F32X3).
+__device__ __forceinline__ float x3_w_at(const float* __restrict__ w, int Cout, int Cin, int co, int ci, int tap, int transpose, int planar) {
+  if (co >= Cout || ci >= Cin) return 0.f;
+  const int taps = planar ? 9 : 27;
+  int t = planar ? tap - 9 : tap;
+  if (t < 0 || t >= taps) return 0.f;
+  if (transpose) t = taps - 1 - t;
+  return transpose ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t];
+}
+// power of two that brings the largest |w| of output channel co to [2^9, 2^10] (1 for an all-zero or absent channel)
+__device__ __forceinline__ float x3_row_mul(const float* __restrict__ w, int Cout, int Cin, int co, int transpose, int planar) {
+  if (co >= Cout) return 1.f;
+  float m = 0.f;
+  const int taps = planar ? 9 : 27;
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int t = 0; t < taps; ++t)
+      m = fmaxf(m, fabsf(transpose ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t]));
+  return m > 0.f ? x3_pow2_scale(m, X3_W_TARGET) : 1.f;
+}
+// half == 0: bf16 fragments; half == 1: scaled fp16 fragments + multipliers (wmul[cog * 16 + row] = 2^-k)
+__device__ __forceinline__ void x3_pack_one(const float* __restrict__ w, uint4* __restrict__ wf, float* __restrict__ wmul, int Cout, int Cin,
+                                            int nsls, int ncog, int transpose, int planar, int half, int idx) {
+  if (idx >= ncog * nsls * 64) return;
+  const int lane = idx & 63, s = (idx >> 6) % nsls, cog = idx / (64 * nsls);
+  const int co = cog * 16 + (lane & 15), kb = lane >> 4;
+  const float mul = half ? x3_row_mul(w, Cout, Cin, co, transpose, planar) : 1.f;
+  if (half && s == 0 && kb == 0) wmul[cog * 16 + (lane & 15)] = 1.f / mul;
+  unsigned short hi[8], lo[8];
+  for (int j = 0; j < 8; ++j) {
+    const int P = 8 * s + 2 * kb + (j >> 2), cg = P / 27, tap = P % 27, ci = 4 * cg + (j & 3);
+    const float v = x3_w_at(w, Cout, Cin, co, ci, tap, transpose, planar) * mul;
+    if (half) {
+      hi[j] = x3_f16_bits(v);
+      lo[j] = x3_f16_bits(v - (float)__builtin_bit_cast(_Float16, hi[j]));
+    } else {
+      x3_split(v, hi[j], lo[j]);
+    }
+  }
+  auto pk = [](const unsigned short* h) {
+    return make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+  };
+  wf[((int64_t)(cog * nsls + s) * 2 + 0) * 64 + lane] = pk(hi);
+  wf[((int64_t)(cog * nsls + s) * 2 + 1) * 64 + lane] = pk(lo);
+}
+
+struct X3Extra {
+  const uint4* wf[2];        // packed fragments per accumulator set (the section of the storage type: bf16 or scaled fp16)
+  const float* wmul[2];      // fp16 section: per-output-channel multiplier 2^-k that undoes the weight scale (null for bf16 storage)
+  int nseg, seg_len, nwork, bf16;   // bf16 != 0: bf16 activation storage (kernel instantiation selector)
+  unsigned xbytes;           // tools/experiments/conv3d_x3p.hip: bytes of one batch item's input channels (buffer-descriptor range)
+  unsigned long long* dbg;   // tools/experiments/conv3d_x3p.hip, RAGMI_X3P_STAMPS builds: per-phase cycle sums
+};
+// fragment words (floats) of ONE section for a conv with these channel counts
+inline int64_t x3_frag_words(int Cout, int Cin) {
+  const int ncgs = (Cin + 3) / 4, nsls = (ncgs * 27 + 7) / 8, ncog = (Cout + 15) / 16;
+  return (int64_t)ncog * nsls * 2 * 64 * 4;
+}
+// fills e.wf / e.wmul from the packed buffers of the call (after the fp32-MFMA section of each)
+inline void x3_weight_sections(X3Extra& e, const K3Args& a, int nset, int dtype) {
+  const int ngroups = (a.Cout + 3) / 4;
+  for (int s = 0; s < nset; ++s) {
+    const float* base = a.wp[s] + (int64_t)ngroups * a.nchunks[s] * PACK_PER_GC;
+    const int64_t fw = x3_frag_words(a.Cout, a.nchunks[s] * 4);
+    e.wf[s] = reinterpret_cast<const uint4*>(dtype == RAGMI_BF16 ? base : base + fw);
+    e.wmul[s] = dtype == RAGMI_BF16 ? nullptr : base + 2 * fw;
+  }
+}
+
+
+// (the plane-stationary form measured in round 3 lives in tools/experiments/conv3d_x3p.hip: declarations and the dispatch hook are
+// in its header comment)
+
+}  // namespace ragmi

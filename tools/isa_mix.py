@@ -61,7 +61,7 @@ def main() -> None:
         print(dem[:110])
         print("   lines", len(body), dict(grp), "spill moves", ops["v_readlane_b32"] + ops["v_writelane_b32"], "scratch",
               sum(v for k, v in ops.items() if k.startswith("scratch_")))
-        print("   ", ops.most_common(14))
+        print("   ", ops.most_common(int(os.environ.get("ISA_TOP", "14"))))
 
 
 if __name__ == "__main__":
