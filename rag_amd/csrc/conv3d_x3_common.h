@@ -83,10 +83,18 @@ __device__ __forceinline__ float x3_pow2_scale(float m, float target) {
 constexpr float X3_F16_CAP = 60000.f;         // |x| * 2^-e must stay below fp16's 65504
 constexpr float X3_ACT_TARGET = 2048.f;       // 2^11: the largest scaled |x| when a column's scale is chosen (16x headroom)
 constexpr float X3_W_TARGET = 1024.f;         // 2^10: the largest scaled |w| of an output channel
+// largest value over the wave's 64 lanes (values >= 0), returned in every lane: four DPP steps reduce each row of 16 lanes
+// (xor 1, xor 2, half-row mirror, row mirror), four v_readlane + scalar max join the rows — no LDS traffic and no waits
+// (__shfl_xor is six ds_bpermute round trips; in the deep-level kernel, once per 54 MFMAs, that was +10 us per launch)
 __device__ __forceinline__ float x3_wave_max(float m) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  return m;
+  int v = __float_as_int(m);                     // non-negative floats order like their bit patterns
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));    // row_half_mirror
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));    // row_mirror
+  const int r = max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                    max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+  return __int_as_float(r);
 }
 
 // packed weight fragments of ONE accumulator set (a conv with Cout outputs and Cin = 4 * ncgs inputs):
