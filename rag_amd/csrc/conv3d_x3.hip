@@ -207,11 +207,19 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
     const int work = (j & 7) * chunk + (j >> 3);
     if ((j >> 3) >= chunk || work >= e.nwork) continue;
-    int t = work;
+    // virtual item -> (sample, column, depth segment[, half]): a sample's items form `ngrp` groups (8: one per XCD at batch 1) of `grp`
+    // (column, segment) pairs; the last `nsplit` pairs of a group are TWO items, the halves of the segment (x3_launch)
+    int t = work, half = -1;
+    const int b = t / (e.ngrp * (e.grp + e.nsplit));
+    t %= e.ngrp * (e.grp + e.nsplit);
+    const int gi = t / (e.grp + e.nsplit), k = t % (e.grp + e.nsplit);
+    if (k < e.grp - e.nsplit) t = gi * e.grp + k;
+    else { t = gi * e.grp + (e.grp - e.nsplit) + ((k - (e.grp - e.nsplit)) >> 1); half = (k - (e.grp - e.nsplit)) & 1; }
     const int x0 = (t % a.tiles_x) * X3_TX; t /= a.tiles_x;
     const int y0 = (t % a.tiles_y) * X3_TY; t /= a.tiles_y;
-    const int seg = t % e.nseg, b = t / e.nseg;
-    const int zs = seg * e.seg_len, ze = min(a.D, zs + e.seg_len);
+    const int seg = t;
+    int zs = seg * e.seg_len, ze = min(a.D, zs + e.seg_len);
+    if (half >= 0) { const int mid = zs + ((ze - zs + 1) >> 1); if (half) zs = mid; else ze = mid; }
     const T* xb = x + b * a.x_bstride;
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
     locate(y0, x0);
@@ -748,8 +756,21 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(1536, cols_seg * ncog), ceil_div(a.D, 8)));
   e.seg_len = (int)ceil_div(a.D, nseg);
   e.nseg = (int)ceil_div(a.D, e.seg_len);
-  const int64_t nwork = cols * e.nseg;
-  RAGMI_REQUIRE(nwork < (1ll << 31), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
+  // Work items.  The persistent grid holds 64 workgroups per XCD (two per CU) and each XCD walks one contiguous eighth of the list, so a
+  // sample's (column, segment) pairs are dealt in 8 groups of `grp`; 208 per group at the headline shape = 3 full rounds of 64 and a
+  // fourth with 16 of 64 slots busy.  When that remainder is at most half a round its pairs are split into the two halves of their
+  // depth segment (`nsplit` per group): twice the items at half the length fill twice the slots.  The cut depends on the sample's
+  // shape only, never on the batch size (fp32 storage: the operand scale is chosen per item, so where items end enters the rounding).
+  const int64_t per_sample = (int64_t)a.tiles_x * a.tiles_y * e.nseg;
+  e.ngrp = per_sample % 8 == 0 ? 8 : 1;
+  e.grp = (int)(per_sample / e.ngrp);
+  e.nsplit = 0;
+  if (e.ngrp == 8 && e.seg_len >= 4) {
+    const int rem = e.grp % 64;
+    if (rem > 0 && rem <= 32) e.nsplit = rem;
+  }
+  const int64_t nwork = (int64_t)a.B * e.ngrp * (e.grp + e.nsplit);
+  RAGMI_REQUIRE(nwork < (1ll << 31) && per_sample < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
   e.bf16 = dtype == RAGMI_BF16 ? 1 : 0;
   const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_HY * x3_row_stride(ncg) * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +

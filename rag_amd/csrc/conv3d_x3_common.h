@@ -150,6 +150,7 @@ struct X3Extra {
   const uint4* wf[2];        // packed fragments per accumulator set (the section of the storage type: bf16 or scaled fp16)
   const float* wmul[2];      // fp16 section: per-output-channel multiplier 2^-k that undoes the weight scale (null for bf16 storage)
   int nseg, seg_len, nwork, bf16;   // bf16 != 0: bf16 activation storage (kernel instantiation selector)
+  int ngrp, grp, nsplit;     // z-marching form: groups per sample; (column, segment) pairs per group of a sample, of which the last nsplit are two half items
   unsigned xbytes;           // tools/experiments/conv3d_x3p.hip: bytes of one batch item's input channels (buffer-descriptor range)
   unsigned long long* dbg;   // tools/experiments/conv3d_x3p.hip, RAGMI_X3P_STAMPS builds: per-phase cycle sums
 };
