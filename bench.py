@@ -10,7 +10,7 @@ SURVEY.md §8(d)); pairs are independent, so ranks shard the batch with NO data-
 collective (weak scaling).  Rank 0 prints ONE JSON line on stdout.
 
 Extra objects in that line:
-  roofline      the dominant kernel of the step (largest share of the per-kernel HIP-event time; today the bf16x3
+  roofline      the dominant kernel of the step (largest share of the per-kernel HIP-event time; today the split-operand (RAGMI_F32X3)
                 convolution of the level-3 cells, conv3d_x3.hip).  `achieved` = its ALGORITHMIC bytes (input once +
                 output once) or flops per launch / its mean launch duration, priced against the LARGER
                 of its two floors (HBM 8 TB/s, or the dense MFMA peak of the form it issues).  The timed region replays ONE
@@ -645,7 +645,7 @@ def main():
             kname = (f"conv3d_x3_kernel<{groups[0]}, {nset}>" if x3 else f"conv3d_k3_kernel<{groups[0]}, {log_tx}, {rows}, {nset}, 2, 0>")
             peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
             # which roof bounds this kernel: the larger of its two floors per launch — HBM: algorithmic bytes / 8 TB/s;
-            # matrix cores: the MFMA flops it must ISSUE / dense peak (the bf16x3 form issues 3 bf16 MFMAs per fp32
+            # matrix cores: the MFMA flops it must ISSUE / dense peak (the split form issues 3 16-bit MFMAs per fp32
             # product, 2 with bf16 activation storage; row / K padding not counted)
             issue = (2.0 if args.dtype == "bf16" else 3.0) if x3 else 1.0
             t_hbm = (nbytes / nlaunch) / (PEAK_HBM_GBS * 1e9)
@@ -670,16 +670,16 @@ def main():
                 roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(ach / peak, 4), **common}
             if x3:
-                roofline["note"] = ("fp32 convolution emulated on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate). Its HBM "
-                                    "floor (input once + output once at 8 TB/s) is above its MFMA floor (3 bf16 MFMAs per product at "
+                roofline["note"] = ("fp32 convolution on the 16-bit matrix cores (scaled fp16 halves: hi*hi + hi*lo + lo*hi, fp32 accumulate). Its HBM "
+                                    "floor (input once + output once at 8 TB/s) is above its MFMA floor (3 16x16x32 MFMAs per product at "
                                     "the 2.5 PFLOP/s dense peak), so HBM is the roof it is priced against; `mfma` = ALGORITHMIC fp32 "
                                     f"flops / time against the bf16 dense peak ({ach / PEAK_FP32_MFMA_TFLOPS:.2f} of the fp32 matrix peak 157.3). "
-                                    "Measured limits on this chip (DESIGN.md 4.6): one 16x16x32 bf16 MFMA per 8.2 ns per SIMD puts the issue "
+                                    "Measured limits on this chip (DESIGN.md 4.3, NOTES.md 4.6): one 16x16x32 MFMA per 8.2 ns per SIMD puts the issue "
                                     "floor of the dual level-3 launch at 51 us; PMC counters put its LDS-active cycles at ~55 % of the launch "
                                     "and the matrix pipe at about a third: no unit is saturated; instruction issue is (per plane and wave 48 MFMAs x 16 "
                                     "cycles + 157 VALU x 4 + 92 LDS reads + scalar work = ~1900 issue cycles, four waves per SIMD)")
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
-                log(f"  conv3d {'x3 (bf16x3) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
+                log(f"  conv3d {'x3 (split operands) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
         cpu = None
         if n_gpus == 1 and not args.no_cpu_baseline:
@@ -729,8 +729,9 @@ def main():
             "value": round(n_gpus * B * args.steps / dt, 3), "unit": "disparity maps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (RAGMI_F32X3: level-3/6/12 3x3x3 convolutions with fp32 operands split into bf16 hi+lo on the bf16 matrix cores, "
-                      "fp32 accumulate; strict_fp32 holds the RAGMI_F32 number)"
+            "dtype": ("f32 (RAGMI_F32X3: level-3/6/12 3x3x3 convolutions with fp32 operands split into power-of-two-scaled FP16 hi+lo halves on "
+                      "the 16-bit matrix cores, hi*hi + hi*lo + lo*hi, fp32 accumulate: fp32-class accuracy, bound in include/rag_amd.h; "
+                      "strict_fp32 holds the RAGMI_F32 number)"
                       if (args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "bf16x3") else
                       "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate"), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if (H, W) == (480, 960) else 1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "

@@ -19,16 +19,21 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 # Arithmetic of the fp32 3x3x3 convolutions — an explicit, process-wide host setting that travels to the library as the dtype
 # argument of each call (RAGMI_F32 or RAGMI_F32X3); the library itself reads no environment variable.
-#   "bf16x3": eligible volumes run as hi/lo-split bf16 products (error bound in include/rag_amd.h; the default),
+#   "bf16x3": eligible volumes run as hi/lo-split products on the 16-bit matrix cores, hi*hi + hi*lo + lo*hi (error bound in
+#             include/rag_amd.h; the inference default).  The name is round 2's, when the halves were bf16; since round 3 they are
+#             power-of-two-scaled FP16 halves (fp32-class accuracy).  "f16x3" is accepted as an alias of the same setting;
 #   "fp32":   every contraction on the fp32-input MFMA forms (exact fmaf chains).
 # The environment variable RAGMI_X3=0 only picks the DEFAULT here, once, at import.
 _CONV_PRECISIONS = ("bf16x3", "fp32")
+_PRECISION_ALIASES = {"f16x3": "bf16x3", "split": "bf16x3"}
 _conv_precision = "fp32" if os.environ.get("RAGMI_X3", "1").strip() == "0" else "bf16x3"
 
 
 def set_conv_precision(precision: str) -> str:
-    """Select the arithmetic of fp32 3x3x3 convolutions ("bf16x3" or "fp32"); returns the previous setting."""
+    """Select the arithmetic of fp32 3x3x3 convolutions ("bf16x3" = the split form, alias "f16x3"; or "fp32"); returns the
+    previous setting."""
     global _conv_precision
+    precision = _PRECISION_ALIASES.get(precision, precision)
     if precision not in _CONV_PRECISIONS:
         raise ValueError(f"conv precision must be one of {_CONV_PRECISIONS}, got {precision!r}")
     old, _conv_precision = _conv_precision, precision
@@ -673,7 +678,7 @@ def disparity_regression_bwd(dout: torch.Tensor, maxdisp: int) -> torch.Tensor:
 
 def conv3d_k3_uses_x3(cin: int, cout: int, B: int, D: int, H: int, W: int, nset: int = 1, has_res: bool = False, ntail: int = 0,
                       dtype: torch.dtype = torch.float32) -> bool:
-    """True when conv3d_k3 (nset=1) / conv3d_k3_dual (nset=2, cin = both inputs) runs this shape on the bf16x3 kernel under the
+    """True when conv3d_k3 (nset=1) / conv3d_k3_dual (nset=2, cin = both inputs) runs this shape on a split-operand (16-bit matrix core) kernel under the
     current precision setting."""
     return bool(load_library().ragmi_conv3d_k3_uses_x3(cin, cout, B, D, H, W, nset, int(has_res), ntail, _conv_dt(_DT[dtype])))
 
