@@ -324,6 +324,12 @@ int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int n
  * [.,.,3,3] weight living in the dz = 1 plane (Feature Net on depth-1 volumes). */
 int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int dtype, void* stream);
 
+/* ragmi_conv3d_k3_pack_ex for a weight that will be used under ONE known arithmetic contract (the training step packs ~150 weights
+ * per step, each for the call that follows): for_dtype == RAGMI_F32 fills only the fp32-MFMA section of `packed` (same buffer size);
+ * such a buffer must be passed to the convolution entry points with dtype RAGMI_F32 only.  Any other for_dtype fills every section,
+ * like ragmi_conv3d_k3_pack_ex. */
+int ragmi_conv3d_k3_pack_for(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int for_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Training step (BASELINE config 5; the reference runs autograd through the same modules, approaches/rag.py:155-219).
  * fp32 only.  Data-gradients of the convolutions are the forward kernels applied to the output gradient with the

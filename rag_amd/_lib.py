@@ -79,6 +79,7 @@ SIGNATURES = {
     "ragmi_bn_train_stats_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ragmi_conv3d_k3_pack_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k3_pack_for": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_sgd_workspace_bytes": (c_int64, []),
     "ragmi_sgd_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
                                     c_void_p]),

@@ -65,7 +65,7 @@ class ConvBRFn(torch.autograd.Function):
         w = weight.detach()
         raw = torch.empty((B, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
         if k == 3:
-            ops.conv3d_k3(x, ops.conv3d_k3_pack(w), cout, None, None, False, raw)
+            ops.conv3d_k3(x, ops.conv3d_k3_pack(w, for_current_precision=True), cout, None, None, False, raw)
         else:
             ops.conv3d_k1(x, w.reshape(cout, -1), None, None, False, raw)
         n = B * _vol(x)
@@ -88,7 +88,7 @@ class ConvBRFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             if k == 3:
                 with ops.conv_precision(ctx.prec):
-                    ops.conv3d_k3(draw, ops.conv3d_k3_pack(w, transpose=True), cin, None, None, False, dx)
+                    ops.conv3d_k3(draw, ops.conv3d_k3_pack(w, transpose=True, for_current_precision=True), cin, None, None, False, dx)
             else:
                 ops.conv3d_k1(draw, w.reshape(cout, cin), None, None, False, dx, transposed=True)   # W^T read in place
         if need_w:
@@ -202,7 +202,7 @@ class ConvBRGroupFn(torch.autograd.Function):
         w0 = params[0]
         wcat = torch.cat([params[3 * i].detach().reshape(C, -1) for i in range(n)]).view((n * C,) + tuple(w0.shape[1:]))
         raw = torch.empty((B, n * C) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
-        ops.conv3d_k3(x, ops.conv3d_k3_pack(wcat), n * C, None, None, False, raw)
+        ops.conv3d_k3(x, ops.conv3d_k3_pack(wcat, for_current_precision=True), n * C, None, None, False, raw)
         nvox = B * _vol(x)
         outs, saved = [], [x, wcat, raw]
         ctx.training = []
@@ -235,7 +235,7 @@ class ConvBRGroupFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             with ops.conv_precision(ctx.prec):
-                ops.conv3d_k3(draw, ops.conv3d_k3_pack(wcat, transpose=True), x.shape[1], None, None, False, dx)
+                ops.conv3d_k3(draw, ops.conv3d_k3_pack(wcat, transpose=True, for_current_precision=True), x.shape[1], None, None, False, dx)
         need_w = [ctx.needs_input_grad[2 + 3 * i] for i in range(n)]
         if any(need_w):
             planar = mods[0].NDIM == 2

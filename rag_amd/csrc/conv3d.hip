@@ -91,15 +91,26 @@ extern "C" int ragmi_conv3d_k3_pack(const void* weight, void* packed, int Cout, 
   return ragmi_conv3d_k3_pack_ex(weight, packed, Cout, Cin, 0, 0, dtype, stream);
 }
 
-extern "C" int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int dtype,
-                                       void* stream) {
+static int pack_sections(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, bool all, void* stream) {
   using namespace ragmi;
   RAGMI_REQUIRE(weight && packed, RAGMI_EINVAL, "conv3d_k3_pack: null pointer");
   RAGMI_REQUIRE(Cout > 0 && Cin > 0, RAGMI_EINVAL, "conv3d_k3_pack: non-positive size");
-  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3_pack: dtype %d not built", dtype);
+  RAGMI_REQUIRE(Cout <= 4 * RAGMI_MAX_GROUPS, RAGMI_EUNSUPPORTED, "conv3d_k3_pack: Cout %d > %d", Cout, 4 * RAGMI_MAX_GROUPS);
   const int64_t total = k3_section_elems(Cout, Cin);
-  pack_both((const float*)weight, (float*)packed, total, Cout, Cin, transpose ? 1 : 0, planar2d ? 1 : 0, static_cast<hipStream_t>(stream));
+  pack_both((const float*)weight, (float*)packed, total, Cout, Cin, transpose ? 1 : 0, planar2d ? 1 : 0, all, static_cast<hipStream_t>(stream));
   return check_launch("conv3d_k3_pack");
+}
+
+extern "C" int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int dtype,
+                                       void* stream) {
+  RAGMI_REQUIRE(dtype == RAGMI_F32, RAGMI_EUNSUPPORTED, "conv3d_k3_pack: dtype %d not built", dtype);
+  return pack_sections(weight, packed, Cout, Cin, transpose, planar2d, true, stream);
+}
+
+extern "C" int ragmi_conv3d_k3_pack_for(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int for_dtype,
+                                        void* stream) {
+  RAGMI_REQUIRE(ragmi::conv_dtype_ok(for_dtype), RAGMI_EUNSUPPORTED, "conv3d_k3_pack_for: dtype %d not built", for_dtype);
+  return pack_sections(weight, packed, Cout, Cin, transpose, planar2d, for_dtype != RAGMI_F32, stream);
 }
 
 extern "C" int ragmi_conv3d_k3_fwd(const void* x, int64_t x_bstride, const void* packed_weight, const void* scale,

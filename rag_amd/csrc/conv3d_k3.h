@@ -593,7 +593,8 @@ RAGMI_K3_DECL(s2_cfg2);
 // bf16x3 form (conv3d_x3.hip): fp32 accuracy on the bf16 matrix cores, used for the big level-3 volumes
 int64_t x3_packed_words(int Cout, int Cin);
 // both sections of the packed weights (fp32-MFMA section of `total_k3` floats, then the bf16x3 fragments) in ONE launch
-int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, hipStream_t s);
+// (`all` = false: the fp32-MFMA section only)
+int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, bool all, hipStream_t s);
 bool x3_eligible(const K3Args& a, int nset, int dtype);
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
 // deep-level bf16x3 form (8 / 16 input channels per set, box tiles): levels 6 and 12

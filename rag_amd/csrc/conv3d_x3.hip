@@ -689,16 +689,18 @@ __global__ void pack_both_kernel(const float* __restrict__ w, float* __restrict_
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx < total_k3) packed[idx] = k3_pack_value(w, Cout, Cin, nchunks, idx, transpose, planar);
   } else {
-    const int half = ((int)blockIdx.x - nb_k3) >= nb_x3 ? 1 : 0;
+    const int half = ((int)blockIdx.x - nb_k3) >= nb_x3 ? 1 : 0;      // block-uniform
+    __shared__ unsigned rowmax[64];
+    if (half) x3_row_max(w, rowmax, Cout, Cin, transpose, planar, (int)threadIdx.x, 256);
     const int64_t fw = (int64_t)ncog * nsls * 2 * 64 * 4;
-    x3_pack_one(w, reinterpret_cast<uint4*>(packed + total_k3 + half * fw), packed + total_k3 + 2 * fw, Cout, Cin, nsls, ncog, transpose, planar,
+    x3_pack_one(w, reinterpret_cast<uint4*>(packed + total_k3 + half * fw), packed + total_k3 + 2 * fw, rowmax, Cout, Cin, nsls, ncog, transpose, planar,
                 half, ((int)blockIdx.x - nb_k3 - half * nb_x3) * 256 + threadIdx.x);
   }
 }
-int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, hipStream_t s) {
+int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, bool all, hipStream_t s) {
   const int ncgs = (Cin + 3) / 4, nsls = (ncgs * 27 + 7) / 8, ncog = (Cout + 15) / 16;
   const int nb_k3 = (int)ceil_div(total_k3, 256), nb_x3 = (int)ceil_div((int64_t)ncog * nsls * 64, 256);
-  hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)(nb_k3 + 2 * nb_x3)), dim3(256), 0, s, w, packed, total_k3, nb_k3, nb_x3, Cout, Cin,
+  hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)(nb_k3 + (all ? 2 * nb_x3 : 0))), dim3(256), 0, s, w, packed, total_k3, nb_k3, nb_x3, Cout, Cin,
                      (Cin + CK - 1) / CK, nsls, ncog, transpose, planar);
   return RAGMI_OK;
 }

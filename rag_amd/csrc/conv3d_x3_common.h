@@ -110,23 +110,32 @@ __device__ __forceinline__ float x3_w_at(const float* __restrict__ w, int Cout, 
   if (transpose) t = taps - 1 - t;
   return transpose ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t];
 }
-// power of two that brings the largest |w| of output channel co to [2^9, 2^10] (1 for an all-zero or absent channel)
-__device__ __forceinline__ float x3_row_mul(const float* __restrict__ w, int Cout, int Cin, int co, int transpose, int planar) {
-  if (co >= Cout) return 1.f;
-  float m = 0.f;
-  const int taps = planar ? 9 : 27;
-  for (int ci = 0; ci < Cin; ++ci)
-    for (int t = 0; t < taps; ++t)
-      m = fmaxf(m, fabsf(transpose ? w[((int64_t)ci * Cout + co) * taps + t] : w[((int64_t)co * Cin + ci) * taps + t]));
+// power of two that brings the largest |w| of an output channel (given as the bit pattern of that maximum) to [2^9, 2^10]
+// (1 for an all-zero or absent channel)
+__device__ __forceinline__ float x3_row_mul(unsigned maxbits) {
+  const float m = __uint_as_float(maxbits);
   return m > 0.f ? x3_pow2_scale(m, X3_W_TARGET) : 1.f;
 }
+// largest |w| of every output channel, as float bit patterns in rowmax[Cout <= 64] (LDS): the workgroup's threads stride the
+// weight tensor once (a scan per thread cost ~10 us per pack, 150 packs per training step)
+__device__ __forceinline__ void x3_row_max(const float* __restrict__ w, unsigned* rowmax, int Cout, int Cin, int transpose, int planar,
+                                           int tid, int nthreads) {
+  for (int i = tid; i < 64; i += nthreads) rowmax[i] = 0u;
+  __syncthreads();
+  const int taps = planar ? 9 : 27, n = Cout * Cin * taps;
+  for (int i = tid; i < n; i += nthreads) {
+    const int co = transpose ? (i / taps) % Cout : i / (Cin * taps);
+    atomicMax(&rowmax[co], __float_as_uint(fabsf(w[i])));
+  }
+  __syncthreads();
+}
 // half == 0: bf16 fragments; half == 1: scaled fp16 fragments + multipliers (wmul[cog * 16 + row] = 2^-k)
-__device__ __forceinline__ void x3_pack_one(const float* __restrict__ w, uint4* __restrict__ wf, float* __restrict__ wmul, int Cout, int Cin,
-                                            int nsls, int ncog, int transpose, int planar, int half, int idx) {
+__device__ __forceinline__ void x3_pack_one(const float* __restrict__ w, uint4* __restrict__ wf, float* __restrict__ wmul, const unsigned* rowmax,
+                                            int Cout, int Cin, int nsls, int ncog, int transpose, int planar, int half, int idx) {
   if (idx >= ncog * nsls * 64) return;
   const int lane = idx & 63, s = (idx >> 6) % nsls, cog = idx / (64 * nsls);
   const int co = cog * 16 + (lane & 15), kb = lane >> 4;
-  const float mul = half ? x3_row_mul(w, Cout, Cin, co, transpose, planar) : 1.f;
+  const float mul = (half && co < Cout) ? x3_row_mul(rowmax[co]) : 1.f;
   if (half && s == 0 && kb == 0) wmul[cog * 16 + (lane & 15)] = 1.f / mul;
   unsigned short hi[8], lo[8];
   for (int j = 0; j < 8; ++j) {

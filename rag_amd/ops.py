@@ -190,10 +190,12 @@ def costvol_stem(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, 
     return out
 
 
-def conv3d_k3_pack(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+def conv3d_k3_pack(weight: torch.Tensor, transpose: bool = False, for_current_precision: bool = False) -> torch.Tensor:
     """Pre-pack an nn.Conv3d weight [Cout, Cin, 3, 3, 3] (or an nn.Conv2d weight [Cout, Cin, 3, 3], run as the dz = 1 plane of
     a 3x3x3 on depth-1 volumes) for conv3d_k3.  transpose=True packs the conv that computes the DATA GRADIENT of this weight's
-    conv (channels swapped, taps flipped): conv3d_k3(dy, packed, cout=Cin, ...) is then dL/dx."""
+    conv (channels swapped, taps flipped): conv3d_k3(dy, packed, cout=Cin, ...) is then dL/dx.  for_current_precision=True
+    (the training step: a pack per call) fills only the sections the CURRENT conv precision reads — under "fp32" the split-operand
+    fragments are skipped (ragmi_conv3d_k3_pack_for); such a pack must be consumed under the same precision."""
     _need_gpu(weight)
     planar = weight.dim() == 4
     if tuple(weight.shape[2:]) != ((3, 3) if planar else (3, 3, 3)):
@@ -203,8 +205,12 @@ def conv3d_k3_pack(weight: torch.Tensor, transpose: bool = False) -> torch.Tenso
     n = lib.ragmi_conv3d_k3_packed_elems(Cout, Cin)
     packed = torch.empty((n,), device=weight.device, dtype=torch.float32)
     w = weight.detach().contiguous()
-    check(lib.ragmi_conv3d_k3_pack_ex(w.data_ptr(), packed.data_ptr(), Cout, Cin, int(transpose), int(planar), F32, _stream()),
-          "conv3d_k3_pack")
+    if for_current_precision:
+        check(lib.ragmi_conv3d_k3_pack_for(w.data_ptr(), packed.data_ptr(), Cout, Cin, int(transpose), int(planar), _conv_dt(F32), _stream()),
+              "conv3d_k3_pack_for")
+    else:
+        check(lib.ragmi_conv3d_k3_pack_ex(w.data_ptr(), packed.data_ptr(), Cout, Cin, int(transpose), int(planar), F32, _stream()),
+              "conv3d_k3_pack")
     return packed
 
 

@@ -13,14 +13,14 @@ cd "$root" || exit 1
 python bench.py > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.stderr.txt" || exit 1
 echo "[collect] bench done"; cat "$out/${tag}_bench.json"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_kt" -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_kt" -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-configs > /dev/null 2>&1 || exit 1
 find "$out/${tag}_kt" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_bench_kernel_stats.csv" \;
 python3 "$root/tools/step_timeline.py" "$out/${tag}_kt" > "$out/${tag}_step_timeline.txt"
 rm -rf "$out/${tag}_kt"
 echo "[collect] kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_f" -- python3 "$root/bench.py" --graph 0 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_f" -- python3 "$root/bench.py" --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2>&1 || exit 1
 echo "[collect] FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_w" -- python3 "$root/bench.py" --graph 0 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_w" -- python3 "$root/bench.py" --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2>&1 || exit 1
 echo "[collect] WRITE_SIZE pass done"
 python3 "$root/tools/pmc_summary.py" "$out/${tag}_pmc_summary.json" "$out/${tag}_bench_kernel_stats.csv" "$out/${tag}_pmc_f" "$out/${tag}_pmc_w" > "$out/${tag}_pmc_summary.txt"
 rm -rf "$out/${tag}_pmc_f" "$out/${tag}_pmc_w"
