@@ -976,6 +976,45 @@ def test_x3_error_bound_adversarial(ra):
                 assert worst <= 1.0, (name, prec, worst, rel)
 
 
+def test_x3_scale_restart_on_growing_planes(ra):
+    """The fp16 operand scale of a column segment is chosen from its first plane; a later plane that does not fit makes the
+    workgroup restart its ring with a larger scale (conv3d_x3.hip).  Planes that start at exactly zero (the scale clamp), grow by
+    1e3 and again by 1e4 inside a segment, and shrink again force that path several times per column; the result must stay inside
+    the documented bound against an fp64 convolution, for the single and the dual (two-set) launch."""
+    D, H, W, cin, cout = 16, 128, 130, 4, 12
+    g1 = gen(171)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g1) * 0.1
+    w2 = torch.randn((cout, cin, 3, 3, 3), generator=g1) * 0.1
+    zscale = torch.tensor([0, 0, 0, 1, 1e3, 1e3, 1e7, 1e3, 1e-3, 1, 1e4, 1e4, 1e4, 1e-2, 3e4, 0], dtype=torch.float32).view(1, 1, D, 1, 1)
+    x = torch.randn((1, 2 * cin, D, H, W), generator=g1) * zscale
+    ref_a = F.conv3d(x[:, :cin].double(), w.double(), padding=1)
+    ref_b = F.conv3d(x[:, cin:].double(), w2.double(), padding=1)
+    mag_a = F.conv3d(x[:, :cin].double().abs(), w.double().abs(), padding=1)
+    mag_b = F.conv3d(x[:, cin:].double().abs(), w2.double().abs(), padding=1)
+
+    def block(xs, wt):
+        wrow = wt.double().abs().flatten(1).max(dim=1).values.view(1, -1, 1, 1, 1)
+        sum_w = wt.double().abs().flatten(1).sum(dim=1).view(1, -1, 1, 1, 1)
+        sum_x = F.conv3d(xs.double().abs(), torch.ones((1, cin, 3, 3, 3), dtype=torch.float64), padding=1)
+        return float(xs.abs().max()) * sum_w + wrow * sum_x
+
+    with ra.ops.conv_precision("bf16x3"):
+        assert ra.ops.conv3d_k3_uses_x3(cin, cout, 1, D, H, W) and ra.ops.conv3d_k3_uses_x3(2 * cin, cout, 1, D, H, W, 2)
+        one = ra.ops.conv3d_k3(gpu(x[:, :cin].contiguous()), ra.ops.conv3d_k3_pack(gpu(w)), cout, None, None, False,
+                               torch.empty((1, cout, D, H, W), device=DEV)).cpu().double()
+        ones, zeros = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+        dual = ra.ops.conv3d_k3_dual(gpu(x), cin, ra.ops.conv3d_k3_pack(gpu(w)), ones, zeros, ra.ops.conv3d_k3_pack(gpu(w2)), ones, zeros,
+                                     cout, False, torch.empty((1, cout, D, H, W), device=DEV)).cpu().double()
+    assert torch.isfinite(one).all() and torch.isfinite(dual).all()
+    b1 = 2.0 ** -20 * mag_a + 2.0 ** -33 * block(x[:, :cin], w)
+    worst1 = float(((one - ref_a).abs() / b1.clamp_min(1e-300)).max())
+    b2 = 2.0 ** -20 * (mag_a + mag_b) + 2.0 ** -33 * (block(x[:, :cin], w) + block(x[:, cin:], w2))
+    worst2 = float(((dual - (ref_a + ref_b)).abs() / b2.clamp_min(1e-300)).max())
+    rel1 = float(((one - ref_a).abs() / mag_a.clamp_min(1e-300))[:, :, 3:15].max())
+    print(f"x3 with scale restarts: |err| / documented bound = {worst1:.3f} (single), {worst2:.3f} (dual); |err| / sum|w x| on the non-zero planes {rel1:.2e}")
+    assert worst1 <= 1.0 and worst2 <= 1.0
+
+
 def test_x3_bf16_storage(ra):
     """bf16 activation storage on the bf16x3 kernel: the activations are exact bf16 operands, only the weights are split (2 MFMAs)."""
     B, cin, cout, D, H, W = 2, 12, 12, 32, 128, 130
