@@ -88,9 +88,13 @@ int ragmi_costvol_fwd(const void* left_fea, const void* right_fea, void* cost,
 
 /*
  * Weight pre-pack for ragmi_conv3d_k3_fwd: reorders an nn.Conv3d weight
- * [Cout, Cin, 3, 3, 3] (src/automl/operations_3d.py:37) into the per-lane
- * broadcast fragments of v_mfma_f32_4x4x1_16b_f32.  `packed` must hold
- * ragmi_conv3d_k3_packed_elems(Cout, Cin) elements.
+ * [Cout, Cin, 3, 3, 3] (src/automl/operations_3d.py:37), Cout <= 64, into the operand
+ * fragments of the matrix-core kernels.  `packed` must hold
+ * ragmi_conv3d_k3_packed_elems(Cout, Cin) floats: the per-lane broadcast fragments of
+ * v_mfma_f32_4x4x1_16b_f32 (RAGMI_F32), then the bf16 hi / lo fragments (RAGMI_BF16),
+ * then the fp16 hi / lo fragments of w * 2^k[co] and the per-output-channel
+ * multipliers 2^-k[co] (RAGMI_F32X3).  One pack serves every dtype of the convolution
+ * entry points (ragmi_conv3d_k3_pack_for fills only what one contract reads).
  */
 int64_t ragmi_conv3d_k3_packed_elems(int Cout, int Cin);
 int ragmi_conv3d_k3_pack(const void* weight, void* packed, int Cout, int Cin, int dtype, void* stream);
