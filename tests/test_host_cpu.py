@@ -299,3 +299,34 @@ def test_supernet_state_dict_matches_reference_and_genotype_parse():
     assert rows == [[1, 1], [0, 0], [3, 1], [4, 1], [8, 1], [6, 1]]
     twin = net.new()                             # mdenas_basicmodel.py:70-74: fresh weights, copied probabilities
     assert torch.equal(twin.p["reduce"], net.p["reduce"]) and twin.p["reduce"] is not net.p["reduce"]
+
+
+def test_conv_precision_names_and_aliases():
+    """"bf16x3" (round 2's name of the split form) stays the canonical setting; "f16x3" / "split" are aliases of it (since round 3
+    the halves are scaled fp16); anything else is refused; the context manager restores the previous setting."""
+    from rag_amd import ops
+    old = ops.get_conv_precision()
+    try:
+        assert ops.set_conv_precision("fp32") == old
+        ops.set_conv_precision("f16x3")
+        assert ops.get_conv_precision() == "bf16x3"
+        with ops.conv_precision("fp32"):
+            assert ops.get_conv_precision() == "fp32"
+            with ops.conv_precision("split"):
+                assert ops.get_conv_precision() == "bf16x3"
+            assert ops.get_conv_precision() == "fp32"
+        assert ops.get_conv_precision() == "bf16x3"
+        with pytest.raises(ValueError):
+            ops.set_conv_precision("fp16")
+    finally:
+        ops.set_conv_precision(old)
+
+
+def test_training_defaults_to_strict_fp32():
+    """rag.py:204-216 trains in fp32: forward_backward / train_step / GraphedTrainStep default to the strict contract, the split
+    form is opt-in by argument."""
+    import inspect
+    from rag_amd import train
+    assert train.TRAIN_PRECISION == "fp32"
+    for fn in (train.forward_backward, train.train_step, train.GraphedTrainStep.__init__):
+        assert inspect.signature(fn).parameters["precision"].default is None      # None -> TRAIN_PRECISION
