@@ -41,7 +41,7 @@
  *                   it matters only when operands ~2^-25 smaller than their tile's largest carry the sum (measured 1e-3 * sum |w x|
  *                   on operands spread element by element over 2^-20..2^20).  The bound is relative to the sum of |products|, not to
  *                   |y|: cancelling sums lose that many ABSOLUTE digits, as in fp32.  Non-finite inputs give non-finite outputs (an
- *                   Inf may come out as NaN).  Round 2 used bf16 halves (8 bits each, ~2^-17 per product): measured over weight
+ *                   Inf may come out as NaN); so do operands above ~2^110 in magnitude, which no scale brings into fp16's range.  Round 2 used bf16 halves (8 bits each, ~2^-17 per product): measured over weight
  *                   seeds at the headline size that left the EPE against the CPU reference between 1e-5 and 1.4e-3 px; the fp16
  *                   halves sit on the strict fp32 path's EPE for every seed (tests/test_hip_parity.py::
  *                   test_x3_margin_over_seeds_and_genotypes_at_headline_size).

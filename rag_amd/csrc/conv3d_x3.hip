@@ -252,7 +252,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       commit((z + 1) % 3);
       __syncthreads();
       if constexpr (!BF) {
-        if (__uint_as_float(*lmaxp) * mul > X3_F16_CAP) { zfirst = z; again = true; break; }   // workgroup-uniform
+        // (workgroup-uniform.  No restart once the scale sits at its floor: an Inf — or an operand above ~2^110 — can never be made
+        // to fit, and restarting for it would never end; such inputs give non-finite outputs, as include/rag_amd.h says)
+        if (__uint_as_float(*lmaxp) * mul > X3_F16_CAP && __float_as_uint(mul) > X3_SCALE_FLOOR_BITS) { zfirst = z; again = true; break; }
       }
       // unconditional (also past the segment end: the addresses are clamped): the loads stay straight-line code ahead of the
       // MFMA block, a branch here made the compiler drain them (s_waitcnt vmcnt(0)) before the first LDS read

@@ -75,10 +75,11 @@ __device__ __forceinline__ f32x4 x3_mma(const uint4& a, const uint4& b, const f3
   if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, a), __builtin_bit_cast(x3_bf16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8, a), __builtin_bit_cast(x3_f16x8, b), c, 0, 0, 0);
 }
-// largest power of two p with p * m <= target (m > 0 finite), clamped to [2^-100, 2^100]: the operand scale
+constexpr unsigned X3_SCALE_FLOOR_BITS = 0x0d000000u;      // 2^-101: the smallest operand scale (Inf and |x| > ~2^110 cannot be scaled into fp16)
+// largest power of two p with p * m <= target (m > 0 finite), clamped to [2^-101, 2^99]: the operand scale
 __device__ __forceinline__ float x3_pow2_scale(float m, float target) {
   const float q = target / fmaxf(m, 1e-30f);
-  return __uint_as_float(min(max(__float_as_uint(q) & 0x7f800000u, 0x0d000000u), 0x71000000u));
+  return __uint_as_float(min(max(__float_as_uint(q) & 0x7f800000u, X3_SCALE_FLOOR_BITS), 0x71000000u));
 }
 constexpr float X3_F16_CAP = 60000.f;         // |x| * 2^-e must stay below fp16's 65504
 constexpr float X3_ACT_TARGET = 2048.f;       // 2^11: the largest scaled |x| when a column's scale is chosen (16x headroom)

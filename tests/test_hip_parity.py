@@ -1015,6 +1015,29 @@ def test_x3_scale_restart_on_growing_planes(ra):
     assert worst1 <= 1.0 and worst2 <= 1.0
 
 
+def test_x3_non_finite_inputs_terminate(ra):
+    """An Inf (or an operand too large to scale into fp16) can never fit the operand scale: the kernel must not keep restarting its
+    ring for it.  Contract (include/rag_amd.h): non-finite inputs give non-finite outputs where they reach, finite outputs elsewhere
+    stay finite; NaNs propagate without touching the scale."""
+    D, H, W, cin, cout = 16, 128, 130, 4, 12
+    g1 = gen(181)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g1) * 0.1
+    x = torch.randn((1, cin, D, H, W), generator=g1)
+    x[0, 1, 5, 40, 50] = float("inf")
+    x[0, 2, 12, 100, 7] = float("nan")
+    x[0, 0, 9, 64, 64] = 3e38
+    with ra.ops.conv_precision("bf16x3"):
+        out = ra.ops.conv3d_k3(gpu(x), ra.ops.conv3d_k3_pack(gpu(w)), cout, None, None, False, torch.empty((1, cout, D, H, W), device=DEV))
+    torch.cuda.synchronize()
+    out = out.cpu()
+    assert not torch.isfinite(out[0, :, 4:7, 39:42, 49:52]).all()                # the Inf's neighbourhood
+    assert torch.isnan(out[0, :, 11:14, 99:102, 6:9]).all()                      # the NaN's neighbourhood, all 27 x cout outputs
+    far = out[0, :, :3, :20, 80:]                                                 # a column no bad value reaches
+    ref = F.conv3d(x[:, :, :4, :21, 79:].double(), w.double(), padding=1)[0, :, :3, :20, 1:]
+    assert torch.isfinite(far).all()
+    np.testing.assert_allclose(far.numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+
+
 def test_x3_bf16_storage(ra):
     """bf16 activation storage on the bf16x3 kernel: the activations are exact bf16 operands, only the weights are split (2 MFMAs)."""
     B, cin, cout, D, H, W = 2, 12, 12, 32, 128, 130

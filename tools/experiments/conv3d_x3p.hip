@@ -372,7 +372,7 @@ __global__ __launch_bounds__(XP_THREADS, X3P_WPS) void conv3d_x3p_kernel(K3Args 
             esh[st] = *reinterpret_cast<const float4*>(par + 32 + st * 16 + 4 * kb);
           }
           // verdict on plane sp: if it did not fit the scale, outputs from sp - 1 on are recomputed by a restarted ring
-          if (__uint_as_float(*lmaxp) * mul > X3_F16_CAP && !again) { again = 1; zhi = min(zhi, sp - 1); zfirst = max(zs, sp - 1); }
+          if (__uint_as_float(*lmaxp) * mul > X3_F16_CAP && __float_as_uint(mul) > X3_SCALE_FLOOR_BITS && !again) { again = 1; zhi = min(zhi, sp - 1); zfirst = max(zs, sp - 1); }
           __builtin_amdgcn_sched_barrier(0);
           X3P_STAMP(1);
           // the vector work that rides between the MFMAs, cut into pieces of a few instructions each
