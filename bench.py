@@ -476,6 +476,15 @@ def other_configs(net, lf, rf, out_f32, ref, device, use_graph, dist):
     h, w = lf.shape[2:]
     g = torch.Generator().manual_seed(4321)
 
+    def leg(name, fn):
+        """run one configuration; a failure is recorded under its key and does not stop the others"""
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001
+            log(f"bench: leg {name} failed ({type(exc).__name__}: {exc})")
+            res[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.synchronize()
+
     def fwd(n_, a_, b_):
         def step():
             with torch.no_grad():
@@ -483,52 +492,64 @@ def other_configs(net, lf, rf, out_f32, ref, device, use_graph, dist):
         return step
 
     # configs[2]: B=8, bf16 activation storage / fp32 accumulate; pair 0 = the headline pair
-    lf8 = torch.cat([lf, torch.randn((7, FEA_C, h, w), generator=g).to(device)])
-    rf8 = torch.cat([rf, torch.randn((7, FEA_C, h, w), generator=g).to(device)])
-    dt, out, launch = measure(fwd(net, lf8.bfloat16(), rf8.bfloat16()), 5, use_graph)
-    res["config2_bf16_b8"] = {
-        "value": round(8 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 5, "launch": launch,
-        "workload": f"BASELINE configs[2]: 8 stereo pairs/GPU/step, {H}x{W}, D={MAXDISP}, bf16 storage / f32 accumulate, all-conv genotype",
-        "epe_bf16_vs_fp32_px": float((out[:1].double() - out_f32[:1].double()).abs().flatten(1).mean(dim=1).mean()),
-        "epe_gpu_vs_cpu_px": O.epe(out[:1].float().cpu(), ref) if ref is not None else None,
-        "epe_gate_px": 0.12, "epe_note": "seeded random weights drive |cost| to 1e4-1e5: softmin is nearly an argmin (DESIGN.md 4.2)"}
-    log(f"  configs[2] bf16 B=8: {res['config2_bf16_b8']['value']} maps/s, EPE vs fp32 build {res['config2_bf16_b8']['epe_bf16_vs_fp32_px']:.3e}")
-    del out, lf8, rf8
+    def _config2_bf16_b8():
+        lf8 = torch.cat([lf, torch.randn((7, FEA_C, h, w), generator=g).to(device)])
+        rf8 = torch.cat([rf, torch.randn((7, FEA_C, h, w), generator=g).to(device)])
+        dt, out, launch = measure(fwd(net, lf8.bfloat16(), rf8.bfloat16()), 5, use_graph)
+        res["config2_bf16_b8"] = {
+            "value": round(8 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 5, "launch": launch,
+            "workload": f"BASELINE configs[2]: 8 stereo pairs/GPU/step, {H}x{W}, D={MAXDISP}, bf16 storage / f32 accumulate, all-conv genotype",
+            "epe_bf16_vs_fp32_px": float((out[:1].double() - out_f32[:1].double()).abs().flatten(1).mean(dim=1).mean()),
+            "epe_gpu_vs_cpu_px": O.epe(out[:1].float().cpu(), ref) if ref is not None else None,
+            "epe_gate_px": 0.12, "epe_note": "seeded random weights drive |cost| to 1e4-1e5: softmin is nearly an argmin (DESIGN.md 4.2)"}
+        log(f"  configs[2] bf16 B=8: {res['config2_bf16_b8']['value']} maps/s, EPE vs fp32 build {res['config2_bf16_b8']['epe_bf16_vs_fp32_px']:.3e}")
+        del out, lf8, rf8
+
+    leg("config2_bf16_b8", _config2_bf16_b8)
     # configs[3]: one GPU's shard (B=8) of the 64-pair DrivingStereo batch at the reference's eval pad 480x960 (stereo_dataset.py:95-96)
-    h3, w3 = 480 // 3, 960 // 3
-    a3 = torch.randn((8, FEA_C, h3, w3), generator=g).to(device)
-    b3 = torch.randn((8, FEA_C, h3, w3), generator=g).to(device)
-    dt, out, launch = measure(fwd(net, a3, b3), 5, use_graph)
-    res["config3_480x960_b8"] = {
-        "value": round(8 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 5, "launch": launch,
-        "workload": f"BASELINE configs[3]: one rank's shard of the 64-pair batch: 8 stereo pairs/GPU/step, 480x960, D={MAXDISP}, f32, all-conv genotype"}
-    log(f"  configs[3] 480x960 B=8: {res['config3_480x960_b8']['value']} maps/s")
-    del out, a3, b3
+    def _config3_480x960_b8():
+        h3, w3 = 480 // 3, 960 // 3
+        a3 = torch.randn((8, FEA_C, h3, w3), generator=g).to(device)
+        b3 = torch.randn((8, FEA_C, h3, w3), generator=g).to(device)
+        dt, out, launch = measure(fwd(net, a3, b3), 5, use_graph)
+        res["config3_480x960_b8"] = {
+            "value": round(8 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 5, "launch": launch,
+            "workload": f"BASELINE configs[3]: one rank's shard of the 64-pair batch: 8 stereo pairs/GPU/step, 480x960, D={MAXDISP}, f32, all-conv genotype"}
+        log(f"  configs[3] 480x960 B=8: {res['config3_480x960_b8']['value']} maps/s")
+        del out, a3, b3
+
+    leg("config3_480x960_b8", _config3_480x960_b8)
     # the all-skip genotype (what an untrained BasicNetwork.genotype() returns) as the lower bound, headline size
-    skip = build_net(device, genotype=rag_amd.modules.ALL_SKIP_GENOTYPE)
-    dt, out, launch = measure(fwd(skip, lf, rf), 10, use_graph)
-    epe_skip = None
-    if ref is not None:
-        sd = {k: v.detach().cpu() for k, v in skip.state_dict().items()}
-        t0 = time.perf_counter()
-        ref_skip = O.matching_net_forward(lf[:1].cpu(), rf[:1].cpu(), sd, O.ALL_SKIP, MAXDISP)
-        cpu_s = time.perf_counter() - t0
-        epe_skip = O.epe(out[:1].float().cpu(), ref_skip)
-    res["all_skip"] = {
-        "value": round(1 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 10, "launch": launch,
-        "workload": f"all-skip genotype (identity branches only in every cell), 1 stereo pair, {H}x{W}, D={MAXDISP}, f32",
-        "epe_gpu_vs_cpu_px": epe_skip, "cpu_oracle_s_per_pair": round(cpu_s, 2) if ref is not None else None}
-    log(f"  all-skip genotype: {res['all_skip']['value']} maps/s, EPE {epe_skip}")
-    del out, skip
-    torch.cuda.empty_cache()
+    def _all_skip():
+        skip = build_net(device, genotype=rag_amd.modules.ALL_SKIP_GENOTYPE)
+        dt, out, launch = measure(fwd(skip, lf, rf), 10, use_graph)
+        epe_skip = None
+        if ref is not None:
+            sd = {k: v.detach().cpu() for k, v in skip.state_dict().items()}
+            t0 = time.perf_counter()
+            ref_skip = O.matching_net_forward(lf[:1].cpu(), rf[:1].cpu(), sd, O.ALL_SKIP, MAXDISP)
+            cpu_s = time.perf_counter() - t0
+            epe_skip = O.epe(out[:1].float().cpu(), ref_skip)
+        res["all_skip"] = {
+            "value": round(1 / dt, 3), "unit": "disparity maps/s", "ms_per_step": round(dt * 1e3, 4), "steps": 10, "launch": launch,
+            "workload": f"all-skip genotype (identity branches only in every cell), 1 stereo pair, {H}x{W}, D={MAXDISP}, f32",
+            "epe_gpu_vs_cpu_px": epe_skip, "cpu_oracle_s_per_pair": round(cpu_s, 2) if ref is not None else None}
+        log(f"  all-skip genotype: {res['all_skip']['value']} maps/s, EPE {epe_skip}")
+        del out, skip
+        torch.cuda.empty_cache()
+
+    leg("all_skip", _all_skip)
     # configs[4]: the training step (B=4 at 192x384), its dominant kernel's roofline and the oracle's fwd+bwd beside it
-    line = train_leg(device, dist, 0, 1, TRAIN_B, 5, 2, use_graph, "fp32", with_cpu=ref is not None)
-    res["config4_train"] = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "phases_rank0", "loss_first_last",
-                                                 "roofline", "cpu_baseline")}
-    res["config4_train"]["workload"] = line["config"]["workload"]
-    res["config4_train"]["conv_precision"] = line["config"]["conv_precision"]
-    res["config4_train"]["launch"] = line["config"]["launch"]
-    log(f"  configs[4] training step: {line['ms_per_step']} ms/step, {line['value']} pairs/s ({line['config']['conv_precision']})")
+    def _config4_train():
+        line = train_leg(device, dist, 0, 1, TRAIN_B, 5, 2, use_graph, "fp32", with_cpu=ref is not None)
+        res["config4_train"] = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "phases_rank0", "loss_first_last",
+                                                     "roofline", "cpu_baseline")}
+        res["config4_train"]["workload"] = line["config"]["workload"]
+        res["config4_train"]["conv_precision"] = line["config"]["conv_precision"]
+        res["config4_train"]["launch"] = line["config"]["launch"]
+        log(f"  configs[4] training step: {line['ms_per_step']} ms/step, {line['value']} pairs/s ({line['config']['conv_precision']})")
+
+    leg("config4_train", _config4_train)
     return res
 
 
@@ -717,12 +738,24 @@ def main():
                 d32 = net(lf[:1].float(), rf[:1].float())
             epe_bf16_vs_fp32 = float((out[:1].double() - d32.double()).abs().flatten(1).mean(dim=1).mean())
             log(f"  EPE bf16 storage vs the fp32 build on the same pair: {epe_bf16_vs_fp32:.3e} px")
-        e2e = end_to_end(device, min(args.steps, 10), use_graph=bool(args.graph)) if (n_gpus == 1 and args.dtype == "f32") else None
-        if e2e:
+        e2e = None
+        if n_gpus == 1 and args.dtype == "f32":
+            try:      # a rider: it must never cost the headline its line
+                e2e = end_to_end(device, min(args.steps, 10), use_graph=bool(args.graph))
+            except Exception as exc:  # noqa: BLE001
+                log(f"bench: end_to_end leg failed ({type(exc).__name__}: {exc})")
+                e2e = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.synchronize()
+        if e2e and "value" in e2e:
             log(f"  end-to-end (images -> disparity, Feature Net + Matching Net): {e2e['value']} maps/s ({e2e['ms_per_pair']} ms/pair)")
         configs = None
         if (n_gpus == 1 and args.dtype == "f32" and B == 1 and (H, W) == (384, 1248) and not args.no_configs):
-            configs = other_configs(net, lf, rf, out, ref if cpu is not None else None, device, bool(args.graph), dist)
+            try:      # the riders must never cost the headline its line
+                configs = other_configs(net, lf, rf, out, ref if cpu is not None else None, device, bool(args.graph), dist)
+            except Exception as exc:  # noqa: BLE001
+                log(f"bench: the legs of the other configurations failed ({type(exc).__name__}: {exc})")
+                configs = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.synchronize()
         ms = dt / args.steps * 1e3
         line = {
             "metric": f"disparity maps/sec at {H}x{W} D=192 (Matching-Net forward)",
