@@ -88,7 +88,7 @@ class K3Profiler:
             log_tx, rows, groups = ops.conv3d_k3_plan(cout, B, D, Hh, Ww)
             res = a[5] if len(a) > 5 else kw.get("res")
             if ops.conv3d_k3_uses_x3(Cin, cout, B, D, Hh, Ww, 1, res is not None, len(kw.get("tails") or []), x.dtype):
-                groups, log_tx, rows = [(Cin + 3) // 4], "x3", 0          # bf16x3 kernel: conv3d_x3_kernel<channel groups, sets>
+                groups, log_tx, rows = [(Cin + 3) // 4], "x3", 0          # f16x3 kernel: conv3d_x3_kernel<channel groups, sets>
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = self._orig(x, packed, cout, *a, **kw)
@@ -154,6 +154,15 @@ def pmc_traffic_bytes(kernel_name: str):
     return None, None
 
 
+def safe_sync():
+    """torch.cuda.synchronize() for error handlers: after a sticky GPU error the synchronize itself raises again — swallowed here,
+    so that a failed rider leg is recorded under its key and never costs the headline its line."""
+    try:
+        torch.cuda.synchronize()
+    except Exception as exc:  # noqa: BLE001
+        log(f"bench: synchronize in an error handler failed too ({type(exc).__name__}: {exc})")
+
+
 def try_capture(fn, census_out=None):
     """Capture fn() into a hipGraph; (graph, result) or (None, None) if the capture is refused.  Thread-local error mode:
     other threads of the process (RCCL's watchdog polls events) must not invalidate the capture.  A failed capture
@@ -178,7 +187,7 @@ def try_capture(fn, census_out=None):
         return graph, out
     except Exception as exc:  # noqa: BLE001
         log(f"bench: hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches")
-        torch.cuda.synchronize()
+        safe_sync()
         return None, None
 
 
@@ -381,7 +390,7 @@ def train_leg(device, dist, rank, n_gpus, B, steps, warmup, use_graph, precision
             graphed = GraphedTrainStep(net, opt, bucket, left, right, gt, clip=5.0, dist=dist, precision=precision)
         except Exception as exc:  # noqa: BLE001
             log(f"bench: hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); eager launches")
-            torch.cuda.synchronize()
+            safe_sync()
 
     def step():
         if graphed is not None:
@@ -412,7 +421,7 @@ def train_leg(device, dist, rank, n_gpus, B, steps, warmup, use_graph, precision
         (kind, Cin, Cout, Bk, D, Hh, Ww), secs, nlaunch, conv_secs = dom
         vox = float(Bk) * D * Hh * Ww
         flops, nbytes = 2.0 * 27 * Cin * Cout * vox, 4.0 * (Cin + Cout) * vox
-        x3 = kind.startswith("conv3d_k3 (") and precision == "bf16x3" and rag_amd.ops.conv3d_k3_uses_x3(Cin, Cout, Bk, D, Hh, Ww)
+        x3 = kind.startswith("conv3d_k3 (") and precision == "f16x3" and rag_amd.ops.conv3d_k3_uses_x3(Cin, Cout, Bk, D, Hh, Ww)
         peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
         t_hbm, t_mfma = nbytes / (PEAK_HBM_GBS * 1e9), (3.0 if x3 else 1.0) * flops / (peak * 1e12)
         per = secs / nlaunch
@@ -483,7 +492,7 @@ def other_configs(net, lf, rf, out_f32, ref, device, use_graph, dist):
         except Exception as exc:  # noqa: BLE001
             log(f"bench: leg {name} failed ({type(exc).__name__}: {exc})")
             res[name] = {"error": f"{type(exc).__name__}: {exc}"}
-            torch.cuda.synchronize()
+            safe_sync()
 
     def fwd(n_, a_, b_):
         def step():
@@ -565,8 +574,8 @@ def main():
                     help="activation storage: f32 (configs[1], default) or bf16 storage / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: time the data-parallel training step instead")
-    ap.add_argument("--train-precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="arithmetic of the training step's 3x3x3 convolutions: fp32 (default, the reference's class) or bf16x3 (opt-in)")
+    ap.add_argument("--train-precision", choices=["fp32", "f16x3"], default="fp32",
+                    help="arithmetic of the training step's 3x3x3 convolutions: fp32 (default, the reference's class) or f16x3 (opt-in)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (configs object)")
     ap.add_argument("--hw", default=None, help="HxW of the stereo pairs, multiples of 12 (default 384x1248 = configs[1]; configs[3]: "
                                                "480x960 with --batch 8)")
@@ -710,7 +719,7 @@ def main():
             log(f"  EPE of the timed GPU path vs the CPU oracle on the same pair: {epe:.3e} px")
             cpu["epe_gpu_vs_cpu_px"] = epe
         strict = None
-        if n_gpus == 1 and args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "bf16x3":
+        if n_gpus == 1 and args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "f16x3":
             # the same workload with every contraction on the fp32-input MFMA forms: the record carries both arithmetic contracts
             with rag_amd.ops.conv_precision("fp32"):
                 for _ in range(2):
@@ -745,7 +754,7 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 log(f"bench: end_to_end leg failed ({type(exc).__name__}: {exc})")
                 e2e = {"error": f"{type(exc).__name__}: {exc}"}
-                torch.cuda.synchronize()
+                safe_sync()
         if e2e and "value" in e2e:
             log(f"  end-to-end (images -> disparity, Feature Net + Matching Net): {e2e['value']} maps/s ({e2e['ms_per_pair']} ms/pair)")
         configs = None
@@ -755,7 +764,7 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 log(f"bench: the legs of the other configurations failed ({type(exc).__name__}: {exc})")
                 configs = {"error": f"{type(exc).__name__}: {exc}"}
-                torch.cuda.synchronize()
+                safe_sync()
         ms = dt / args.steps * 1e3
         line = {
             "metric": f"disparity maps/sec at {H}x{W} D=192 (Matching-Net forward)",
@@ -765,7 +774,7 @@ def main():
             "dtype": ("f32 (RAGMI_F32X3: level-3/6/12 3x3x3 convolutions with fp32 operands split into power-of-two-scaled FP16 hi+lo halves on "
                       "the 16-bit matrix cores, hi*hi + hi*lo + lo*hi, fp32 accumulate: fp32-class accuracy, bound in include/rag_amd.h; "
                       "strict_fp32 holds the RAGMI_F32 number)"
-                      if (args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "bf16x3") else
+                      if (args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "f16x3") else
                       "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate"), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if (H, W) == (480, 960) else 1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",

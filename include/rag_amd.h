@@ -330,8 +330,9 @@ int ragmi_conv3d_k3_pack_ex(const void* weight, void* packed, int Cout, int Cin,
 
 /* ragmi_conv3d_k3_pack_ex for a weight that will be used under ONE known arithmetic contract (the training step packs ~150 weights
  * per step, each for the call that follows): for_dtype == RAGMI_F32 fills only the fp32-MFMA section of `packed` (same buffer size);
- * such a buffer must be passed to the convolution entry points with dtype RAGMI_F32 only.  Any other for_dtype fills every section,
- * like ragmi_conv3d_k3_pack_ex. */
+ * such a buffer must be passed to the convolution entry points with dtype RAGMI_F32 only — the sections it skips are POISONED (NaN
+ * fragments and multipliers), so a call under another dtype returns NaN everywhere instead of reading uninitialised memory.  Any
+ * other for_dtype fills every section, like ragmi_conv3d_k3_pack_ex. */
 int ragmi_conv3d_k3_pack_for(const void* weight, void* packed, int Cout, int Cin, int transpose, int planar2d, int for_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

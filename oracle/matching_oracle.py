@@ -375,8 +375,8 @@ def stereo_metrics(disp_est: torch.Tensor, disp_gt: torch.Tensor, maxdisp: float
     """Appr.eval's per-batch scalars, approaches/rag.py:418-430 with utilstool/metrics.py:21-65 restated:
     mask = 0 < gt < maxdisp; loss = smooth-L1 over all masked pixels of the batch; EPE / D1 / Thres-tau are computed
     per image and averaged over the images with mask.mean() / (gt > 0).mean() >= 0.1 (0 when none is kept).
-    PARITY UNPINNED for this function: utilstool.metrics imports torchvision (utilstool/experiment.py:7), which is not
-    installed here, so no fixture could be generated from the reference itself; it is a line-by-line restatement."""
+    Parity PINNED (round 4) by tests/golden/g11_metrics.npz: the reference's own metric functions run by make_golden.py (with an
+    empty placeholder for the unrelated `torchvision.utils` import of utilstool/experiment.py:7)."""
     mask = (disp_gt < maxdisp) & (disp_gt > 0)
     out = {"loss": float(F.smooth_l1_loss(disp_est[mask], disp_gt[mask], reduction="mean"))}
 

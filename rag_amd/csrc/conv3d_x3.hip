@@ -79,7 +79,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     par[96 + i] = sc;
     par[32 + i] = (ok && a.shift[set]) ? a.shift[set][co] : 0.f;
   }
-  if (tid == 0) *lmaxp = 0u;
+  if (tid < 2) lmaxp[tid] = 0u;
   // Fused consumer 1x1x1 convs ("tails") on the matrix cores: out_t[k][voxel] = sum_c W_t[k][c] * v[c][voxel] is a few more
   // 16x16x32 products whose K slots are laid out so that every lane quarter feeds ITS OWN four channels (slots 8kb..8kb+3 and
   // 8kb+4..8kb+7 carry two 16-bit parts of channels 4kb..4kb+3), so no value crosses lanes.  Rows: tail 0 -> 0..3, tail 1 -> 4..7.
@@ -170,19 +170,24 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     }
   };
   // largest |value| among this thread's valid halo elements of the plane in flight (fp32 storage: feeds the operand scale)
+  // (elements no scale can bring into fp16 — Inf, NaN, |x| >= 2^115 — take no part: they become fp16 Inf / NaN on their own and
+  // disturb the outputs whose 3x3x3 window holds them, like the reference's arithmetic; letting them pick the scale would flush
+  // every ordinary activation of the tile to zero for the rest of the segment)
   auto local_max = [&]() {
     float m = 0.f;
 #pragma unroll
     for (int p = 0; p < NPF; ++p) {
-      const float mp = fmaxf(fmaxf(fabsf(pf[p][0]), fabsf(pf[p][1])), fmaxf(fabsf(pf[p][2]), fabsf(pf[p][3])));
+      const float mp = x3_scalable_max4(pf[p][0], pf[p][1], pf[p][2], pf[p][3]);
       m = fmaxf(m, ((valid >> p) & 1u) ? mp : 0.f);
     }
     return m;
   };
   // a plane that does not fit the column's scale: record its magnitude; the workgroup restarts its ring behind the next barrier
+  // (lmaxp[1], never the word the scale is derived from: lmaxp[0] only changes between the two barriers that open a ring pass, so
+  // `mul` and the restart test below are workgroup-uniform by construction)
   auto note_overflow = [&]() {
     const float m = local_max();
-    if (m * mul > X3_F16_CAP) atomicMax(lmaxp, __float_as_uint(m));
+    if (m * mul > X3_F16_CAP) atomicMax(lmaxp + 1, __float_as_uint(m));
   };
   // this wave's column tiles of a plane: nt = wave * X3_NT + i -> (row y = nt / 2, x half = nt % 2); X3_NT is even, so tile i
   // sits a compile-time distance behind tile 0 (an immediate offset of the LDS read)
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     const T* xb = x + b * a.x_bstride;
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
     locate(y0, x0);
-    if constexpr (!BF) { if (tid == 0) *lmaxp = 0u; }  // (ordered before the first atomicMax below by the barrier that follows)
+    if constexpr (!BF) { if (tid < 2) lmaxp[tid] = 0u; }  // (ordered before the first atomicMax below by the barrier that follows)
     int zfirst = zs;
     // fp32 storage: the ring (re)starts at plane zfirst with the operand scale chosen from that plane — its largest |x| lands at
     // 2^10..2^11, a factor >= 16 below fp16's range for the planes that follow; one that still does not fit restarts the ring at
@@ -231,11 +236,15 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     for (;;) {
       if constexpr (!BF) {
         __syncthreads();
+        // lmaxp[0] = the maximum the scale is chosen from: running maximum of the segment so far (a restart folds the overflow
+        // note in) joined by plane zfirst.  Written only here, between this pass's two barriers; lmaxp[1] = overflow notes, written
+        // only AFTER the second barrier and read behind the z loop's barriers.
+        if (tid == 0) { const unsigned note = lmaxp[1]; lmaxp[1] = 0u; if (note) atomicMax(lmaxp, note); }
         prefetch(xb, zfirst);
         const float wm = x3_wave_max(local_max());
         if (lane == 0) atomicMax(lmaxp, __float_as_uint(wm));
         __syncthreads();
-        mul = x3_pow2_scale(__uint_as_float(*lmaxp), X3_ACT_TARGET);
+        mul = x3_pow2_scale(__uint_as_float(lmaxp[0]), X3_ACT_TARGET);
         if (tid < 32) par[tid] = par[96 + tid] * (1.f / mul);       // the epilogue's scale undoes the column's 2^-e
         commit(zfirst % 3);
         prefetch(xb, zfirst - 1); note_overflow(); commit((zfirst - 1 + 3) % 3);
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       if constexpr (!BF) {
         // (workgroup-uniform.  No restart once the scale sits at its floor: an Inf — or an operand above ~2^110 — can never be made
         // to fit, and restarting for it would never end; such inputs give non-finite outputs, as include/rag_amd.h says)
-        if (__uint_as_float(*lmaxp) * mul > X3_F16_CAP && __float_as_uint(mul) > X3_SCALE_FLOOR_BITS) { zfirst = z; again = true; break; }
+        if (lmaxp[1] != 0u && __float_as_uint(mul) > X3_SCALE_FLOOR_BITS) { zfirst = z; again = true; break; }
       }
       // unconditional (also past the segment end: the addresses are clamped): the loads stay straight-line code ahead of the
       // MFMA block, a branch here made the compiler drain them (s_waitcnt vmcnt(0)) before the first LDS read
@@ -442,6 +451,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
     par[NSET * COGS * 16 + i] = (co < a.Cout && a.shift[set]) ? a.shift[set][co] : 0.f;
   }
   if (tid < 3) lmaxp[tid] = 0u;
+  __syncthreads();      // the slots are zero before any wave's first atomicMax (waves that skip the loops above arrive there early)
   float pf[NPF][4];
   unsigned valid = 0;
   const T* const x = static_cast<const T*>(a.x);
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
         float m = 0.f;
 #pragma unroll
         for (int p = 0; p < NPF; ++p) {
-          const float mp = fmaxf(fmaxf(fabsf(pf[p][0]), fabsf(pf[p][1])), fmaxf(fabsf(pf[p][2]), fabsf(pf[p][3])));
+          const float mp = x3_scalable_max4(pf[p][0], pf[p][1], pf[p][2], pf[p][3]);     // (Inf / NaN / >= 2^115 take no part)
           m = fmaxf(m, ((valid >> p) & 1u) ? mp : 0.f);
         }
         m = x3_wave_max(m);
@@ -685,11 +695,24 @@ int64_t x3_packed_words(int Cout, int Cin) {
 // the sections of ragmi_conv3d_k3_pack_ex in one launch: workgroups [0, nb_k3) fill the fp32-MFMA section, the next nb_x3 the
 // bf16 fragments, the last nb_x3 the scaled fp16 fragments and their multipliers (a training step packs ~150 weights; each launch
 // it does not make is ~3.5 us)
+// poison != 0 (ragmi_conv3d_k3_pack_for(RAGMI_F32): only the fp32-MFMA section is filled): the first fragment of the bf16 and of
+// the fp16 section and every multiplier become NaN, so a convolution that consumes such a pack under another contract returns NaN
+// everywhere instead of the products of uninitialised memory.
 __global__ void pack_both_kernel(const float* __restrict__ w, float* __restrict__ packed, int64_t total_k3, int nb_k3, int nb_x3, int Cout, int Cin,
-                                 int nchunks, int nsls, int ncog, int transpose, int planar) {
+                                 int nchunks, int nsls, int ncog, int transpose, int planar, int poison) {
   if ((int)blockIdx.x < nb_k3) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx < total_k3) packed[idx] = k3_pack_value(w, Cout, Cin, nchunks, idx, transpose, planar);
+    if (poison && blockIdx.x == 0) {
+      const int64_t fw = (int64_t)ncog * nsls * 2 * 64 * 4;
+      unsigned* const sec = reinterpret_cast<unsigned*>(packed + total_k3);
+      for (int c = 0; c < ncog; ++c)        // hi fragment of slice 0 of every output block: 64 lanes x 4 words
+        for (int i = threadIdx.x; i < 256; i += 256) {
+          sec[(int64_t)c * nsls * 2 * 64 * 4 + i] = 0x7fc07fc0u;             // bf16 NaN pairs
+          sec[fw + (int64_t)c * nsls * 2 * 64 * 4 + i] = 0x7e007e00u;        // fp16 NaN pairs
+        }
+      for (int i = threadIdx.x; i < ncog * 16; i += 256) sec[2 * fw + i] = 0x7fc00000u;
+    }
   } else {
     const int half = ((int)blockIdx.x - nb_k3) >= nb_x3 ? 1 : 0;      // block-uniform
     __shared__ unsigned rowmax[64];
@@ -703,7 +726,7 @@ int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin
   const int ncgs = (Cin + 3) / 4, nsls = (ncgs * 27 + 7) / 8, ncog = (Cout + 15) / 16;
   const int nb_k3 = (int)ceil_div(total_k3, 256), nb_x3 = (int)ceil_div((int64_t)ncog * nsls * 64, 256);
   hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)(nb_k3 + (all ? 2 * nb_x3 : 0))), dim3(256), 0, s, w, packed, total_k3, nb_k3, nb_x3, Cout, Cin,
-                     (Cin + CK - 1) / CK, nsls, ncog, transpose, planar);
+                     (Cin + CK - 1) / CK, nsls, ncog, transpose, planar, all ? 0 : 1);
   return RAGMI_OK;
 }
 

@@ -1,5 +1,4 @@
-// Shared pieces of the split-operand 3x3x3 convolution kernels (conv3d_x3.hip: z-marching and deep forms; conv3d_x3p.hip: the
-// plane-stationary form): operand splits, the MFMA wrapper, operand-scale helpers, packed-fragment layout and launch extras.
+// Shared pieces of the split-operand 3x3x3 convolution kernels (conv3d_x3.hip: z-marching and deep forms): operand splits, the MFMA wrapper, operand-scale helpers, packed-fragment layout and launch extras.
 #pragma once
 #include <cstdlib>
 
@@ -81,6 +80,13 @@ __device__ __forceinline__ float x3_pow2_scale(float m, float target) {
   const float q = target / fmaxf(m, 1e-30f);
   return __uint_as_float(min(max(__float_as_uint(q) & 0x7f800000u, X3_SCALE_FLOOR_BITS), 0x71000000u));
 }
+// largest |v| of four values among those a power-of-two scale can bring into fp16's range: bit patterns from 2^115 up (finite
+// outliers the floor scale 2^-101 cannot fit, Inf, NaN) count as 0.  Bit patterns of non-negative floats order like the values.
+constexpr unsigned X3_UNSCALABLE_BITS = 0x79000000u;      // 2^115
+__device__ __forceinline__ float x3_scalable_max4(float v0, float v1, float v2, float v3) {
+  auto f = [](float v) { const unsigned b = __float_as_uint(v) & 0x7fffffffu; return b < X3_UNSCALABLE_BITS ? b : 0u; };
+  return __uint_as_float(max(max(f(v0), f(v1)), max(f(v2), f(v3))));
+}
 constexpr float X3_F16_CAP = 60000.f;         // |x| * 2^-e must stay below fp16's 65504
 constexpr float X3_ACT_TARGET = 2048.f;       // 2^11: the largest scaled |x| when a column's scale is chosen (16x headroom)
 constexpr float X3_W_TARGET = 1024.f;         // 2^10: the largest scaled |w| of an output channel
@@ -161,8 +167,6 @@ struct X3Extra {
   const float* wmul[2];      // fp16 section: per-output-channel multiplier 2^-k that undoes the weight scale (null for bf16 storage)
   int nseg, seg_len, nwork, bf16;   // bf16 != 0: bf16 activation storage (kernel instantiation selector)
   int ngrp, grp, nsplit;     // z-marching form: groups per sample; (column, segment) pairs per group of a sample, of which the last nsplit are two half items
-  unsigned xbytes;           // tools/experiments/conv3d_x3p.hip: bytes of one batch item's input channels (buffer-descriptor range)
-  unsigned long long* dbg;   // tools/experiments/conv3d_x3p.hip, RAGMI_X3P_STAMPS builds: per-phase cycle sums
 };
 // fragment words (floats) of ONE section for a conv with these channel counts
 inline int64_t x3_frag_words(int Cout, int Cin) {
@@ -181,7 +185,7 @@ inline void x3_weight_sections(X3Extra& e, const K3Args& a, int nset, int dtype)
 }
 
 
-// (the plane-stationary form measured in round 3 lives in tools/experiments/conv3d_x3p.hip: declarations and the dispatch hook are
-// in its header comment)
+// (the plane-stationary form measured in rounds 2-3 and not shipped is in the history: git show e045bcd:tools/experiments/conv3d_x3p.hip;
+// its numbers are profiles/r03_x3p_investigation.md)
 
 }  // namespace ragmi

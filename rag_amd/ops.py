@@ -19,19 +19,19 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 # Arithmetic of the fp32 3x3x3 convolutions — an explicit, process-wide host setting that travels to the library as the dtype
 # argument of each call (RAGMI_F32 or RAGMI_F32X3); the library itself reads no environment variable.
-#   "bf16x3": eligible volumes run as hi/lo-split products on the 16-bit matrix cores, hi*hi + hi*lo + lo*hi (error bound in
-#             include/rag_amd.h; the inference default).  The name is round 2's, when the halves were bf16; since round 3 they are
-#             power-of-two-scaled FP16 halves (fp32-class accuracy).  "f16x3" is accepted as an alias of the same setting;
+#   "f16x3":  eligible volumes run as hi/lo-split products on the 16-bit matrix cores, hi*hi + hi*lo + lo*hi, on power-of-two-scaled
+#             FP16 halves (fp32-class accuracy; error bound in include/rag_amd.h; the inference default, ABI dtype RAGMI_F32X3).
+#             "bf16x3" — round 2's name, when the halves were bf16 — and "split" are accepted as aliases of the same setting;
 #   "fp32":   every contraction on the fp32-input MFMA forms (exact fmaf chains).
 # The environment variable RAGMI_X3=0 only picks the DEFAULT here, once, at import.
-_CONV_PRECISIONS = ("bf16x3", "fp32")
-_PRECISION_ALIASES = {"f16x3": "bf16x3", "split": "bf16x3"}
-_conv_precision = "fp32" if os.environ.get("RAGMI_X3", "1").strip() == "0" else "bf16x3"
+_CONV_PRECISIONS = ("f16x3", "fp32")
+_PRECISION_ALIASES = {"bf16x3": "f16x3", "split": "f16x3"}
+_conv_precision = "fp32" if os.environ.get("RAGMI_X3", "1").strip() == "0" else "f16x3"
 
 
 def set_conv_precision(precision: str) -> str:
-    """Select the arithmetic of fp32 3x3x3 convolutions ("bf16x3" = the split form, alias "f16x3"; or "fp32"); returns the
-    previous setting."""
+    """Select the arithmetic of fp32 3x3x3 convolutions ("f16x3" = the split form, aliases "bf16x3" / "split"; or "fp32"); returns
+    the previous setting (always a canonical name)."""
     global _conv_precision
     precision = _PRECISION_ALIASES.get(precision, precision)
     if precision not in _CONV_PRECISIONS:
@@ -61,7 +61,7 @@ class conv_precision:
 
 def _conv_dt(dt: int) -> int:
     """ABI dtype of a 3x3x3 convolution call for activation dtype code `dt` under the current precision setting."""
-    return F32X3 if (dt == F32 and _conv_precision == "bf16x3") else dt
+    return F32X3 if (dt == F32 and _conv_precision == "f16x3") else dt
 
 
 def _stream() -> int:

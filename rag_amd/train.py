@@ -71,7 +71,7 @@ def masked_smooth_l1(disp: torch.Tensor, gt: torch.Tensor, maxdisp: int) -> torc
     return (per * mask).sum() / mask.sum()
 
 
-TRAIN_PRECISION = "fp32"     # the reference's training step is fp32 (rag.py:204-216); "bf16x3" is opt-in (~6 % of the step)
+TRAIN_PRECISION = "fp32"     # the reference's training step is fp32 (rag.py:204-216); "f16x3" is opt-in (~6 % of the step)
 
 
 def forward_backward(net, bucket: GradBucket, left, right, gt, *, task_arch=None, features: bool = False,
@@ -79,7 +79,7 @@ def forward_backward(net, bucket: GradBucket, left, right, gt, *, task_arch=None
     """forward -> masked smooth-L1 -> zero the bucket -> backward (rag.py:208-214).  `features=True`: `net` is a
     MatchingNet and left/right are Feature-Net outputs.  `precision`: arithmetic of the 3x3x3 convolutions of the step (forward and
     data gradient): "fp32" (default, TRAIN_PRECISION: every contraction on the fp32-input MFMA forms, the reference's arithmetic
-    class) or "bf16x3" (opt-in; bound in include/rag_amd.h).  Returns the (detached) loss."""
+    class) or "f16x3" (opt-in; bound in include/rag_amd.h).  Returns the (detached) loss."""
     from . import ops
     with ops.conv_precision(precision or TRAIN_PRECISION):
         disp = net(left, right, task_arch) if features else net(left, right, 0, task_arch if task_arch is not None else net.arch_init)

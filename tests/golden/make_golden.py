@@ -7,8 +7,11 @@ small ``.npz`` fixtures next to this script.  The reference never travels to
 the GPU box; only these data files do.  On a machine without /root/reference
 this script exits with a message and changes nothing.
 
-The only harness-side shim is ``torch.cuda.current_device`` -> CPU, required by
-DisparityRegression (src/models/rag_model.py:26) to run without a GPU.
+Harness-side shims: ``torch.cuda.current_device`` -> CPU, required by
+DisparityRegression (src/models/rag_model.py:26) to run without a GPU; and, for
+G11 only, an empty placeholder module named ``torchvision`` so that
+``utilstool/experiment.py:7``'s import statement succeeds (the metric functions
+under test never touch it).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -349,6 +352,59 @@ def main():
     blob = {"arch_t0": arch0, "arch_t1": best, "winners": list(winners), "length": {k_: int(v) for k_, v in net.length.items()}}
     arrays["blob"] = np.frombuffer(json.dumps(blob).encode(), dtype=np.uint8)
     save("g10_grown_model", **arrays)
+
+    # ------------------------------------------------------------------ G11: eval-loop loss + metrics
+    # utilstool/metrics.py:21-65 with the mask and loss of approaches/rag.py:418-430.  metrics.py imports `make_nograd_func`
+    # from utilstool/experiment.py, whose module-level `import torchvision.utils as vutils` (experiment.py:7) serves an image
+    # logger (experiment.py:87) that the metric functions never reach; torchvision is not installed here.  Harness-side shim of
+    # the same class as `current_device` above: an EMPTY placeholder module under that name, so the import statement succeeds —
+    # no function of it is ever called, and none is defined.
+    import types
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.utils = types.ModuleType("torchvision.utils")
+        sys.modules["torchvision"], sys.modules["torchvision.utils"] = tv, tv.utils
+    import warnings
+    import torch.nn.functional as F
+    from utilstool.metrics import D1_metric, EPE_metric, Thres_metric
+    max_disp = 192                                         # rag.py:60
+    gen = torch.Generator().manual_seed(1111)
+    arrays = {}
+
+    def metric_case(tag, est, gt):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                # size_average= is deprecated spelling of reduction="mean"
+            mask = (gt < max_disp) & (gt > 0)                                               # rag.py:418
+            loss = F.smooth_l1_loss(est[mask], gt[mask], size_average=True)                 # rag.py:419
+            vals = [loss, EPE_metric(est, gt, mask), D1_metric(est, gt, mask), Thres_metric(est, gt, mask, 1.0),
+                    Thres_metric(est, gt, mask, 2.0), Thres_metric(est, gt, mask, 3.0)]     # rag.py:421-429
+        arrays[f"{tag}::est"], arrays[f"{tag}::gt"] = est.numpy(), gt.numpy()
+        arrays[f"{tag}::scalars"] = np.array([float(v) for v in vals], dtype=np.float64)     # loss, EPE, D1, Thres1, Thres2, Thres3
+
+    # a: three ordinary images: gt ~ U(-10, 210) (zeros / negatives and >= 192 fall outside the mask), est = gt + noise of mixed sizes
+    gt = torch.rand((3, 24, 40), generator=gen) * 220 - 10
+    est = gt + torch.randn(gt.shape, generator=gen) * torch.tensor([0.5, 2.0, 6.0]).view(3, 1, 1)
+    metric_case("a", est.contiguous(), gt)
+    # b: image 1 keeps < 10 % of its gt > 0 pixels inside the mask (nearly all >= 192): the per-image wrapper skips it (metrics.py:31-32)
+    gt = torch.rand((3, 16, 32), generator=gen) * 180 + 5
+    gt[1] = 195 + torch.rand((16, 32), generator=gen) * 20
+    gt[1, 0, :24] = 50.0                                   # 24 of 512 pixels = 4.7 % stay
+    est = gt + torch.randn(gt.shape, generator=gen) * 3
+    metric_case("b", est, gt)
+    # c: every image is skipped: the metrics return 0 (metrics.py:36-38); the loss is still the mean over the few masked pixels
+    gt = 200 + torch.rand((2, 8, 16), generator=gen) * 10
+    gt[:, 0, :4] = 100.0
+    est = gt - 1.7
+    metric_case("c", est, gt)
+    # d: exact thresholds: errors of exactly 1, 2, 3 px and 5 % (strict comparisons, metrics.py:46, 55)
+    gt = torch.full((1, 4, 8), 40.0)
+    est = gt.clone()
+    est[0, 0, :4] += torch.tensor([1.0, 2.0, 3.0, 3.5])
+    est[0, 1, :4] -= torch.tensor([1.0, 2.0, 3.0, 3.5])
+    gt[0, 2, :] = 100.0
+    est[0, 2, :4] = 100.0 + torch.tensor([3.0, 4.0, 5.0, 5.5])   # 5.5 / 100 > 0.05 and > 3
+    metric_case("d", est, gt)
+    save("g11_metrics", **arrays)
 
 
 if __name__ == "__main__":

@@ -554,6 +554,15 @@ def test_stereo_metrics_vs_oracle(ra, B, H, W, maxdisp, case):
         assert abs(got[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, got[k], v)
 
 
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_stereo_metrics_vs_reference_fixture(ra, case):
+    """The fused loss + metrics kernel against the REFERENCE's own numbers (g11: utilstool/metrics.py:21-65 + rag.py:418-430)."""
+    g = load_golden("g11_metrics")
+    got = ra.metrics.stereo_metrics(gpu(g[f"{case}::est"]), gpu(g[f"{case}::gt"]), 192).floats()
+    for k, v in zip(("loss", "EPE", "D1", "Thres1", "Thres2", "Thres3"), g[f"{case}::scalars"]):
+        assert abs(got[k] - v) <= 2e-5 * max(1.0, abs(v)), (case, k, got[k], v)
+
+
 def test_masked_smooth_l1_forward_backward(ra):
     est = (torch.rand((2, 36, 48), generator=gen(74)) * 30).requires_grad_(True)
     gt = torch.rand((2, 36, 48), generator=gen(75)) * 30
@@ -654,7 +663,7 @@ def test_bucket_direct_gradients_match_autograd_accumulation(ra):
 
 # --------------------------------------------------------------------------- the kernels the TRAINING BENCH runs (configs[4] sizes)
 # bench.py --train runs B=4 at 192x384, D=192: the level-3 volumes are 4 x 64 x 64 x 128 = 2^21 voxels, where the data gradient
-# (the forward kernel on the weight packed transposed / flipped) dispatches to the bf16x3 kernel and the weight gradient to the
+# (the forward kernel on the weight packed transposed / flipped) dispatches to the f16x3 kernel and the weight gradient to the
 # persistent-workgroup kernel with its partial-sum workspace.  The small cases above never reach those paths.
 L3_TRAIN = (4, 64, 64, 128)
 
@@ -670,11 +679,11 @@ def test_dgrad_transposed_pack_on_x3_at_training_size(ra, cin, cout):
     x = torch.zeros((B, cin, D, H, W), requires_grad=True)
     torch.set_num_threads(16)
     (ref,) = torch.autograd.grad(F.conv3d(x, w, padding=1), x, dy)
-    with ra.ops.conv_precision("bf16x3"):
+    with ra.ops.conv_precision("f16x3"):
         assert ra.ops.conv3d_k3_uses_x3(cout, cin, B, D, H, W)          # the gradient conv reads cout channels, writes cin
         dx = ra.ops.conv3d_k3(gpu(dy), ra.ops.conv3d_k3_pack(gpu(w), transpose=True), cin, None, None, False,
                               torch.empty((B, cin, D, H, W), device=DEV))
-    close(dx, ref, 2e-4, "dx (bf16x3, transposed pack)")
+    close(dx, ref, 2e-4, "dx (f16x3, transposed pack)")
     with ra.ops.conv_precision("fp32"):
         dx32 = ra.ops.conv3d_k3(gpu(dy), ra.ops.conv3d_k3_pack(gpu(w), transpose=True), cin, None, None, False,
                                 torch.empty((B, cin, D, H, W), device=DEV))
@@ -709,16 +718,16 @@ def _rel_err(got, ref64):
 # Sums over 2^21 voxels (and, end to end, a soft-argmin over costs of 1e3-1e4) are ill-conditioned in fp32: the CPU reference's OWN
 # fp32 results differ from an fp64 evaluation by up to 5e-3 of a tensor's largest gradient.  These tests therefore measure every
 # path against the fp64 evaluation and bound the GPU's error by a multiple of the error the reference's fp32 arithmetic makes on the
-# same inputs (floor: the tolerance of the small-shape tests): strict fp32 (RAGMI_F32) must sit in the same noise class, bf16x3
+# same inputs (floor: the tolerance of the small-shape tests): strict fp32 (RAGMI_F32) must sit in the same noise class, f16x3
 # (RAGMI_F32X3: ~30x the per-product rounding of fp32, include/rag_amd.h) may amplify it by the stated factor.
-NOISE_FACTOR = {"fp32": 2.5, "bf16x3": 12.0}
+NOISE_FACTOR = {"fp32": 2.5, "f16x3": 12.0}
 # Parameter gradients are sums over every voxel THROUGH the ReLU mask, and the mask is discontinuous: a pre-activation within the
 # forward error of zero flips it, which moves the sum by a whole |dy|.  With N voxels per channel, a forward error of eps relative
 # to the activation scale flips ~0.4 eps N of them (density of a unit normal at 0): at N = 2^21, fp32 (eps ~ 1e-7) flips < 1
-# element, bf16x3 (eps ~ 1e-5: 2^-16 per product, include/rag_amd.h) flips ~8, i.e. an absolute error of ~3 |dy| on sums of
+# element, f16x3 (eps ~ 1e-5: 2^-16 per product, include/rag_amd.h) flips ~8, i.e. an absolute error of ~3 |dy| on sums of
 # magnitude sqrt(N) ~ 1.4e3 — 2e-3 relative, independent of how well conditioned the sum is in fp32.  Measured 1.4e-3 (dw), 2.5e-3
 # (dbeta); elementwise results (y, dx) keep the 2e-4 floor.
-REDUCTION_FLOOR = {"fp32": 2e-4, "bf16x3": 6e-3}
+REDUCTION_FLOOR = {"fp32": 2e-4, "f16x3": 6e-3}
 
 
 def test_convbr_group_fn_at_training_size(ra):
@@ -752,7 +761,7 @@ def test_convbr_group_fn_at_training_size(ra):
     names = [f"y{i}" for i in range(n)] + ["dx"] + [f"{k}{i}" for i in range(n) for k in ("dw", "dgamma", "dbeta")]
     ref64, ref32 = reference(torch.float64), reference(torch.float32)
     noise = {k: _rel_err(r32, r64) for k, r32, r64 in zip(names, ref32, ref64)}
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "f16x3"):
         gm = [type(m)(C, C, 3, 1, 1) for m in mods]
         for a_, b_ in zip(gm, mods):
             a_.load_state_dict(b_.state_dict())
@@ -761,7 +770,7 @@ def test_convbr_group_fn_at_training_size(ra):
         xg = gpu(x).requires_grad_(True)
         params = [p for m in gm for p in (m.conv.weight, m.bn.weight, m.bn.bias)]
         with ra.ops.conv_precision(prec):
-            assert ra.ops.conv3d_k3_uses_x3(C, n * C, B, D, H, W) == (prec == "bf16x3")
+            assert ra.ops.conv3d_k3_uses_x3(C, n * C, B, D, H, W) == (prec == "f16x3")
             outs = ag.ConvBRGroupFn.apply(xg, tuple(gm), *params, *[gpu(r) for r in res])
             torch.autograd.backward(outs, [gpu(d) for d in dys])
         got = list(outs) + [xg.grad] + [p.grad for p in params]
@@ -777,7 +786,7 @@ def test_convbr_group_fn_at_training_size(ra):
 def test_matchingnet_train_step_at_reference_crop(ra):
     """One training step of the Matching Net at the reference's own crop (192x384, stereo_dataset.py:59-62; D = 192; one pair of
     run_rag.sh:17's batch of four): disparity, loss, feature gradients and every parameter gradient — at the sizes at which
-    bench.py --train's kernels are selected (level-3 volumes of 2^19 voxels: bf16x3 or fp32-MFMA forward and data-gradient
+    bench.py --train's kernels are selected (level-3 volumes of 2^19 voxels: f16x3 or fp32-MFMA forward and data-gradient
     convolutions, persistent weight-gradient kernel) — against the CPU oracle + PyTorch autograd evaluated in fp64, with the
     oracle's own fp32 evaluation as the noise yardstick.  approaches/rag.py:204-216."""
     from test_oracle_golden import oracle_train_step
@@ -813,14 +822,14 @@ def test_matchingnet_train_step_at_reference_crop(ra):
           f"{max(noise1.values()):.2e}; per-tensor ratio of the two CPU evaluations' errors: min {spread[0]:.2f} median {spread[len(spread) // 2]:.2f} "
           f"max {spread[-1]:.2f} over {len(spread)} tensors; EPE between the two CPU fp32 evaluations {O.epe(_d1, d32):.3e} px")
     epe_noise = O.epe(d32, d64)
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "f16x3"):
         net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=maxdisp)
         net.load_state_dict(sd, strict=True)
         net = net.to(DEV).train()
         net.stem3d0[0].eval()                                 # a reused unit, as in the oracle helper (rag.py:159-200)
         lf, rf = gpu(g["left_fea"]).requires_grad_(True), gpu(g["right_fea"]).requires_grad_(True)
         with ra.ops.conv_precision(prec):
-            assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 64, 128) == (prec == "bf16x3")
+            assert ra.ops.conv3d_k3_uses_x3(12, 12, 1, 64, 64, 128) == (prec == "f16x3")
             disp = net(lf, rf)
             loss = _smooth_l1_step(disp, gpu(g["gt"]), maxdisp)
             loss.backward()

@@ -302,20 +302,21 @@ def test_supernet_state_dict_matches_reference_and_genotype_parse():
 
 
 def test_conv_precision_names_and_aliases():
-    """"bf16x3" (round 2's name of the split form) stays the canonical setting; "f16x3" / "split" are aliases of it (since round 3
-    the halves are scaled fp16); anything else is refused; the context manager restores the previous setting."""
+    """"f16x3" is the canonical name of the split form (scaled fp16 halves since round 3); "bf16x3" (round 2's name) and "split"
+    are aliases of it; anything else is refused; the context manager restores the previous setting."""
     from rag_amd import ops
     old = ops.get_conv_precision()
     try:
         assert ops.set_conv_precision("fp32") == old
-        ops.set_conv_precision("f16x3")
-        assert ops.get_conv_precision() == "bf16x3"
+        ops.set_conv_precision("bf16x3")
+        assert ops.get_conv_precision() == "f16x3"
         with ops.conv_precision("fp32"):
             assert ops.get_conv_precision() == "fp32"
             with ops.conv_precision("split"):
-                assert ops.get_conv_precision() == "bf16x3"
+                assert ops.get_conv_precision() == "f16x3"
             assert ops.get_conv_precision() == "fp32"
-        assert ops.get_conv_precision() == "bf16x3"
+        assert ops.get_conv_precision() == "f16x3"
+        assert ops.set_conv_precision("f16x3") == "f16x3"
         with pytest.raises(ValueError):
             ops.set_conv_precision("fp16")
     finally:

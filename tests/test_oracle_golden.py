@@ -164,8 +164,19 @@ def test_g10_grown_model():
         np.testing.assert_allclose(disp.numpy(), g[f"search_disp_{tag}"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_stereo_metrics_vs_reference_fixture(case):
+    """g11: the reference's own EPE_metric / D1_metric / Thres_metric (utilstool/metrics.py:21-65) and the mask + loss of
+    approaches/rag.py:418-430, run by tests/golden/make_golden.py.  a: three ordinary images; b: one image dropped by the 10 %
+    rule; c: every image dropped (metrics 0); d: errors exactly on the thresholds (strict comparisons)."""
+    g = load_golden("g11_metrics")
+    m = O.stereo_metrics(torch.from_numpy(g[f"{case}::est"]), torch.from_numpy(g[f"{case}::gt"]), 192)
+    got = np.array([m[k] for k in ("loss", "EPE", "D1", "Thres1", "Thres2", "Thres3")])
+    np.testing.assert_allclose(got, g[f"{case}::scalars"], rtol=1e-6, atol=1e-7)
+
+
 def test_stereo_metrics_known_answer():
-    """Hand-computed case for the metrics restatement (utilstool/metrics.py:21-65 is not importable here: torchvision)."""
+    """Hand-computed case for the metrics restatement (kept beside the reference-generated fixture g11)."""
     gt = torch.tensor([[[10.0, 20.0, 0.0, 200.0]], [[300.0, 250.0, 5.0, 0.0]]])          # B=2, H=1, W=4, maxdisp 192
     est = torch.tensor([[[10.5, 24.0, 7.0, 100.0]], [[1.0, 2.0, 5.0, 9.0]]])
     # image 0: mask = [1,1,0,0], gt>0 = [1,1,0,1] -> ratio 0.75 (kept); errors 0.5, 4.0 (4 > 3 px and 20 % > 5 %)

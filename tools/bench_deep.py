@@ -16,7 +16,7 @@ for cs, cout, shape in [(16, 48, (1, 16, 32, 104)), (8, 24, (1, 32, 64, 208)), (
     wb = (torch.randn((cout, cs, 3, 3, 3), generator=g) * 0.1).to(dev)
     pa, pb = ops.conv3d_k3_pack(wa), ops.conv3d_k3_pack(wb)
     y = torch.empty((shape[0], cout) + shape[1:], device=dev)
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "f16x3"):
         with ops.conv_precision(prec):
             used = ops.conv3d_k3_uses_x3(2 * cs, cout, *shape, nset=2)
             for _ in range(3):

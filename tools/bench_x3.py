@@ -1,6 +1,6 @@
-"""bf16x3 convolution (conv3d_x3.hip) vs the fp32-MFMA kernel through the same entry point (profiling aid).
+"""f16x3 convolution (conv3d_x3.hip) vs the fp32-MFMA kernel through the same entry point (profiling aid).
 Run twice:  python tools/bench_x3.py   and   RAGMI_X3=0 python tools/bench_x3.py  (the variable only picks the DEFAULT precision
-of rag_amd.ops at import: bf16x3 / fp32; ops.conv_precision(...) is the API)"""
+of rag_amd.ops at import: f16x3 / fp32; ops.conv_precision(...) is the API)"""
 import os
 import sys
 import torch

@@ -1,4 +1,4 @@
-"""Single 3x3x3 convolutions on the SMALL (level-6 / level-12) volumes under the default precision (the deep-level bf16x3 form
+"""Single 3x3x3 convolutions on the SMALL (level-6 / level-12) volumes under the default precision (the deep-level f16x3 form
 of DESIGN.md 4.7 where the channel counts are 8 / 16 per set, the fp32-MFMA kernel otherwise); tools/bench_deep.py times the dual
 launches of the headline forward under both precisions."""
 import os

@@ -1,4 +1,4 @@
-"""A few level-3 dual-cell launches (4 + 4 -> 12 channels at 64x128x416, bf16x3) for counter passes:
+"""A few level-3 dual-cell launches (4 + 4 -> 12 channels at 64x128x416, f16x3) for counter passes:
     rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d out -- python3 tools/x3_dual_one.py"""
 import os
 import sys

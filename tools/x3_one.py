@@ -1,4 +1,4 @@
-"""One level-3 dual-cell-shaped bf16x3 launch set for counter passes (rocprofv3 --pmc ... -- python3 tools/x3_one.py)."""
+"""One level-3 dual-cell-shaped f16x3 launch set for counter passes (rocprofv3 --pmc ... -- python3 tools/x3_one.py)."""
 import os
 import sys
 import torch
