@@ -18,6 +18,8 @@ all: $(LIB)
 # the SLP vectorizer packs the soft-argmin's independent fp32 chains into v_pk_* pairs and pays for it in v_mov shuffles
 # (57 -> 47 us with it off); the cost-volume planes kernel gains from the same packing (54 us with, 60 without), so it stays on elsewhere.
 $(CSRC)/disp.o: CXXFLAGS += -fno-slp-vectorize
+# same for the single-output-channel convolution: 434 v_pk_fma_f32 + 160 v_mov_b32 instead of 864 v_fmac_f32 (packed fp32 issues at the same FLOP rate)
+$(CSRC)/conv3d_c1.o: CXXFLAGS += -fno-slp-vectorize
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv3d_k3.h $(CSRC)/conv3d_x3_common.h include/rag_amd.h
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@

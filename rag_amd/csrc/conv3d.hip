@@ -177,6 +177,7 @@ extern "C" int ragmi_conv3d_k3_small_fwd_ex(const void* x, int64_t x_bstride, co
   a.wp[0] = (const float*)weight; a.scale[0] = (const float*)scale; a.shift[0] = (const float*)shift;
   a.nchunks[0] = Cin / CK;
   a.store_main = 1;
+  if (c1_eligible(a, dtype, y_dtype)) return c1_launch(a, dtype, y_dtype, static_cast<hipStream_t>(stream));     // conv3d_c1.hip
   if (dtype == RAGMI_BF16 && y_dtype == RAGMI_F32) return launch_k3_valu_bf16_f32out(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));
   return dtype == RAGMI_BF16 ? launch_k3_valu_bf16(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream))
                              : launch_k3_valu_f32(a, choose_cfg(B, D, H, W), static_cast<hipStream_t>(stream));

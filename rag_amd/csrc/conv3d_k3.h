@@ -594,6 +594,9 @@ RAGMI_K3_DECL(s2_cfg2);
 int64_t x3_packed_words(int Cout, int Cin);
 // both sections of the packed weights (fp32-MFMA section of `total_k3` floats, then the bf16x3 fragments) in ONE launch
 // (`all` = false: the fp32-MFMA section only)
+// conv3d_c1.hip: the single-output-channel form (the head's last_3_3d at full resolution)
+bool c1_eligible(const K3Args& a, int dtype, int y_dtype);
+int c1_launch(const K3Args& k, int dtype, int y_dtype, hipStream_t st);
 int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, bool all, hipStream_t s);
 bool x3_eligible(const K3Args& a, int nset, int dtype);
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);

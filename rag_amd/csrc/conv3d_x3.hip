@@ -64,9 +64,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     int o[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int P = (q % (NSLS * 4)) * 2 + j, cgl = P / 27, tap = P % 27;
+      const int P = (q % (NSLS * 4)) * 2 + j, cgl = P % NCGS, tap = P / NCGS;      // tap-major pairs (x3_pack_one)
       const int slot = (ring + tap / 9) % 3;          // plane z+dz-1 sits in slot (ring + dz) % 3
-      o[j] = cgl < NCGS ? (((set * NCGS + cgl) * 3 + slot) * PLS + ((tap / 3) % 3) * RS + tap % 3) * (int)sizeof(uint2) : 0;
+      // (padding pairs — zero weights — read offset 0: a voxel of one of the three planes in the ring, inside the 3x3x3 window)
+      o[j] = tap < 27 ? (((set * NCGS + cgl) * 3 + slot) * PLS + ((tap / 3) % 3) * RS + tap % 3) * (int)sizeof(uint2) : 0;
     }
     loff[i] = make_int2(o[0], o[1]);
   }
@@ -363,19 +364,22 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 // Deep-level form (Matching-Net levels 6 and 12, rag_model.py:236-268: 8 or 16 input channels per set, volumes of 2^19 .. 2^16
 // voxels).  The z-marching kernel above starves there: its 8 x 32 columns give a level-12 volume (16 x 32 x 104) 16 columns, and
 // with 4-channel operand records every K-slice costs four 8-byte LDS reads, a table read and address arithmetic per lane.
-//  * Operand records are 8 CHANNELS of one voxel (16 bytes), [cg8][z][y][x] in LDS: one ds_read_b128 per operand, and because a
-//    lane quarter kb always reads the same (channel half, dx shift), every K-slice address is the lane's base plus a COMPILE-TIME
-//    immediate — no VALU work, no offset table.  K-slice = 32 = {dx, dx+1(, dx+2, dx+3)} x 8/16 channels of one (dz, dy) row; the
-//    fourth dx is a zero weight against the extra halo column (HX = TX + 3): 27 taps in 36 slots, 75 % of the K lanes carry work.
+//  * Operand records are 8 CHANNELS of one voxel (16 bytes), [cg8][z][y][x] in LDS: one ds_read_b128 per operand.  A K-slice (32) is
+//    4 taps x 8 channels or 2 taps x 16 channels, taps in their linear order (dz, dy, dx) — the tap-major pair order of the packed
+//    fragments (x3_pack_one), so the fragments are used as packed: 27 taps in 28 K slots (7 / 14 slices per set; round 3 used
+//    {dx .. dx+3} of one row per slice: 36 slots, 9 / 18 slices, and a fragment gather at every launch).  A lane quarter's record
+//    address for slice s is a per-lane constant of the launch (NSLS registers set up once): base + immediate in the K loop, no VALU
+//    work.  The padding slot (tap 27, zero weights) re-reads tap 26: a voxel INSIDE the 3x3x3 window, so a non-finite value can only
+//    reach outputs whose window holds it (round 3's fourth dx read one voxel past the window: Inf x 0 = NaN one voxel further).
 //  * Box tiles 2 x 8 x 16 (z, y, x): 16 column tiles = 8 waves x 2, so a level-12 volume is 224 boxes per output-channel block
-//    instead of 16 columns; the halo (4 x 10 x 19) comes from L2 (these volumes are 1.7-14 MB).
+//    instead of 16 columns; the halo (4 x 10 x 18) comes from L2 (these volumes are 1.7-14 MB).
 //  * One SET (input tensor) per stage: the box of set 0 is multiplied while set 1's travels HBM/L2 -> registers, and the LDS holds
-//    one set's box (24-49 KB) next to the workgroup's weight fragments, which stay resident for the whole launch (persistent
-//    workgroups; fragments are gathered from the z-marching layout of ragmi_conv3d_k3_pack at start, so the packed format is shared).
+//    one set's box (23-46 KB) next to the workgroup's weight fragments (28-56 KB), which stay resident for the whole launch
+//    (persistent workgroups; copied as packed by ragmi_conv3d_k3_pack).
 //  * Output-channel blocks of 16 ride blockIdx.y.  (Two blocks per workgroup sharing the operand reads were measured at level 6:
 //    64 us against 58 — their weights push the workgroup to 98 KB of LDS, one per CU, and the stages serialise.)
 constexpr int XD_TY = 8, XD_TX = 16;
-constexpr int XD_HY = XD_TY + 2, XD_HX = XD_TX + 3;
+constexpr int XD_HY = XD_TY + 2, XD_HX = XD_TX + 2;
 constexpr int64_t XD_MIN_VOXELS = 1 << 14;
 constexpr int XD_THREADS = 512;                        // 8 waves: wave w owns rows (w & 3) * 2, +1 of planes w >> 2 (, + 2)
 
@@ -387,10 +391,8 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
   static_assert(!WS || NSET == 2, "per-stage weights only pay with two sets");
   constexpr int XD_TZ = 2, XD_HZ = XD_TZ + 2, XD_PL = XD_HZ * XD_HY * XD_HX, XD_NT = XD_TZ;
   constexpr bool BF = std::is_same<T, bf16_t>::value;
-  constexpr int SPR = CH8;                              // K-slices per (dz, dy) row: 8 ch -> dx 0..3 in one, 16 ch -> {0,1} and {2,3}
-  constexpr int NSLS = 9 * SPR;                         // slices per set
   constexpr int NCG4 = 2 * CH8;                         // 4-channel groups per set: the staging unit and the packed fragments' unit
-  constexpr int NSLS_V1 = (NCG4 * 27 + 7) / 8;          // slices per set in the packed (z-marching) fragment layout
+  constexpr int NSLS = (NCG4 * 27 + 7) / 8;             // K-slices per set, as packed: 7 (8 channels: 4 taps each) or 14 (16: 2 taps)
   constexpr int NPF = (NCG4 * XD_PL + XD_THREADS - 1) / XD_THREADS;
   constexpr int REC = CH8 * XD_PL;                      // 16-byte records per copy (hi or lo)
   extern __shared__ __attribute__((aligned(16))) uint4 xd_lds[];
@@ -405,43 +407,18 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
   float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
   asm volatile("" : "+v"(act_floor));      // opaque: otherwise the compiler turns max(u, floor) back into max(u, 0) + a select per value
   const int64_t DHW = (int64_t)HW * a.D;
-  // weight fragments of this workgroup's output blocks: A[row = lane & 15][k = 8 kb + j] = w[co][channel 8 cg8 + j][tap (dz, dy, dx)],
-  // (cg8, dx) from the lane quarter and the slice; gathered in 8-byte halves (4 channels of one tap) from the packed fragments
-  // (nine gathers in flight per thread: as a plain loop the 18 trips each waited out an L2 round trip — 10 of the 40 us of a
-  // level-12 launch were this prologue)
-  constexpr int NWS = COGS * NSLS * 2 * 64 * 2;          // 8-byte halves of one set's fragments
-  constexpr int NWT = (NWS + XD_THREADS - 1) / XD_THREADS;   // ... per thread (9 for 18 K-slices x 1 block or 9 x 2)
-  int wsrc[NWT];                                         // source (in 8-byte units from e.wf[set]) of this thread's halves, -1: a zero
-#pragma unroll
-  for (int u = 0; u < NWT; ++u) {
-    const int i = min(tid + u * XD_THREADS, NWS - 1);
-    const int half = i & 1;
-    int q = i >> 1;
-    const int ln = q & 63; q >>= 6;
-    const int hl = q & 1; q >>= 1;
-    const int sl = q % NSLS, cl = q / NSLS;
-    const int m = ln & 15, kq = ln >> 4;
-    const int cg8 = CH8 == 2 ? (kq & 1) : 0, dx = 2 * (sl % SPR) + (CH8 == 2 ? (kq >> 1) : kq);
-    const int tap = (sl / SPR) * 3 + min(dx, 2);        // (dz * 3 + dy) * 3 + dx
-    const int P = (2 * cg8 + half) * 27 + tap;          // pair index of the packed layout: 4-channel group * 27 + tap
-    const int src = ((((min(cog0 + cl, ncog - 1) * NSLS_V1 + (P >> 3)) * 2 + hl) * 64 + ((P & 7) >> 1) * 16 + m) << 1) + (P & 1);
-    wsrc[u] = (dx < 3 && cog0 + cl < ncog) ? src : -1;
-  }
-  uint2 wv[NWT];
-  auto wfetch = [&](int set) {                           // unconditional (clamped) loads, zeroed at the commit: straight-line code
-    const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set]);
-#pragma unroll
-    for (int u = 0; u < NWT; ++u) wv[u] = src[max(wsrc[u], 0)];
-  };
-  auto wcommit = [&](int region) {
-    uint2* const dst = reinterpret_cast<uint2*>(lw) + region * NWS;
-#pragma unroll
-    for (int u = 0; u < NWT; ++u)
-      if (tid + u * XD_THREADS < NWS) dst[tid + u * XD_THREADS] = wsrc[u] >= 0 ? wv[u] : make_uint2(0u, 0u);
+  // weight fragments of this workgroup's output blocks, as packed (tap-major pairs: lane quarter kb of slice s holds the 8 channels
+  // 8 (kb & 1) .. +7 of tap 2 s + (kb >> 1) for 16 channels per set, all 8 channels of tap 4 s + kb for 8)
+  constexpr int NWS = COGS * NSLS * 2 * 64;              // uint4 words of one set's fragments
+  auto wcopy = [&](int set, int region) {
+    for (int i = tid; i < NWS; i += XD_THREADS) {
+      const int cl = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
+      lw[region * NWS + i] = cog0 + cl < ncog ? e.wf[set][(int64_t)(cog0 + cl) * NSLS * 2 * 64 + r] : make_uint4(0u, 0u, 0u, 0u);
+    }
   };
   if constexpr (!WS) {
 #pragma unroll
-    for (int set = 0; set < NSET; ++set) { wfetch(set); wcommit(set); }
+    for (int set = 0; set < NSET; ++set) wcopy(set, set);
   }
   for (int i = tid; i < NSET * COGS * 16; i += XD_THREADS) {
     const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
@@ -499,7 +476,14 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
   };
   // this wave's two column tiles: rows (tz, ty0) and (tz, ty0 + 1) of the box; lane quarter -> (channel half, dx shift)
   const int tz = wave >> 2, ty0 = (wave & 3) * 2;
-  const int vb0 = (((CH8 == 2 ? (kb & 1) : 0) * XD_PL) + (tz * XD_HY + ty0) * XD_HX + n + (CH8 == 2 ? (kb >> 1) : kb)) * (int)sizeof(uint4);
+  const int vb0 = (((CH8 == 2 ? (kb & 1) : 0) * XD_PL) + (tz * XD_HY + ty0) * XD_HX + n) * (int)sizeof(uint4);
+  // this lane quarter's operand record of every K-slice: its tap's (dz, dy, dx) offset in the box, fixed for the launch
+  int vsl[NSLS];
+#pragma unroll
+  for (int sl = 0; sl < NSLS; ++sl) {
+    const int tap = min(CH8 == 2 ? 2 * sl + (kb >> 1) : 4 * sl + kb, 26);         // the padding slot re-reads tap 26 (zero weights)
+    vsl[sl] = vb0 + ((tap / 9 * XD_HY + (tap / 3) % 3) * XD_HX + tap % 3) * (int)sizeof(uint4);
+  }
   const char* const lbytes = reinterpret_cast<const char*>(xd_lds);
   constexpr int LO_BYTES = REC * (int)sizeof(uint4);
   const int ngroups = (a.Cout + 3) >> 2;
@@ -525,7 +509,6 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
     decode(work_of(j), b, z0, y0, x0);
     locate(z0, y0, x0);
     prefetch(x + b * a.x_bstride, 0);
-    if constexpr (WS) wfetch(0);
   }
 #ifdef RAGMI_DIAG
   const bool diag_nostore = (a.relu & 0x100) != 0, diag_nomfma = (a.relu & 0x200) != 0, diag_nostage = (a.relu & 0x400) != 0;
@@ -568,7 +551,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
         inv_mul[st] = 1.f / mul;
       }
       if (!diag_nostage) commit(mul);
-      if constexpr (WS) wcommit(0);
+      if constexpr (WS) wcopy(st, 0);
       __syncthreads();
       if constexpr (!BF) {
         if (tid == 0) lmaxp[(stage + 2) % 3] = 0u;
@@ -578,19 +561,17 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
         if constexpr (st + 1 < NSET) prefetch(x + b * a.x_bstride, st + 1);
         else { locate(zn, yn, xn); prefetch(x + bn * a.x_bstride, 0); }
       }
-      if constexpr (WS) wfetch((st + 1) % NSET);
       __builtin_amdgcn_sched_barrier(0);               // the loads stay ahead of the MFMA block
       if (!diag_nomfma)
 #pragma unroll
       for (int sl = 0; sl < NSLS; ++sl) {
         constexpr int ROWB = XD_HX * (int)sizeof(uint4);
-        const int off = (((sl / SPR) / 3 * XD_HY + (sl / SPR) % 3) * XD_HX + 2 * (sl % SPR)) * (int)sizeof(uint4);   // compile time
         uint4 bh[XD_NT], bl[XD_NT];
 #pragma unroll
         for (int i = 0; i < XD_NT; ++i) {
           const int d = (i & 1) * ROWB + (i >> 1) * 2 * XD_HY * ROWB;        // compile time: tile i = row +(i & 1), plane +2 (i >> 1)
-          bh[i] = *reinterpret_cast<const uint4*>(lbytes + vb0 + off + d);
-          if constexpr (!BF) bl[i] = *reinterpret_cast<const uint4*>(lbytes + vb0 + off + d + LO_BYTES);
+          bh[i] = *reinterpret_cast<const uint4*>(lbytes + vsl[sl] + d);
+          if constexpr (!BF) bl[i] = *reinterpret_cast<const uint4*>(lbytes + vsl[sl] + d + LO_BYTES);
         }
 #pragma unroll
         for (int cl = 0; cl < COGS; ++cl) {
@@ -652,7 +633,7 @@ template <class T, int CH8, int NSET, int COGS, bool WS>
 static int x3d_launch_one(K3Args a, X3Extra e, hipStream_t st) {
   constexpr int PL = 4 * XD_HY * XD_HX;
   constexpr size_t lds = (size_t)(std::is_same<T, bf16_t>::value ? 1 : 2) * CH8 * PL * sizeof(uint4) +
-                         (size_t)(WS ? 1 : NSET) * COGS * 9 * CH8 * 2 * 64 * sizeof(uint4) + (size_t)(2 * NSET * COGS * 16 + 4) * sizeof(float);
+                         (size_t)(WS ? 1 : NSET) * COGS * ((2 * CH8 * 27 + 7) / 8) * 2 * 64 * sizeof(uint4) + (size_t)(2 * NSET * COGS * 16 + 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "deep-level tile does not fit the LDS");
   a.tiles_x = (int)ceil_div(a.W, XD_TX); a.tiles_y = (int)ceil_div(a.H, XD_TY); a.tiles_z = (int)ceil_div(a.D, 2);
   const int64_t nwork = (int64_t)a.tiles_x * a.tiles_y * a.tiles_z * a.B;
@@ -682,6 +663,9 @@ int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   // from L2 with every box, so that two workgroups still fit a CU): 72.8 us against 57.5 for the level-6 launch — at the 128-VGPR
   // cap of four waves per SIMD the kernel spills 37 registers, and the per-stage weight loads sit in front of every stage.
 #define RAGMI_XD(CH8_, NSET_, COGS_, WS_) (bf ? x3d_launch_one<bf16_t, CH8_, NSET_, COGS_, WS_>(a, e, st) : x3d_launch_one<float, CH8_, NSET_, COGS_, WS_>(a, e, st))
+#ifdef RAGMI_XD_COGS2      // A/B build: both output blocks of a level-6 dual cell in one workgroup (56 + 23 KB of LDS: two workgroups per CU)
+  if (ch8 == 1 && nset == 2 && a.Cout > 16) return RAGMI_XD(1, 2, 2, false);
+#endif
   if (ch8 == 1) return nset == 2 ? RAGMI_XD(1, 2, 1, false) : RAGMI_XD(1, 1, 1, false);
   return nset == 2 ? RAGMI_XD(2, 2, 1, false) : RAGMI_XD(2, 1, 1, false);
 #undef RAGMI_XD

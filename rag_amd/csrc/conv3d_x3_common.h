@@ -106,7 +106,10 @@ __device__ __forceinline__ float x3_wave_max(float m) {
 
 // packed weight fragments of ONE accumulator set (a conv with Cout outputs and Cin = 4 * ncgs inputs):
 // wf[((cog * nsls + s) * 2 + hl) * 64 + lane] (uint4 = 8 halves): A[row = lane & 15][k = 8 (lane>>4) + j],
-// k -> pair P = 8 s + 2 (lane>>4) + (j>>2) = cg * 27 + tap, channel 4 cg + (j&3).  The source is indexed like the fp32
+// k -> pair P = 8 s + 2 (lane>>4) + (j>>2) = tap * ncgs + cg (TAP-MAJOR since round 4), channel 4 cg + (j&3); pairs past 27 * ncgs
+// are zeros.  Tap-major puts the 8 (16) channels of ONE tap into one (two) lane quarter(s) of a slice, which is exactly the operand
+// record of the deep-level kernel: both kernels read the same fragments, 27 taps in 28 K slots for 8 / 16 channels.
+// The source is indexed like the fp32
 // pack (transpose / planar options of ragmi_conv3d_k3_pack_ex).  Two sections: bf16 halves of w (bf16 activation storage),
 // then fp16 halves of w * 2^k[co] followed by the per-output-channel multipliers 2^-k[co] (fp32 storage, RAGMI_F32X3).
 __device__ __forceinline__ float x3_w_at(const float* __restrict__ w, int Cout, int Cin, int co, int ci, int tap, int transpose, int planar) {
@@ -146,8 +149,8 @@ __device__ __forceinline__ void x3_pack_one(const float* __restrict__ w, uint4* 
   if (half && s == 0 && kb == 0) wmul[cog * 16 + (lane & 15)] = 1.f / mul;
   unsigned short hi[8], lo[8];
   for (int j = 0; j < 8; ++j) {
-    const int P = 8 * s + 2 * kb + (j >> 2), cg = P / 27, tap = P % 27, ci = 4 * cg + (j & 3);
-    const float v = x3_w_at(w, Cout, Cin, co, ci, tap, transpose, planar) * mul;
+    const int ncgs = (Cin + 3) / 4, P = 8 * s + 2 * kb + (j >> 2), cg = P % ncgs, tap = P / ncgs, ci = 4 * cg + (j & 3);
+    const float v = tap < 27 ? x3_w_at(w, Cout, Cin, co, ci, tap, transpose, planar) * mul : 0.f;
     if (half) {
       hi[j] = x3_f16_bits(v);
       lo[j] = x3_f16_bits(v - (float)__builtin_bit_cast(_Float16, hi[j]));

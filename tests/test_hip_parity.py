@@ -193,6 +193,33 @@ def test_conv3d_k3_small_vs_oracle(ra, cin, cout, shape):
     np.testing.assert_allclose(out.cpu().numpy(), exp.numpy(), **TOL)
 
 
+@pytest.mark.parametrize("cin,shape,dtype,bn", [
+    (12, (1, 64, 128, 416), "f32", False),     # last_3_3d of the headline forward (rag_model.py:269, :361-365)
+    (12, (2, 9, 140, 260), "f32", True),       # two pairs; partial tiles in y and x, a partial last depth segment, folded BN + ReLU
+    (4, (1, 33, 129, 64), "f32", False),       # one row past a tile border
+    (12, (1, 16, 64, 256), "bf16", False)])    # bf16 activation storage, fp32 output (the head's `mat` stays fp32)
+def test_conv3d_c1_single_output_channel_form(ra, cin, shape, dtype, bn):
+    """conv3d_c1_kernel (input-stationary z-marching VALU form, Cout = 1, volumes >= 2^18 voxels per sample, W % 4 == 0) behind
+    ragmi_conv3d_k3_small_fwd_ex, against F.conv3d in float64; written into a channel slice of a wider buffer."""
+    B, D, H, W = shape
+    assert D * H * W >= 1 << 18 and W % 4 == 0
+    bf = dtype == "bf16"
+    x = torch.randn((B, cin, D, H, W), generator=gen(35))
+    if bf:
+        x = x.to(torch.bfloat16)
+    w = torch.randn((1, cin, 3, 3, 3), generator=gen(36)) * (2.0 / (27 * cin)) ** 0.5
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    scale = shift = None
+    if bn:
+        scale, shift = torch.rand(1, generator=gen(37)) + 0.5, torch.randn(1, generator=gen(38)) * 0.1
+        ref = F.relu(ref * scale.double() + shift.double())
+    out = torch.full((B, 3, D, H, W), float("nan"), device=DEV)
+    ra.ops.conv3d_k3_small(gpu(x), gpu(w), gpu(scale) if bn else None, gpu(shift) if bn else None, bn, out, 1)
+    got = out.cpu()
+    assert torch.isnan(got[:, 0]).all() and torch.isnan(got[:, 2]).all()         # the neighbouring channels are untouched
+    np.testing.assert_allclose(got[:, 1:2].double().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("dual", [False, True])
 @pytest.mark.parametrize("store_main", [True, False])
 @pytest.mark.parametrize("shape", [(1, 5, 9, 33), (2, 4, 8, 20), (1, 64, 16, 64)])
