@@ -149,6 +149,102 @@ __global__ __launch_bounds__(256) void disp_softargmin_x3_kernel(DispArgs a) {
   if (ox0 + tx < a.Wo && oy0 + ty < a.Ho) a.out[(int64_t)b * a.Ho * a.Wo + (int64_t)oy * a.Wo + ox] = ws / s;
 }
 
+// The wavefront-reduction form north_star names, for the same configuration (maxdisp = 3 d, 3x upsampling): 16 lanes share one
+// output pixel, lane l owns the coarse planes 4l .. 4l+3 (d <= 64) and their 12 fine samples; a wave step is 4 pixels.
+//  * per step a lane takes 4 bilinear plane samples (16 LDS reads — the thread-per-pixel form makes 2 x 4 d = 512 per pixel, plus a
+//    broadcast tap-table read per fine sample) and gets the two neighbouring planes' samples from the lanes beside it (DPP row shifts);
+//  * its 12 (wp, wc, wn, dd) tap entries are per-lane constants of the whole launch (registers), built with the same lin_index
+//    arithmetic as the tap table of the tiled kernel;
+//  * minimum, sum of exponentials and weighted sum are reduced over the 16 lanes of a DPP row (4 steps each, no LDS).
+// Same reference exponent (the minimum over the coarse plane samples) and the same per-sample arithmetic as the tiled kernel; only
+// the order of the two final sums differs (per lane, then across lanes).
+__device__ __forceinline__ float dpp_row_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));    // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));    // row_mirror
+  return v;
+}
+__device__ __forceinline__ float dpp_row_min(float v) {
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
+  return v;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void disp_softargmin_wave_kernel(DispArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dxw_lds[];
+  float* const tile = dxw_lds;                                         // [d][5][13]: plane stride 65 = 1 mod 32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = lane & 15, pq = lane >> 4;
+  const int ox0 = blockIdx.x * DX3_TX, oy0 = blockIdx.y * DX3_TY, b = blockIdx.z;
+  const int cy0 = lin_index(oy0, a.h, a.Ho, a.sh, 0).i0, cx0 = lin_index(ox0, a.w, a.Wo, a.sw, 0).i0;
+  const int hw = a.h * a.w, D = a.d;
+  const T* base = static_cast<const T*>(a.cost) + (int64_t)b * D * hw;
+  for (int i = tid; i < D * DX3_CP; i += 256) {
+    const int z = i / DX3_CP, r = i % DX3_CP;
+    const int gy = min(cy0 + r / DX3_CC, a.h - 1), gx = min(cx0 + r % DX3_CC, a.w - 1);
+    tile[i] = ld(base + (int64_t)z * hw + gy * a.w + gx);
+  }
+  // lane l owns the coarse planes k = l + 16 q (q = 0..3): the 16 lanes of a pixel read 16 CONSECUTIVE planes at a time, one bank
+  // each.  Its 12 fine samples dd = 3 k + j: weights of the window (plane k-1, k, k+1) — per-lane constants of the launch
+  float wp[12], wc[12], wn[12], fd[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int k = l + 16 * (i / 3), dd = 3 * k + i % 3;
+    const LinIdx lz = lin_index(min(dd, a.maxdisp - 1), D, a.maxdisp, a.sd, 0);
+    wp[i] = wc[i] = wn[i] = 0.f;
+    fd[i] = (float)dd;
+    if (k < D && dd < a.maxdisp) {
+      if (lz.i0 < k) { wp[i] = lz.w0; wc[i] = lz.w1; }
+      else if (lz.i1 != lz.i0) { wc[i] = lz.w0; wn[i] = lz.w1; }
+      else wc[i] = lz.w0 + lz.w1;
+    }
+  }
+  __syncthreads();
+  constexpr float K = 1.4426950408889634f;
+  for (int step = 0; step < 16; ++step) {
+    const int idx = step * 4 + pq, ty = wave * 2 + (idx >> 5), tx = idx & 31;
+    const int ox = min(ox0 + tx, a.Wo - 1), oy = min(oy0 + ty, a.Ho - 1);
+    const LinIdx ly = lin_index(oy, a.h, a.Ho, a.sh, 0);
+    const LinIdx lx = lin_index(ox, a.w, a.Wo, a.sw, 0);
+    const float* const t00 = tile + (ly.i0 - cy0) * DX3_CC + (lx.i0 - cx0);
+    const int o01 = lx.i1 - lx.i0, o10 = (ly.i1 - ly.i0) * DX3_CC;
+    float v[4], vm[4], vx[4];
+    float lo = INFINITY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = l + 16 * q;
+      const float* const t = t00 + min(k, D - 1) * DX3_CP;
+      v[q] = ly.w0 * (lx.w0 * t[0] + lx.w1 * t[o01]) + ly.w1 * (lx.w0 * t[o10] + lx.w1 * t[o10 + o01]);
+      lo = k < D ? fminf(lo, v[q]) : lo;
+    }
+    // plane k-1 / k+1: the lane before / after in the pixel's row, same q — across the row's ends it is q -/+ 1 of the lane at the other end
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vm[q] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[q]), 0x121, 0xF, 0xF, false));   // row_ror:1: lane l <- lane l-1 (0 <- 15)
+      vx[q] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[q]), 0x12F, 0xF, 0xF, false));   // row_ror:15: lane l <- lane l+1 (15 <- 0)
+    }
+    lo = dpp_row_min(lo);
+    float s = 0.f, ws = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int q = i / 3;
+      const float vp_ = l == 0 ? (q == 0 ? v[0] : vm[q - 1]) : vm[q];         // (plane -1 does not exist: its weight is 0)
+      const float vn_ = l == 15 ? (q == 3 ? v[3] : vx[q + 1]) : vx[q];
+      const float c = fmaf(wp[i], vp_, fmaf(wc[i], v[q], wn[i] * vn_));
+      float e = __builtin_amdgcn_exp2f((lo - c) * K);
+      e = (wp[i] + wc[i] + wn[i]) > 0.f ? e : 0.f;                     // samples past maxdisp / the volume (d < 64)
+      s += e;
+      ws = fmaf(e, fd[i], ws);
+    }
+    s = dpp_row_sum(s);
+    ws = dpp_row_sum(ws);
+    if (l == 0 && ox0 + tx < a.Wo && oy0 + ty < a.Ho) a.out[(int64_t)b * a.Ho * a.Wo + (int64_t)oy * a.Wo + ox] = ws / s;
+  }
+}
+
 // standalone DisparityRegression: out = sum_d prob[:, d] * d
 template <class T>
 __global__ __launch_bounds__(256) void disparity_regression_kernel(const T* __restrict__ prob, float* __restrict__ out,
@@ -181,6 +277,14 @@ extern "C" int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int
   const size_t lds3 = lds + (size_t)d * DX3_CP * sizeof(float);
   if (maxdisp == 3 * d && Ho == 3 * h && Wo == 3 * w && lds3 <= 64 * 1024) {   // the reference's configuration (rag_model.py:40, 272-273): the tiled form
     const dim3 g3((unsigned)ceil_div(Wo, DX3_TX), (unsigned)ceil_div(Ho, DX3_TY), (unsigned)B);
+#ifdef RAGMI_DISP_WAVE      // A/B build (tools/build_variant.sh): the wavefront-reduction form, d <= 64
+    if (d <= 64) {
+      const size_t ldsw = (size_t)d * DX3_CP * sizeof(float);
+      if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_wave_kernel<bf16_t>, g3, dim3(256), ldsw, static_cast<hipStream_t>(stream), a);
+      else hipLaunchKernelGGL(disp_softargmin_wave_kernel<float>, g3, dim3(256), ldsw, static_cast<hipStream_t>(stream), a);
+      return check_launch("disp_softargmin");
+    }
+#endif
     if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_x3_kernel<bf16_t>, g3, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(disp_softargmin_x3_kernel<float>, g3, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
     return check_launch("disp_softargmin");
