@@ -307,7 +307,10 @@ int ragmi_disparity_regression_fwd(const void* prob, void* out, int B, int D, in
  *   ragmi_costvol_stem_prepare: weight [Cout, 2C, 3,3,3] fp32 -> `variants` (ragmi_costvol_stem_weights_elems floats)
  *   ragmi_costvol_stem_fwd:     left/right [B,C,H,W] (dtype) -> y[B, Cout(+), D, H, W] = act(scale*(conv)+shift) (channels 0..Cout-1,
  *                               batch stride y_bstride), optional fused consumer 1x1x1 tails as in ragmi_conv3d_k3_fwd_ex;
- *                               `workspace`: ragmi_costvol_stem_workspace_elems floats.  C, Cout <= 16. */
+ *                               `workspace`: ragmi_costvol_stem_workspace_elems floats.  C, Cout <= 16.
+ *                               dtype RAGMI_F32 / RAGMI_BF16: the A / B planes by fp32 FMAs (exact products); RAGMI_F32X3 (fp32
+ *                               storage): the planes as split-operand products on the 16-bit matrix cores under the bound
+ *                               documented for the 3x3x3 convolutions above, when C % 4 == 0 and C <= 12 (else as RAGMI_F32). */
 int64_t ragmi_costvol_stem_weights_elems(int C, int Cout);
 int ragmi_costvol_stem_prepare(const void* weight, void* variants, int C, int Cout, void* stream);
 int64_t ragmi_costvol_stem_workspace_elems(int B, int C, int Cout, int D, int H, int W);

@@ -663,7 +663,12 @@ int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   // from L2 with every box, so that two workgroups still fit a CU): 72.8 us against 57.5 for the level-6 launch — at the 128-VGPR
   // cap of four waves per SIMD the kernel spills 37 registers, and the per-stage weight loads sit in front of every stage.
 #define RAGMI_XD(CH8_, NSET_, COGS_, WS_) (bf ? x3d_launch_one<bf16_t, CH8_, NSET_, COGS_, WS_>(a, e, st) : x3d_launch_one<float, CH8_, NSET_, COGS_, WS_>(a, e, st))
-#ifdef RAGMI_XD_COGS2      // A/B build: both output blocks of a level-6 dual cell in one workgroup (56 + 23 KB of LDS: two workgroups per CU)
+  // 8 channels per set, two sets, more than one output block (the level-6 dual cells: 8 + 8 -> 24): BOTH blocks in one workgroup —
+  // every operand record is read once for two blocks' MFMAs (0.67 LDS reads per MFMA instead of 1) and the box is staged once
+  // instead of twice.  With the fragments as packed (7 slices per set) that is 56 + 23 KB of LDS: two workgroups per CU still fit.
+  // Same box, both builds (tools/ab_bench.sh): level-6 launch 58.9 -> 46.0 us, step 1.225 -> 1.200 ms.  (Round 2 measured the same
+  // idea at 9 slices per set — 98 KB, one workgroup per CU — and lost: 64 vs 58 us.)
+#ifndef RAGMI_XD_COGS1
   if (ch8 == 1 && nset == 2 && a.Cout > 16) return RAGMI_XD(1, 2, 2, false);
 #endif
   if (ch8 == 1) return nset == 2 ? RAGMI_XD(1, 2, 1, false) : RAGMI_XD(1, 1, 1, false);

@@ -18,7 +18,7 @@
 //   costvol_stem_weights : the pre-summed weight variants (once per weight version)
 //   costvol_stem_planes  : the variant planes (VALU, input tile + variant weights in LDS)
 //   costvol_stem_combine : out = act(scale * (A + B) + shift) (+ fused consumer 1x1x1 tails), HBM-write-bound
-#include "common.h"
+#include "conv3d_x3_common.h"
 
 namespace ragmi {
 
@@ -67,6 +67,7 @@ struct PlaneDesc {
   int width;      // plane width (xi = 0..width-1)
   int x0;         // source column of xi = 0
   int right;      // 0: left features, 3 taps (kh = 1);  1: right features, 5 taps (kh = 2)
+  int variant;    // index of the variant's weight fragments / multipliers (matrix-core form)
 };
 constexpr int CS_MAXDESC = 32;
 struct PlanesArgs {
@@ -165,6 +166,154 @@ __global__ __launch_bounds__(CS_NT) void costvol_stem_planes_kernel(PlanesArgs a
 #pragma unroll
     for (int p = 0; p < CS_PX; ++p)
       if (xb + xx + p < d.width) out[(int64_t)co * a.H * d.width + p] = acc[p][co];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The variant planes on the 16-bit matrix cores (RAGMI_F32X3: the split-operand contract of conv3d_x3.hip — fp32 operands as two
+// power-of-two-scaled FP16 halves, hi*hi + hi*lo + lo*hi, fp32 accumulation).  The VALU kernel above spends 53 us on 1.5 GFLOP
+// (one broadcast LDS read per 8 FMAs); as 16x16x32 products the same planes are ~0.4 M MFMAs, a few microseconds of matrix time.
+//   rows = 16 output channels, columns = 16 consecutive plane columns xi, K = 8 pairs of (tap, 4-channel group) x 4 channels,
+//   pairs tap-major: P = tap * (C / 4) + cg, tap = dy * ntap + k  (A planes: 9 taps, B planes: 15)
+// Weight fragments per variant (packed once per weight version by costvol_stem_pack_kernel, after the fp32 variants):
+//   wf[((v * NS + s) * 2 + hl) * 64 + lane] (uint4 = 8 halves of w * 2^k[co]),  wmul[v * 16 + co] = 2^-k[co]
+// with v = cls * CS_NTC + tcidx (A, NS = CS_NSA slices) or CS_NCLS * CS_NTC + cls * 2 + xr (B, CS_NSB slices: slots of CS_NSB each).
+constexpr int CS_NVA = CS_NCLS * CS_NTC, CS_NVB = CS_NCLS * 2;
+__host__ __device__ constexpr int cs_nslices(int C, int ntap) { return ((C / 4) * 3 * ntap + 7) / 8; }
+__host__ __device__ inline int64_t cs_frag_words(int C) {   // floats of all fragment slots + multipliers
+  return ((int64_t)CS_NVA * cs_nslices(C, 3) + (int64_t)CS_NVB * cs_nslices(C, 5)) * 2 * 64 * 4 + (int64_t)(CS_NVA + CS_NVB) * 16;
+}
+
+__global__ __launch_bounds__(256) void costvol_stem_pack_kernel(const float* __restrict__ variants, float* __restrict__ frag, int C, int Cout) {
+  const int v = blockIdx.x, isb = v >= CS_NVA ? 1 : 0, ntap = isb ? 5 : 3, ncg = C / 4;
+  const int ns = cs_nslices(C, ntap);
+  const int na = CS_NCLS * CS_NTC * C * 9 * Cout;
+  const float* const w = isb ? variants + na + (int64_t)(v - CS_NVA) * C * 15 * Cout : variants + (int64_t)v * C * 9 * Cout;   // [c][dy][k][co]
+  __shared__ unsigned rowmax[16];
+  if (threadIdx.x < 16) rowmax[threadIdx.x] = 0u;
+  __syncthreads();
+  const int nw = C * 3 * ntap * Cout;
+  for (int i = threadIdx.x; i < nw; i += 256) atomicMax(&rowmax[i % Cout], __float_as_uint(fabsf(w[i])));
+  __syncthreads();
+  const int nsa = cs_nslices(C, 3), nsb = cs_nslices(C, 5);
+  uint4* const wf = reinterpret_cast<uint4*>(frag) + (isb ? ((int64_t)CS_NVA * nsa + (int64_t)(v - CS_NVA) * nsb) : (int64_t)v * nsa) * 2 * 64;
+  float* const wmul = frag + ((int64_t)CS_NVA * nsa + (int64_t)CS_NVB * nsb) * 2 * 64 * 4 + v * 16;
+  if (threadIdx.x < 16) wmul[threadIdx.x] = threadIdx.x < Cout ? 1.f / x3_row_mul(rowmax[threadIdx.x]) : 1.f;
+  for (int idx = threadIdx.x; idx < ns * 64; idx += 256) {
+    const int lane = idx & 63, sl = idx >> 6, co = lane & 15, kb = lane >> 4;
+    const float mul = co < Cout ? x3_row_mul(rowmax[co]) : 1.f;
+    unsigned short hi[8], lo[8];
+    for (int j = 0; j < 8; ++j) {
+      const int P = 8 * sl + 2 * kb + (j >> 2), tap = P / ncg, cg = P % ncg, c = 4 * cg + (j & 3);
+      const float val = (tap < 3 * ntap && co < Cout) ? w[((c * 3 + tap / ntap) * ntap + tap % ntap) * Cout + co] * mul : 0.f;
+      hi[j] = x3_f16_bits(val);
+      lo[j] = x3_f16_bits(val - (float)__builtin_bit_cast(_Float16, hi[j]));
+    }
+    auto pk = [](const unsigned short* h) {
+      return make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    };
+    wf[(sl * 2 + 0) * 64 + lane] = pk(hi);
+    wf[(sl * 2 + 1) * 64 + lane] = pk(lo);
+  }
+}
+
+// One workgroup (256 threads) = an 8 x 64 tile of one variant plane set: the (10 x 68) halo of all C feature channels goes
+// HBM -> registers -> (largest |x| of the tile -> operand scale 2^-e) -> FP16 hi / lo records [cg][row][x][4 ch] in LDS; wave w then
+// owns rows 2w, 2w+1 (8 column tiles of 16), its weight fragments (NS slices, hi + lo) sit in registers.
+constexpr int CSM_TX = 64, CSM_TY = 8, CSM_HX = CSM_TX + 4, CSM_HY = CSM_TY + 2, CSM_THREADS = 256;
+constexpr int CSM_RS = CSM_HX + 1;                         // record stride of a halo row (8-byte records)
+template <int NCG, int NTAP>
+__global__ __launch_bounds__(CSM_THREADS, 2) void costvol_stem_planes_mfma_kernel(PlanesArgs a, const uint4* __restrict__ frag_a,
+                                                                                 const uint4* __restrict__ frag_b, const float* __restrict__ wmul_all) {
+  constexpr int NS = (NCG * 3 * NTAP + 7) / 8, KH = NTAP == 5 ? 2 : 1;
+  constexpr int NREC = NCG * CSM_HY * CSM_HX, NPF = (NREC + CSM_THREADS - 1) / CSM_THREADS;
+  __shared__ __attribute__((aligned(16))) uint2 lhi[NCG * CSM_HY * CSM_RS], llo[NCG * CSM_HY * CSM_RS];
+  __shared__ unsigned lmax;
+  const PlaneDesc d = a.d[blockIdx.z % a.ndesc];
+  const int b = blockIdx.z / a.ndesc;
+  const int xb = blockIdx.x * CSM_TX, yb = blockIdx.y * CSM_TY;
+  if (xb >= d.width || (d.right ? 5 : 3) != NTAP) return;         // uniform: descriptors have different widths / tap counts
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kb = lane >> 4;
+  const float* const src = static_cast<const float*>(d.right ? a.right : a.left) + (int64_t)b * a.C * a.H * a.W;
+  if (tid == 0) lmax = 0u;
+  // halo records of this thread: 4 channels of one (row, column)
+  float pf[NPF][4];
+  unsigned valid = 0;
+  const int64_t HW = (int64_t)a.H * a.W;
+#pragma unroll
+  for (int p = 0; p < NPF; ++p) {
+    const int el = p * CSM_THREADS + tid, cg = el / (CSM_HY * CSM_HX), r = el % (CSM_HY * CSM_HX);
+    const int ty = r / CSM_HX, tx = r % CSM_HX, gy = yb + ty - 1, gx = d.x0 + xb + tx - KH;
+    const bool ok = el < NREC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    valid |= (ok ? 1u : 0u) << p;
+    const float* const pc = src + (int64_t)min(cg, NCG - 1) * 4 * HW + (int64_t)min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pf[p][c] = pc[c * HW];              // unconditional (clamped) loads; zeros substituted at the commit
+  }
+  // weight fragments of this variant -> registers (the same for every tile of the plane set)
+  const int v = d.variant;
+  const uint4* const wf = (NTAP == 5 ? frag_b + (int64_t)(v - CS_NVA) * NS * 2 * 64 : frag_a + (int64_t)v * NS * 2 * 64);
+  uint4 ah[NS], al[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { ah[s] = wf[(s * 2 + 0) * 64 + lane]; al[s] = wf[(s * 2 + 1) * 64 + lane]; }
+  // operand record offsets of this lane quarter: slice s, pair j -> (tap, cg) -> (cg * HY + dy) * RS + k   (padding pairs: pair 0's)
+  int poff[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int P = 8 * s + 2 * kb + j, tap = P / NCG, cg = P % NCG;
+      poff[s][j] = tap < 3 * NTAP ? (cg * CSM_HY + tap / NTAP) * CSM_RS + tap % NTAP : 0;
+    }
+  float m = 0.f;
+#pragma unroll
+  for (int p = 0; p < NPF; ++p) {
+    const float mp = x3_scalable_max4(pf[p][0], pf[p][1], pf[p][2], pf[p][3]);
+    m = fmaxf(m, ((valid >> p) & 1u) ? mp : 0.f);
+  }
+  m = x3_wave_max(m);
+  __syncthreads();                                                   // lmax is zero
+  if (lane == 0) atomicMax(&lmax, __float_as_uint(m));
+  __syncthreads();
+  const float mul = x3_pow2_scale(__uint_as_float(lmax), 16384.f);   // exact maximum: no headroom needed
+#pragma unroll
+  for (int p = 0; p < NPF; ++p) {
+    const int el = p * CSM_THREADS + tid;
+    if (el >= NREC) continue;
+    const int cg = el / (CSM_HY * CSM_HX), r = el % (CSM_HY * CSM_HX);
+    const bool ok = (valid >> p) & 1u;
+    unsigned l01, l23;
+    const unsigned h01 = x3_split2h(ok ? pf[p][0] : 0.f, ok ? pf[p][1] : 0.f, mul, l01), h23 = x3_split2h(ok ? pf[p][2] : 0.f, ok ? pf[p][3] : 0.f, mul, l23);
+    const int dst = (cg * CSM_HY + r / CSM_HX) * CSM_RS + r % CSM_HX;
+    lhi[dst] = make_uint2(h01, h23);
+    llo[dst] = make_uint2(l01, l23);
+  }
+  __syncthreads();
+  const float inv = 1.f / mul;
+  float osc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) osc[r] = wmul_all[v * 16 + 4 * kb + r] * inv;
+  const int64_t plane = (int64_t)a.H * d.width;
+  float* const out = a.ws + b * a.ws_bstride + d.out_off;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int row = 2 * wave + (t >> 2), col = (t & 3) * 16 + n;      // tile t of this wave: row, 16 columns
+    const int base = row * CSM_RS + col;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint2 h0 = lhi[base + poff[s][0]], h1 = lhi[base + poff[s][1]], l0 = llo[base + poff[s][0]], l1 = llo[base + poff[s][1]];
+      const uint4 bh = make_uint4(h0.x, h0.y, h1.x, h1.y), bl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+      acc = x3_mma<false>(ah[s], bh, acc);
+      acc = x3_mma<false>(ah[s], bl, acc);
+      acc = x3_mma<false>(al[s], bh, acc);
+    }
+    const int y = yb + row, xi = xb + col;
+    if (y < a.H && xi < d.width) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * kb + r < a.Cout) out[(int64_t)(4 * kb + r) * plane + (int64_t)y * d.width + xi] = acc[r] * osc[r];
+    }
   }
 }
 
@@ -314,7 +463,8 @@ static void stem_layout(int C, int Cout, int D, int H, int W, StemLayout& l) {
 
 extern "C" int64_t ragmi_costvol_stem_weights_elems(int C, int Cout) {
   if (C <= 0 || Cout <= 0) return 0;
-  return (int64_t)ragmi::CS_NCLS * (ragmi::CS_NTC * 9 + 2 * 15) * C * Cout;
+  // the fp32 variants (VALU planes kernel: RAGMI_F32 / RAGMI_BF16), then their FP16 hi / lo fragments and multipliers (RAGMI_F32X3)
+  return (int64_t)ragmi::CS_NCLS * (ragmi::CS_NTC * 9 + 2 * 15) * C * Cout + (C % 4 == 0 ? ragmi::cs_frag_words(C) : 0);
 }
 
 extern "C" int ragmi_costvol_stem_prepare(const void* weight, void* variants, int C, int Cout, void* stream) {
@@ -325,6 +475,9 @@ extern "C" int ragmi_costvol_stem_prepare(const void* weight, void* variants, in
   const int64_t na = (int64_t)CS_NCLS * CS_NTC * C * 9 * Cout, nb = (int64_t)CS_NCLS * 2 * C * 15 * Cout;
   hipLaunchKernelGGL(costvol_stem_weights_kernel, dim3((unsigned)ceil_div(na + nb, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      (const float*)weight, (float*)variants, (float*)variants + na, C, Cout);
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(costvol_stem_pack_kernel, dim3(CS_NVA + CS_NVB), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const float*)variants, (float*)variants + na + nb, C, Cout);
   return check_launch("costvol_stem_prepare");
 }
 
@@ -345,8 +498,12 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
   RAGMI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && B <= 65535, RAGMI_EINVAL, "costvol_stem: bad size");
   RAGMI_REQUIRE(C > 0 && Cout > 0 && C <= CS_MAXC && Cout <= CS_MAXC, RAGMI_EUNSUPPORTED, "costvol_stem: C and Cout must be in 1..%d",
                 CS_MAXC);
-  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "costvol_stem: dtype %d not built", dtype);
+  RAGMI_REQUIRE(conv_dtype_ok(dtype), RAGMI_EUNSUPPORTED, "costvol_stem: dtype %d not built", dtype);
   RAGMI_REQUIRE(ntail >= 0 && ntail <= 2 && (ntail == 0 || tails), RAGMI_EINVAL, "costvol_stem: at most two tails");
+  // RAGMI_F32X3: fp32 storage, the variant planes as split-operand products on the matrix cores where the shape allows
+  // (whole 4-channel groups, <= 12 feature channels); everything else of this entry point is fp32 either way
+  const bool mfma_planes = dtype == RAGMI_F32X3 && C % 4 == 0 && C <= 12;
+  if (dtype == RAGMI_F32X3) dtype = RAGMI_F32;
   StemLayout l;
   stem_layout(C, Cout, D, H, W, l);
   RAGMI_REQUIRE(l.per_batch < (1ll << 31), RAGMI_EUNSUPPORTED, "costvol_stem: planes too large for 32-bit offsets");
@@ -359,11 +516,11 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
   const int sa = C * 9 * Cout, sb = C * 15 * Cout;
   for (int c = 0; c < CS_NCLS; ++c) {
     if (!l.used[c]) continue;
-    pa.d[n++] = PlaneDesc{(c * CS_NTC + 4) * sa, (int)l.off_afull[c], W, 0, 0};                       // tc = 2
+    pa.d[n++] = PlaneDesc{(c * CS_NTC + 4) * sa, (int)l.off_afull[c], W, 0, 0, c * CS_NTC + 4};                       // tc = 2
     for (int k = 0; k < 4; ++k)                                                                       // tc = -2..1
-      pa.d[n++] = PlaneDesc{(c * CS_NTC + k) * sa, (int)(l.off_aband[c] + (int64_t)k * Cout * H * l.wband), l.wband, 0, 0};
-    pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 0) * sb, (int)l.off_b0[c], W + 2, -2, 1};
-    pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 1) * sb, (int)l.off_b1[c], l.wb1, l.u1_0, 1};
+      pa.d[n++] = PlaneDesc{(c * CS_NTC + k) * sa, (int)(l.off_aband[c] + (int64_t)k * Cout * H * l.wband), l.wband, 0, 0, c * CS_NTC + k};
+    pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 0) * sb, (int)l.off_b0[c], W + 2, -2, 1, CS_NVA + c * 2 + 0};
+    pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 1) * sb, (int)l.off_b1[c], l.wb1, l.u1_0, 1, CS_NVA + c * 2 + 1};
   }
   pa.ndesc = n;
   for (int k = 0; k < n; ++k) maxw = std::max(maxw, pa.d[k].width);
@@ -378,7 +535,24 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
     case 4: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 4>), pgrid, dim3(CS_NT), plds, st, pa); break;          \
     default: hipLaunchKernelGGL((costvol_stem_planes_kernel<TT, 0>), pgrid, dim3(CS_NT), plds, st, pa); break;         \
   }
-  if (dtype == RAGMI_BF16) { RAGMI_CS_PLANES(bf16_t) } else { RAGMI_CS_PLANES(float) }
+  if (mfma_planes) {
+    const int nsa = cs_nslices(C, 3), nsb = cs_nslices(C, 5);
+    const uint4* const fa = reinterpret_cast<const uint4*>((const float*)variants + l.na + l.nb);
+    const uint4* const fb = fa + (int64_t)CS_NVA * nsa * 2 * 64;
+    const float* const wm = reinterpret_cast<const float*>(fb + (int64_t)CS_NVB * nsb * 2 * 64);
+    const dim3 mgrid((unsigned)ceil_div(maxw, CSM_TX), (unsigned)ceil_div(H, CSM_TY), (unsigned)(n * B));
+    // two launches over the same descriptor list: the 3-tap (left) and the 5-tap (right) plane sets are different instantiations,
+    // a workgroup whose descriptor belongs to the other one exits at once
+#define RAGMI_CS_MFMA(NCG_)                                                                                              \
+    hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_, 3>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm);     \
+    hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_, 5>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm);
+    switch (C / 4) {
+      case 1: RAGMI_CS_MFMA(1) break;
+      case 2: RAGMI_CS_MFMA(2) break;
+      default: RAGMI_CS_MFMA(3) break;
+    }
+#undef RAGMI_CS_MFMA
+  } else if (dtype == RAGMI_BF16) { RAGMI_CS_PLANES(bf16_t) } else { RAGMI_CS_PLANES(float) }
 #undef RAGMI_CS_PLANES
 
   CombineArgs ca{};

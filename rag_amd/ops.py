@@ -185,7 +185,7 @@ def costvol_stem(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, 
     ntail, tarr = _tail_array(tails)
     p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     check(lib.ragmi_costvol_stem_fwd(left_fea.data_ptr(), right_fea.data_ptr(), variants.data_ptr(), p(scale), p(shift), int(relu),
-                                     out.data_ptr(), _planes(out), ws.data_ptr(), B, C, cout, d, h, w, ntail, tarr, dt, _stream()),
+                                     out.data_ptr(), _planes(out), ws.data_ptr(), B, C, cout, d, h, w, ntail, tarr, _conv_dt(dt), _stream()),
           "costvol_stem")
     return out
 
