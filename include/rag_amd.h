@@ -261,6 +261,18 @@ int ragmi_trilinear3d_fwd(const void* x, void* y, int B, int C,
  * `ConvBR_3d(1x1x1)(F.interpolate(x))` (rag_model.py:150-155, 358-365) run conv-first: the channel mix and the folded BatchNorm
  * are affine and the taps sum to one, so act(bn(conv(interp(x)))) == act(interp(bn(conv(x)))) and the mix runs on 1/8 of
  * the voxels. */
+/* The Matching-Net head's last two steps in one kernel (rag_model.py:357-365: `upsample_6` = nn.Upsample(scale_factor=2,
+ * mode='trilinear', align_corners=True), then last_3_3d = ConvBR_3d(C, 1, 3, 1, 1, bn=False, relu=False)):
+ *   y[:, y_ch0] = act(scale * conv3x3x3_pad1(upsample2(x))[:, 0] + shift)   (scale/shift optional, one output channel)
+ * x: [B, Cin, Di, Hi, Wi] (dtype, batch stride x_bstride), weight: the raw [1, Cin, 3, 3, 3] fp32 tensor, y: [B, *, 2Di, 2Hi, 2Wi]
+ * (y_dtype: the input's, or RAGMI_F32 for a RAGMI_BF16 input).  The upsampled tensor is never materialised: every operand of the
+ * convolution is interpolated in registers with the same fp32 source-index rule as ragmi_trilinear3d_fwd (nesting z, y, x instead
+ * of ATen's x, y, z: reassociation only).  ragmi_upconv3d_c1_supported: Cin <= 64, every input axis >= 2; otherwise run
+ * ragmi_trilinear3d_fwd + ragmi_conv3d_k3_small_fwd_ex. */
+int ragmi_upconv3d_c1_supported(int Cin, int Di, int Hi, int Wi);
+int ragmi_upconv3d_c1_fwd(const void* x, int64_t x_bstride, const void* weight, const void* scale, const void* shift, int relu, void* y,
+                          int64_t y_bstride, int y_ch0, int B, int Cin, int Di, int Hi, int Wi, int dtype, int y_dtype, void* stream);
+
 int ragmi_trilinear3d_act_fwd(const void* x, int64_t x_bstride, void* y, int64_t y_bstride, int y_ch0, int relu, int B, int C,
                               int Di, int Hi, int Wi, int Do, int Ho, int Wo, int align_corners, int dtype, void* stream);
 

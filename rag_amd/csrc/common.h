@@ -138,6 +138,14 @@ struct LinIdx {
   float w0, w1;
 };
 __device__ __forceinline__ LinIdx lin_index(int dst, int in_size, int out_size, float scale, int align_corners) {
+  // ATen's arithmetic, bit for bit (checked against torch CPU on this image, round 4: 100 % identical outputs in 1-D):
+  //   align_corners=True : src = fl(scale * dst); i0 = (int)src; lambda = src - i0   (the product is ROUNDED before it is used twice)
+  //   align_corners=False: src = fma(scale, dst + 0.5, -0.5)                          (one rounding: the CPU build contracts it)
+  // hipcc's default -ffp-contract=fast would fuse the first product into the subtraction too — a more accurate lambda (by up to
+  // 8e-6 at an index of ~400) but not the reference's, and fused in one kernel and not in another (the standalone upsample kernel
+  // and the fused head differed by 4e-5 at the headline shape for this reason alone) — so contraction is off in here and the one
+  // fused operation is written out.
+#pragma clang fp contract(off)
   LinIdx r;
   if (in_size == out_size) {
     r.i0 = r.i1 = dst;
@@ -149,7 +157,7 @@ __device__ __forceinline__ LinIdx lin_index(int dst, int in_size, int out_size, 
   if (align_corners) {
     src = scale * (float)dst;
   } else {
-    src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = __builtin_fmaf(scale, (float)dst + 0.5f, -0.5f);
     src = src < 0.f ? 0.f : src;
   }
   int i0 = (int)src;
@@ -161,6 +169,12 @@ __device__ __forceinline__ LinIdx lin_index(int dst, int in_size, int out_size, 
   r.w1 = lam;
   r.w0 = 1.f - lam;
   return r;
+}
+// one linear interpolation w0 * a + w1 * b in ATen's rounding: the second product rounded, the first fused into the sum (what its
+// CPU kernels compile to: identical bits in the 1-D check above); x innermost, then y, then z in every kernel that mirrors ATen
+__device__ __forceinline__ float lerp2(float w0, float a, float w1, float b) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(w0, a, w1 * b);
 }
 inline float lin_scale(int in_size, int out_size, int align_corners) {
   if (align_corners) return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;

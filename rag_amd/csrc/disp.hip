@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void disp_softargmin_kernel(DispArgs a) {
 
   auto plane = [&](int z) -> float {  // bilinear sample of coarse plane z at (oy, ox); x innermost like ATen
     const T* p = base + (int64_t)z * hw;
-    return ly.w0 * (lx.w0 * ld(p + o00) + lx.w1 * ld(p + o01)) + ly.w1 * (lx.w0 * ld(p + o10) + lx.w1 * ld(p + o11));
+    return lerp2(ly.w0, lerp2(lx.w0, ld(p + o00), lx.w1, ld(p + o01)), ly.w1, lerp2(lx.w0, ld(p + o10), lx.w1, ld(p + o11)));
   };
 
   // Walk the fine disparities in order; the coarse pair (cz, cz+1) only ever moves forward, so each
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void disp_softargmin_x3_kernel(DispArgs a) {
   __syncthreads();
   auto plane = [&](int z) {                  // bilinear sample of coarse plane z at (oy, ox); x innermost like ATen
     const int o = z * DX3_CP;
-    return ly.w0 * (lx.w0 * t00[o] + lx.w1 * t01[o]) + ly.w1 * (lx.w0 * t10[o] + lx.w1 * t11[o]);
+    return lerp2(ly.w0, lerp2(lx.w0, t00[o], lx.w1, t01[o]), ly.w1, lerp2(lx.w0, t10[o], lx.w1, t11[o]));
   };
   float lo = INFINITY;
 #pragma clang loop unroll_count(4) vectorize(disable)
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void disp_softargmin_wave_kernel(DispArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int k = l + 16 * q;
       const float* const t = t00 + min(k, D - 1) * DX3_CP;
-      v[q] = ly.w0 * (lx.w0 * t[0] + lx.w1 * t[o01]) + ly.w1 * (lx.w0 * t[o10] + lx.w1 * t[o10 + o01]);
+      v[q] = lerp2(ly.w0, lerp2(lx.w0, t[0], lx.w1, t[o01]), ly.w1, lerp2(lx.w0, t[o10], lx.w1, t[o10 + o01]));
       lo = k < D ? fminf(lo, v[q]) : lo;
     }
     // plane k-1 / k+1: the lane before / after in the pixel's row, same q — across the row's ends it is q -/+ 1 of the lane at the other end

@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
       for (int u = 0; u < U; ++u) {
         if (c0 + u >= a.Cin) break;
         const int ci = c0 + u;
-        const float a0 = ly.w0 * (lx.w0 * tap[u][0] + lx.w1 * tap[u][1]) + ly.w1 * (lx.w0 * tap[u][2] + lx.w1 * tap[u][3]);
-        const float a1 = ly.w0 * (lx.w0 * tap[u][4] + lx.w1 * tap[u][5]) + ly.w1 * (lx.w0 * tap[u][6] + lx.w1 * tap[u][7]);
-        const float xv = lz.w0 * a0 + lz.w1 * a1;
+        const float a0 = lerp2(ly.w0, lerp2(lx.w0, tap[u][0], lx.w1, tap[u][1]), ly.w1, lerp2(lx.w0, tap[u][2], lx.w1, tap[u][3]));
+        const float a1 = lerp2(ly.w0, lerp2(lx.w0, tap[u][4], lx.w1, tap[u][5]), ly.w1, lerp2(lx.w0, tap[u][6], lx.w1, tap[u][7]));
+        const float xv = lerp2(lz.w0, a0, lz.w1, a1);
         float wv[NCO];
 #pragma unroll
         for (int j = 0; j < NCO; j += 4) {

@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void trilinear_kernel(ResampleArgs a) {
     const float v100 = ld(pc + r10 + lx.i0), v101 = ld(pc + r10 + lx.i1);
     const float v110 = ld(pc + r11 + lx.i0), v111 = ld(pc + r11 + lx.i1);
     // x innermost, then y, then z (ATen's cpu_upsample_linear nesting)
-    const float a0 = ly.w0 * (lx.w0 * v000 + lx.w1 * v001) + ly.w1 * (lx.w0 * v010 + lx.w1 * v011);
-    const float a1 = ly.w0 * (lx.w0 * v100 + lx.w1 * v101) + ly.w1 * (lx.w0 * v110 + lx.w1 * v111);
-    const float v = lz.w0 * a0 + lz.w1 * a1;
+    const float a0 = lerp2(ly.w0, lerp2(lx.w0, v000, lx.w1, v001), ly.w1, lerp2(lx.w0, v010, lx.w1, v011));
+    const float a1 = lerp2(ly.w0, lerp2(lx.w0, v100, lx.w1, v101), ly.w1, lerp2(lx.w0, v110, lx.w1, v111));
+    const float v = lerp2(lz.w0, a0, lz.w1, a1);
     st(yp + c * ovol, a.relu ? fmaxf(v, 0.f) : v);
   }
 }
@@ -124,14 +124,14 @@ __global__ __launch_bounds__(256) void trilinear_up_kernel(ResampleArgs a) {
 #pragma unroll
       for (int p = 0; p < TU_PZ; ++p) {
         const float* q = t + p * (TU_PY * TU_PX);
-        pl[p] = ly.w0 * (lx.w0 * q[o00] + lx.w1 * q[o01]) + ly.w1 * (lx.w0 * q[o10] + lx.w1 * q[o11]);     // x innermost, then y (ATen's nesting)
+        pl[p] = lerp2(ly.w0, lerp2(lx.w0, q[o00], lx.w1, q[o01]), ly.w1, lerp2(lx.w0, q[o10], lx.w1, q[o11]));     // x innermost, then y (ATen's nesting)
       }
 #pragma unroll
       for (int k = 0; k < TU_TZ; ++k) {
         const int i0 = lz[k].i0 - pz0, i1 = lz[k].i1 - pz0;      // wave-uniform plane picks
         const float a0 = i0 == 0 ? pl[0] : i0 == 1 ? pl[1] : i0 == 2 ? pl[2] : pl[3];
         const float a1 = i1 == 0 ? pl[0] : i1 == 1 ? pl[1] : i1 == 2 ? pl[2] : pl[3];
-        const float v = lz[k].w0 * a0 + lz[k].w1 * a1;
+        const float v = lerp2(lz[k].w0, a0, lz[k].w1, a1);
         if (inside && oz0 + k < a.Do) st(yp + c * ovol + k * zs, a.relu ? fmaxf(v, 0.f) : v);
       }
     }

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void disp_softargmin_bwd_kernel(DispBwdArgs a)
   const int o00 = ly.i0 * a.w + lx.i0, o01 = ly.i0 * a.w + lx.i1, o10 = ly.i1 * a.w + lx.i0, o11 = ly.i1 * a.w + lx.i1;
   auto plane = [&](int z) -> float {
     const float* p = base + (int64_t)z * hw;
-    return ly.w0 * (lx.w0 * p[o00] + lx.w1 * p[o01]) + ly.w1 * (lx.w0 * p[o10] + lx.w1 * p[o11]);
+    return lerp2(ly.w0, lerp2(lx.w0, p[o00], lx.w1, p[o01]), ly.w1, lerp2(lx.w0, p[o10], lx.w1, p[o11]));
   };
   // Both passes walk the fine disparities in order like the forward kernel (disp.hip): the coarse pair (cz, cz+1) only moves
   // forward, so each coarse plane is sampled once per pass, the fine taps come from the LDS table and the softmax runs in base 2

@@ -791,14 +791,22 @@ class MatchingNet(nn.Module):
             return self.last_3_3d[i3](last_output, out_dtype=f32)
         heads = (self.last_3_3d[i3], self.last_6_3d[i6], self.last_12_3d[i12])
         up = ag.resample if any(m.autograd_mode(last_output) for m in heads) else ops.trilinear3d
+        def up_last3(y):
+            """upsample_6 + last_3_3d (rag_model.py:357-365): ONE kernel when the upsampling is an exact factor 2 (always, for the
+            sizes the reference accepts) — the 12-channel full-resolution tensor is never written."""
+            m3 = self.last_3_3d[i3]
+            if (up is ops.trilinear3d and m3._small() and m3.conv.out_channels == 1 and tuple(y.shape[2:]) == (d // 2, h // 2, w // 2)
+                    and (d, h, w) == (2 * (d // 2), 2 * (h // 2), 2 * (w // 2)) and ops.upconv3d_c1_supported(y.shape[1], d // 2, h // 2, w // 2)):
+                wk, scale, shift = m3.prepared()             # the raw [1, C, 3, 3, 3] weight (VALU forms read it as is)
+                return ops.upconv3d_c1(y, wk, scale, shift, m3.relu, out_dtype=f32)
+            return m3(up(y, (d, h, w), True), out_dtype=f32)
+
         if last_output.size()[3] == h // 2:
-            y = up(self.last_6_3d[i6](last_output), (d, h, w), True)
-            return self.last_3_3d[i3](y, out_dtype=f32)
+            return up_last3(self.last_6_3d[i6](last_output))
         if last_output.size()[3] == h // 4:
-            # upsample_12 is fused into last_6_3d's 1x1x1 kernel; upsample_6 feeds a 3x3x3 conv and stays a kernel
+            # upsample_12 is fused into last_6_3d's 1x1x1 kernel (conv-first); upsample_6 is fused into last_3_3d's kernel
             y = self.last_6_3d[i6](self.last_12_3d[i12](last_output), resample_to=(d // 2, h // 2, w // 2))
-            y = up(y, (d, h, w), True)
-            return self.last_3_3d[i3](y, out_dtype=f32)
+            return up_last3(y)
         # the reference reaches `return mat` with mat unbound here (UnboundLocalError)
         raise ValueError("MatchingNet: feature height must be a multiple of 4 (input H a multiple of 12)")
 

@@ -388,6 +388,32 @@ def conv2d_k3_strided(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu:
     return out
 
 
+def upconv3d_c1_supported(cin: int, di: int, hi: int, wi: int) -> bool:
+    return bool(load_library().ragmi_upconv3d_c1_supported(int(cin), int(di), int(hi), int(wi)))
+
+
+def upconv3d_c1(x: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool,
+                out: Optional[torch.Tensor] = None, out_ch0: int = 0, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """act(bn(conv3x3x3(F.interpolate(x, scale_factor=2, mode='trilinear', align_corners=True)))) for a ONE-output-channel conv
+    (raw weight [1, Cin, 3, 3, 3]) without materialising the upsampled tensor: the head's upsample_6 + last_3_3d
+    (rag_model.py:357-365), ragmi_upconv3d_c1_fwd.  `out` may be float32 while x is bfloat16."""
+    _need_gpu(weight, scale, shift)
+    dt = _act(x)
+    B, Cin, Di, Hi, Wi = x.shape
+    if tuple(weight.shape) != (1, Cin, 3, 3, 3):
+        raise ValueError("upconv3d_c1: weight must be [1, Cin, 3, 3, 3]")
+    if out is None:
+        out = torch.empty((B, 1, 2 * Di, 2 * Hi, 2 * Wi), device=x.device, dtype=out_dtype or x.dtype)
+    ydt = _act(out)
+    if tuple(out.shape[2:]) != (2 * Di, 2 * Hi, 2 * Wi) or out.shape[0] != B or out_ch0 >= out.shape[1]:
+        raise ValueError("upconv3d_c1: out must be [B, >= out_ch0 + 1, 2Di, 2Hi, 2Wi]")
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(load_library().ragmi_upconv3d_c1_fwd(x.data_ptr(), _planes(x), weight.detach().contiguous().data_ptr(), ptr(scale), ptr(shift),
+                                               int(relu), out.data_ptr(), _planes(out), int(out_ch0), B, Cin, Di, Hi, Wi, dt, ydt, _stream()),
+          "upconv3d_c1")
+    return out
+
+
 def trilinear3d(x: torch.Tensor, size: Sequence[int], align_corners: bool) -> torch.Tensor:
     """F.interpolate(x, size, mode='trilinear', align_corners=...) for x[B,C,D,H,W]."""
     dt = _act(x)

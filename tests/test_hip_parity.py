@@ -220,6 +220,44 @@ def test_conv3d_c1_single_output_channel_form(ra, cin, shape, dtype, bn):
     np.testing.assert_allclose(got[:, 1:2].double().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,shape,dtype,bn", [
+    (12, (1, 32, 64, 208), "f32", False),      # the headline head: [1,12,32,64,208] -> mat [1,1,64,128,416] (rag_model.py:357-365)
+    (12, (2, 5, 37, 50), "f32", True),         # two pairs; odd input sizes: partial tiles everywhere, partial depth segment; BN + ReLU
+    (4, (1, 2, 2, 2), "f32", False),           # the smallest volume: every voxel is a border voxel
+    (8, (1, 7, 33, 18), "f32", False),         # a tile border one row past 64 output rows
+    (12, (1, 8, 40, 80), "bf16", False)])      # bf16 activation storage, fp32 output
+def test_upconv3d_c1_fused_head_vs_oracle(ra, cin, shape, dtype, bn):
+    """upconv3d_c1_kernel: conv3x3x3(Upsample(x2, trilinear, align_corners=True)(x)) with one output channel, the upsampled tensor
+    never materialised — against ATen's fp32 F.interpolate + F.conv3d in float64, AND against this library's own two-kernel path (standalone
+    upsample + conv3d_c1 / generic small-Cout kernel), which evaluates the same fp32 source indices."""
+    B, Di, Hi, Wi = shape
+    bf = dtype == "bf16"
+    x = torch.randn((B, cin, Di, Hi, Wi), generator=gen(41))
+    if bf:
+        x = x.to(torch.bfloat16)
+    w = torch.randn((1, cin, 3, 3, 3), generator=gen(42)) * (2.0 / (27 * cin)) ** 0.5
+    # the reference's arithmetic: ATen's fp32 upsample (fp32 source indices: up to 4e-5 from an exact interpolation at an index of
+    # ~400), then the convolution — summed in float64 here
+    up = F.interpolate(x.float(), scale_factor=2, mode="trilinear", align_corners=True)
+    ref = F.conv3d(up.double(), w.double(), padding=1)
+    scale = shift = None
+    if bn:
+        scale, shift = torch.rand(1, generator=gen(43)) + 0.5, torch.randn(1, generator=gen(44)) * 0.1
+        ref = F.relu(ref * scale.double() + shift.double())
+    assert ra.ops.upconv3d_c1_supported(cin, Di, Hi, Wi)
+    out = torch.full((B, 2, 2 * Di, 2 * Hi, 2 * Wi), float("nan"), device=DEV)
+    ra.ops.upconv3d_c1(gpu(x), gpu(w), gpu(scale) if bn else None, gpu(shift) if bn else None, bn, out, 1)
+    got = out.cpu()
+    assert torch.isnan(got[:, 0]).all()
+    np.testing.assert_allclose(got[:, 1:2].double().numpy(), ref.numpy(), rtol=3e-5, atol=3e-5)
+    # the two-kernel path of this library (fp32 upsample written to HBM, then the convolution): same source indices, same products
+    two = torch.empty((B, 1, 2 * Di, 2 * Hi, 2 * Wi), device=DEV)
+    ra.ops.conv3d_k3_small(ra.ops.trilinear3d(gpu(x), (2 * Di, 2 * Hi, 2 * Wi), True), gpu(w), gpu(scale) if bn else None,
+                           gpu(shift) if bn else None, bn, two)
+    if not bf:           # (bf16 storage rounds the materialised upsample to bf16; the fused kernel keeps it in fp32)
+        np.testing.assert_allclose(got[:, 1:2].numpy(), two.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("dual", [False, True])
 @pytest.mark.parametrize("store_main", [True, False])
 @pytest.mark.parametrize("shape", [(1, 5, 9, 33), (2, 4, 8, 20), (1, 64, 16, 64)])
@@ -302,6 +340,23 @@ def test_trilinear_vs_aten(ra, align, shape, size):
     ref = F.interpolate(x, size, mode="trilinear", align_corners=align)
     out = ra.ops.trilinear3d(gpu(x), size, align)
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("shape,size", [((1, 3, 16, 32, 104), (32, 64, 208)),      # x2 up (the tiled LDS kernel when align)
+                                        ((2, 4, 9, 21, 50), (5, 11, 25)),          # ~x0.5 down, odd sizes (scale_dimension's odd rule)
+                                        ((1, 2, 8, 16, 200), (24, 48, 600)),       # x3 (Disp's factor), indices up to 600
+                                        ((1, 2, 7, 5, 9), (7, 13, 9))])            # mixed: identity / up / identity
+def test_trilinear_bit_identical_to_aten_cpu(ra, align, shape, size):
+    """Round 4: lin_index and the interpolation blends reproduce ATen's CPU arithmetic bit for bit — the source index src = fl(scale
+    * dst) rounded BEFORE its integer part and fraction are taken (align_corners) or fma(scale, dst + 0.5, -0.5) (not aligned), each
+    blend fma(w0, a, fl(w1 * b)), x innermost, then y, then z (csrc/common.h).  The resample kernels therefore return the
+    reference's own bits, not an approximation of them."""
+    x = torch.randn(shape, generator=gen(21)) * 50.0
+    ref = F.interpolate(x, size, mode="trilinear", align_corners=align)
+    out = ra.ops.trilinear3d(gpu(x), size, align).cpu()
+    same = int((out == ref).sum())
+    assert same == ref.numel(), f"{ref.numel() - same} of {ref.numel()} voxels differ; max |diff| {float((out - ref).abs().max()):.3e}"
 
 
 @pytest.mark.parametrize("relu", [False, True])

@@ -3,8 +3,9 @@
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
     python tools/step_timeline.py <dir> > profiles/rNN_step_timeline.txt
 
-The pass is found as the last run of dispatches that starts with costvol_stem_planes_kernel (or the kernel named by a second
-argument) and ends with disp_softargmin_kernel.
+The pass is found as the last run of dispatches that starts with costvol_stem_planes_mfma_kernel (the headline's first kernel under
+the default precision; or the kernel named by a second argument, e.g. costvol_stem_planes_kernel for the strict-fp32 pass) and
+ends with the next disp_softargmin kernel.
 """
 import csv
 import glob
@@ -18,7 +19,7 @@ def short(name: str) -> str:
     return re.sub(r"\(.*$", "", name)
 
 
-def main(root: str, first: str = "costvol_stem_planes_kernel") -> None:
+def main(root: str, first: str = "costvol_stem_planes_mfma_kernel") -> None:
     files = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)
     if not files:
         raise SystemExit("no *kernel_trace.csv under " + root)
@@ -31,9 +32,13 @@ def main(root: str, first: str = "costvol_stem_planes_kernel") -> None:
     ends = [i for i, r in enumerate(rows) if "disp_softargmin" in r[2]]
     if not starts or not ends:
         raise SystemExit("no forward pass found")
-    # the last complete pass that belongs to the Matching-Net bench (planes ... disp with no other planes in between)
-    e = ends[-1]
-    s = max(i for i in starts if i < e)
+    # the last complete pass of that kind (first kernel ... the next soft-argmin)
+    s = starts[-1]
+    later = [i for i in ends if i > s]
+    if not later:
+        s = starts[-2]
+        later = [i for i in ends if i > s]
+    e = later[0]
     t0 = rows[s][0]
     print("start_us  dur_us  gap_us  kernel")
     prev_end = t0
