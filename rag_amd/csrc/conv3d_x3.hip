@@ -416,7 +416,13 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
       lw[region * NWS + i] = cog0 + cl < ncog ? e.wf[set][(int64_t)(cog0 + cl) * NSLS * 2 * 64 + r] : make_uint4(0u, 0u, 0u, 0u);
     }
   };
+#ifdef RAGMI_DIAG
+  const bool diag_nowcopy = (a.relu & 0x800) != 0;
+#else
+  constexpr bool diag_nowcopy = false;
+#endif
   if constexpr (!WS) {
+    if (!diag_nowcopy)
 #pragma unroll
     for (int set = 0; set < NSET; ++set) wcopy(set, set);
   }

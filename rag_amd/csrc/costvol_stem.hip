@@ -223,16 +223,13 @@ __global__ __launch_bounds__(256) void costvol_stem_pack_kernel(const float* __r
 constexpr int CSM_TX = 64, CSM_TY = 8, CSM_HX = CSM_TX + 4, CSM_HY = CSM_TY + 2, CSM_THREADS = 256;
 constexpr int CSM_RS = CSM_HX + 1;                         // record stride of a halo row (8-byte records)
 template <int NCG, int NTAP>
-__global__ __launch_bounds__(CSM_THREADS, 2) void costvol_stem_planes_mfma_kernel(PlanesArgs a, const uint4* __restrict__ frag_a,
-                                                                                 const uint4* __restrict__ frag_b, const float* __restrict__ wmul_all) {
+__device__ __forceinline__ void costvol_stem_planes_mfma_body(const PlanesArgs& a, const PlaneDesc& d, const uint4* __restrict__ frag_a,
+                                                              const uint4* __restrict__ frag_b, const float* __restrict__ wmul_all,
+                                                              uint2* lhi, uint2* llo, unsigned& lmax) {
   constexpr int NS = (NCG * 3 * NTAP + 7) / 8, KH = NTAP == 5 ? 2 : 1;
   constexpr int NREC = NCG * CSM_HY * CSM_HX, NPF = (NREC + CSM_THREADS - 1) / CSM_THREADS;
-  __shared__ __attribute__((aligned(16))) uint2 lhi[NCG * CSM_HY * CSM_RS], llo[NCG * CSM_HY * CSM_RS];
-  __shared__ unsigned lmax;
-  const PlaneDesc d = a.d[blockIdx.z % a.ndesc];
   const int b = blockIdx.z / a.ndesc;
   const int xb = blockIdx.x * CSM_TX, yb = blockIdx.y * CSM_TY;
-  if (xb >= d.width || (d.right ? 5 : 3) != NTAP) return;         // uniform: descriptors have different widths / tap counts
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kb = lane >> 4;
   const float* const src = static_cast<const float*>(d.right ? a.right : a.left) + (int64_t)b * a.C * a.H * a.W;
   if (tid == 0) lmax = 0u;
@@ -315,6 +312,19 @@ __global__ __launch_bounds__(CSM_THREADS, 2) void costvol_stem_planes_mfma_kerne
         if (4 * kb + r < a.Cout) out[(int64_t)(4 * kb + r) * plane + (int64_t)y * d.width + xi] = acc[r] * osc[r];
     }
   }
+}
+
+// both tap counts in ONE launch (the 3-tap left and the 5-tap right plane sets took 15 + 16 us as two launches, each latency-bound):
+// the descriptor picks the instantiation (wave-uniform)
+template <int NCG>
+__global__ __launch_bounds__(CSM_THREADS, 2) void costvol_stem_planes_mfma_kernel(PlanesArgs a, const uint4* __restrict__ frag_a,
+                                                                                 const uint4* __restrict__ frag_b, const float* __restrict__ wmul_all) {
+  __shared__ __attribute__((aligned(16))) uint2 lhi[NCG * CSM_HY * CSM_RS], llo[NCG * CSM_HY * CSM_RS];
+  __shared__ unsigned lmax;
+  const PlaneDesc d = a.d[blockIdx.z % a.ndesc];
+  if ((int)blockIdx.x * CSM_TX >= d.width) return;               // uniform: descriptors have different widths
+  if (d.right) costvol_stem_planes_mfma_body<NCG, 5>(a, d, frag_a, frag_b, wmul_all, lhi, llo, lmax);
+  else costvol_stem_planes_mfma_body<NCG, 3>(a, d, frag_a, frag_b, wmul_all, lhi, llo, lmax);
 }
 
 struct CombineArgs {
@@ -541,11 +551,7 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
     const uint4* const fb = fa + (int64_t)CS_NVA * nsa * 2 * 64;
     const float* const wm = reinterpret_cast<const float*>(fb + (int64_t)CS_NVB * nsb * 2 * 64);
     const dim3 mgrid((unsigned)ceil_div(maxw, CSM_TX), (unsigned)ceil_div(H, CSM_TY), (unsigned)(n * B));
-    // two launches over the same descriptor list: the 3-tap (left) and the 5-tap (right) plane sets are different instantiations,
-    // a workgroup whose descriptor belongs to the other one exits at once
-#define RAGMI_CS_MFMA(NCG_)                                                                                              \
-    hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_, 3>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm);     \
-    hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_, 5>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm);
+#define RAGMI_CS_MFMA(NCG_) hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm);
     switch (C / 4) {
       case 1: RAGMI_CS_MFMA(1) break;
       case 2: RAGMI_CS_MFMA(2) break;

@@ -127,13 +127,40 @@ __global__ __launch_bounds__(256) void disp_softargmin_x3_kernel(DispArgs a) {
     const int o = z * DX3_CP;
     return lerp2(ly.w0, lerp2(lx.w0, t00[o], lx.w1, t01[o]), ly.w1, lerp2(lx.w0, t10[o], lx.w1, t11[o]));
   };
+  constexpr float K = 1.4426950408889634f;
+  float s = 0.f, ws = 0.f;
+  // d = 64 (maxdisp 192, the reference's only configuration, rag_model.py:274): the 64 plane samples of pass 1 stay in REGISTERS for
+  // pass 2 — no second round of 4 d LDS reads and bilinear arithmetic (same operations on the same values: identical bits).  Chunks
+  // of 8 planes fenced by sched_barrier: unfenced, the scheduler hoisted all 256 operand reads and the kernel spilled or ran at
+  // 87 us (round 2).  Same box, both builds: 49.9 -> 40.3 us (90 VGPRs, 5 waves per SIMD).
+  if (D == 64) {
+    float v[64];
+    float lo = INFINITY;
+#pragma unroll
+    for (int z = 0; z < 64; ++z) {
+      v[z] = plane(z);
+      lo = fminf(lo, v[z]);
+      if ((z & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      const float vp_ = v[k > 0 ? k - 1 : 0], vc_ = v[k], vn_ = v[k < 63 ? k + 1 : 63];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float4 tb = ztab[3 * k + j];
+        const float c = fmaf(tb.x, vp_, fmaf(tb.y, vc_, tb.z * vn_));
+        const float e = __builtin_amdgcn_exp2f((lo - c) * K);
+        s += e;
+        ws = fmaf(e, tb.w, ws);
+      }
+      if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   float lo = INFINITY;
 #pragma clang loop unroll_count(4) vectorize(disable)
   for (int z = 0; z < D; ++z) lo = fminf(lo, plane(z));
-  constexpr float K = 1.4426950408889634f;
   // exponent of a sample: (min - cost) * K: the difference is formed BEFORE the scaling by K, like the generic kernel, so large
   // |cost| does not lose the bits that matter near the minimum
-  float s = 0.f, ws = 0.f;
   float vc = plane(0), vp = vc, vn = plane(min(1, D - 1));
   for (int k = 0; k < D; ++k) {
 #pragma unroll
@@ -145,6 +172,7 @@ __global__ __launch_bounds__(256) void disp_softargmin_x3_kernel(DispArgs a) {
       ws = fmaf(e, tb.w, ws);
     }
     vp = vc; vc = vn; vn = plane(min(k + 2, D - 1));
+  }
   }
   if (ox0 + tx < a.Wo && oy0 + ty < a.Ho) a.out[(int64_t)b * a.Ho * a.Wo + (int64_t)oy * a.Wo + ox] = ws / s;
 }
