@@ -96,7 +96,15 @@ __global__ __launch_bounds__(256) void disp_softargmin_x3_kernel(DispArgs a) {
   float4* const ztab = reinterpret_cast<float4*>(dx3_lds);            // [maxdisp] (wp, wc, wn, dd)
   float* const tile = dx3_lds + 4 * a.maxdisp;                        // [d][5][13]
   const int tid = threadIdx.x, tx = tid % DX3_TX, ty = tid / DX3_TX;
-  const int ox0 = blockIdx.x * DX3_TX, oy0 = blockIdx.y * DX3_TY, b = blockIdx.z;
+  // XCD-aware tile order: workgroup j runs on XCD j % 8 (round-robin dispatch); every XCD walks one contiguous chunk of the
+  // x-fastest tile list, so tiles that share coarse rows / columns of the cost meet in ONE L2.  With blockIdx.x = tile x the eight
+  // neighbours of a tile sat on eight different XCDs and every L2 fetched its own copy of the shared halo: 77 MB from the memory
+  // side for a 13.6 MB tensor (profiles/r04y_pmc_summary.txt).
+  const int ntx = (a.Wo + DX3_TX - 1) / DX3_TX, nty = (a.Ho + DX3_TY - 1) / DX3_TY, ntile = ntx * nty;
+  const int chunk = (ntile + 7) / 8, jb = blockIdx.x;
+  const int tidx = (jb & 7) * chunk + (jb >> 3);
+  if ((jb >> 3) >= chunk || tidx >= ntile) return;
+  const int ox0 = (tidx % ntx) * DX3_TX, oy0 = (tidx / ntx) * DX3_TY, b = blockIdx.z;
   const int ox = min(ox0 + tx, a.Wo - 1), oy = min(oy0 + ty, a.Ho - 1);       // out-of-range threads shadow the last pixel, store nothing
   const int cy0 = lin_index(oy0, a.h, a.Ho, a.sh, 0).i0, cx0 = lin_index(ox0, a.w, a.Wo, a.sw, 0).i0;
   const int hw = a.h * a.w, D = a.d;
@@ -305,6 +313,7 @@ extern "C" int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int
   const size_t lds3 = lds + (size_t)d * DX3_CP * sizeof(float);
   if (maxdisp == 3 * d && Ho == 3 * h && Wo == 3 * w && lds3 <= 64 * 1024) {   // the reference's configuration (rag_model.py:40, 272-273): the tiled form
     const dim3 g3((unsigned)ceil_div(Wo, DX3_TX), (unsigned)ceil_div(Ho, DX3_TY), (unsigned)B);
+    const dim3 g1((unsigned)(ceil_div((int64_t)g3.x * g3.y, 8) * 8), 1, (unsigned)B);      // the tiled kernel decodes its tile itself (XCD-aware)
 #ifdef RAGMI_DISP_WAVE      // A/B build (tools/build_variant.sh): the wavefront-reduction form, d <= 64
     if (d <= 64) {
       const size_t ldsw = (size_t)d * DX3_CP * sizeof(float);
@@ -313,8 +322,8 @@ extern "C" int ragmi_disp_softargmin_fwd(const void* cost, void* out, int B, int
       return check_launch("disp_softargmin");
     }
 #endif
-    if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_x3_kernel<bf16_t>, g3, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(disp_softargmin_x3_kernel<float>, g3, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
+    if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_x3_kernel<bf16_t>, g1, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(disp_softargmin_x3_kernel<float>, g1, dim3(256), lds3, static_cast<hipStream_t>(stream), a);
     return check_launch("disp_softargmin");
   }
   if (dtype == RAGMI_BF16) hipLaunchKernelGGL(disp_softargmin_kernel<bf16_t>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
