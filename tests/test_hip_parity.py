@@ -757,6 +757,40 @@ def test_bf16_config3_full_workload_gate(ra):
     assert e16 <= BF16_FULL_GATE, e16
 
 
+def test_bf16_storage_epe_at_two_cost_scales(ra):
+    """VERDICT r03 8(c), measured in round 4 — and the hypothesis it was meant to confirm is REFUTED.  Round 3 explained configs[2]'s
+    0.09-0.10 px (bf16 activation storage vs the fp32 build, seeded random weights, |cost| ~ 1e4) by the conditioning of a nearly-argmin
+    softmin.  The same network with last_3_3d's weight scaled by 1e-3 (|cost| ~ 10-100, the scale of a trained net's matching cost;
+    `mat` scales by exactly that factor, nothing else changes) does NOT show the error collapse: the EPE GROWS (0.075 -> 0.29 px).
+    What bf16 storage carries is a RELATIVE error of `mat` of ~3e-3 of its largest magnitude (8 significant bits per stored stage,
+    ~20 stages); on a peaked softmin most pixels do not move at all and a few move far, on a smooth one every pixel's expectation
+    shifts a little — the second costs more EPE.  So configs[2] is a throughput / accuracy trade, not an fp32-class result: its gate is
+    stated from BOTH regimes (<= 0.12 px at the benchmark's own weights, <= 0.5 px at the trained-net cost scale) together with the
+    relative error of `mat` that explains them."""
+    rows = O.ALL_CONV
+    g = gen(1234)
+    lf, rf = torch.randn((1, 12, 128, 416), generator=g), torch.randn((1, 12, 128, 416), generator=g)
+    out = {}
+    for f in (1.0, 1e-3):
+        sd = O.random_matching_state_dict(rows, seed=0)
+        sd["last_3_3d.0.conv.weight"] = sd["last_3_3d.0.conv.weight"] * f
+        net = ra.MatchingNet(ra.ALL_CONV_GENOTYPE, maxdisp=192)
+        net.load_state_dict(sd)
+        net = net.to(DEV).eval()
+        with torch.no_grad():
+            feats = (gpu(lf), gpu(rf))
+            m32 = net.matching(None, net.arch_init, None, features=feats)
+            m16 = net.matching(None, net.arch_init, None, features=(feats[0].to(BF), feats[1].to(BF)))
+            d32, d16 = net.disp(m32).cpu(), net.disp(m16).cpu()
+        rel = float((m16.float() - m32).abs().max() / m32.abs().max())
+        out[f] = (float(m32.abs().max()), O.epe(d16, d32), float((d16 - d32).abs().max()), rel)
+        print(f"last_3_3d weight x {f:g}: max |cost| {out[f][0]:.3g}; bf16 storage vs fp32 build: max |mat err| / max |mat| {rel:.2e}, "
+              f"EPE {out[f][1]:.3e} px (max {out[f][2]:.3f} px)")
+    assert out[1.0][0] > 1e3 and out[1e-3][0] < 1e3                    # the two regimes
+    assert out[1.0][1] <= BF16_FULL_GATE and out[1e-3][1] <= 0.5       # the stated gates of configs[2]
+    assert max(out[1.0][3], out[1e-3][3]) <= 2e-2                       # the relative error of `mat` under bf16 storage
+
+
 # --------------------------------------------------------------------------- grown model: checkpoint round trip + serving (N4)
 def test_multitask_serving_after_checkpoint_round_trip(ra, tmp_path):
     from rag_amd import checkpoint as ck
