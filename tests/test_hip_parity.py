@@ -342,6 +342,40 @@ def test_trilinear_vs_aten(ra, align, shape, size):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape,couts,dtype", [((1, 12, 16, 128, 512), (8, 8), "f32"),     # cell 3's pair at a quarter of the headline depth
+                                               ((2, 12, 8, 256, 520), (8, 4), "f32"),      # two samples, different output widths per conv
+                                               ((1, 8, 16, 128, 512), (8, 8), "bf16")])
+def test_k1_resample_pair_big_volume_down2(ra, shape, couts, dtype):
+    """x0.5 down-sampling (align_corners=True) + 1x1x1 ConvBR pairs on volumes of >= 2^20 voxels (rag_model.py:146-155 for cell 3:
+    the level 3 -> 6 pair, the HBM-bound launch) — against ATen's fp32 F.interpolate followed by the channel mix in float64.  The
+    interpolation is ATen's bit for bit, so the tolerance is that of the 1x1x1 sum alone.  (Round 4 measured a 16-byte-per-lane
+    "streaming" form of this kernel — two outputs per thread — against the shipped 8-byte pair loads, which are contiguous across
+    lanes already: 88-93 us vs 68 us; not kept.)"""
+    B, C, Di, Hi, Wi = shape
+    assert Di * Hi * Wi >= 1 << 20
+    size = (Di // 2, Hi // 2, Wi // 2)
+    bf = dtype == "bf16"
+    xs = [torch.randn(shape, generator=gen(61 + k)) for k in range(2)]
+    if bf:
+        xs = [x.to(torch.bfloat16) for x in xs]
+    ws = [torch.randn((co, C), generator=gen(63 + k)) * 0.3 for k, co in enumerate(couts)]
+    sc = [torch.rand(co, generator=gen(65 + k)) + 0.5 for k, co in enumerate(couts)]
+    sh = [torch.randn(co, generator=gen(67 + k)) * 0.1 for k, co in enumerate(couts)]
+    out = torch.full((B, sum(couts) + 1) + size, float("nan"), device=DEV, dtype=torch.bfloat16 if bf else torch.float32)
+    specs = [(gpu(xs[0]), gpu(ws[0]), gpu(sc[0]), gpu(sh[0]), True, 0), (gpu(xs[1]), gpu(ws[1]), gpu(sc[1]), gpu(sh[1]), False, couts[0])]
+    ra.ops.conv3d_k1_resample_pair(specs, size, out)
+    got = out.float().cpu()
+    ch0 = 0
+    for k, co in enumerate(couts):
+        up = F.interpolate(xs[k].float(), size, mode="trilinear", align_corners=True).double()
+        ref = torch.einsum("oc,bcdhw->bodhw", ws[k].double(), up) * sc[k].double().view(1, -1, 1, 1, 1) + sh[k].double().view(1, -1, 1, 1, 1)
+        ref = F.relu(ref) if k == 0 else ref
+        tol = dict(rtol=1e-2, atol=3e-2) if bf else dict(rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got[:, ch0:ch0 + co].double().numpy(), ref.numpy(), **tol)
+        ch0 += co
+    assert torch.isnan(got[:, ch0]).all()
+
+
 @pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("shape,size", [((1, 3, 16, 32, 104), (32, 64, 208)),      # x2 up (the tiled LDS kernel when align)
                                         ((2, 4, 9, 21, 50), (5, 11, 25)),          # ~x0.5 down, odd sizes (scale_dimension's odd rule)
