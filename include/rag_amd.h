@@ -137,9 +137,16 @@ typedef struct {
   int32_t y_ch0;
   int32_t cout;
 } ragmi_tail_t;
+/* `relu` bit 0: ReLU after the BatchNorm.  `relu` bit 1 (value 2): a DOWN-SAMPLING tail — the 1x1x1 ConvBR_3d of a consumer cell that
+ * works one level down (Cell_3d with downup_sample = -1: F.interpolate(x, half size, 'trilinear', align_corners=True) followed by
+ * pre_preprocess / preprocess, rag_model.py:146-155), computed conv-first in the producer's epilogue: y is [B, *, D/2, H/2, W/2].
+ * Up to two of them (4 output channels each) beside up to two full-resolution tails; only the z-marching split-operand form takes
+ * them (ragmi_conv3d_k3_uses_x3 with RAGMI_F32X3, fp32 storage, <= 12 input channels) and only for even D, H, W whose x0.5 source
+ * pairs are aligned (ragmi_down2_tail_supported: output o reads inputs (2o, 2o+1) on every axis; the last may clamp). */
+int ragmi_down2_tail_supported(int D, int H, int W);
 
 /*
- * ragmi_conv3d_k3_fwd / ragmi_conv3d_k3_dual_fwd with up to two tails.  store_main = 0 skips writing the 3x3x3
+ * ragmi_conv3d_k3_fwd / ragmi_conv3d_k3_dual_fwd with up to two full-resolution tails (plus up to two down-sampling ones).  store_main = 0 skips writing the 3x3x3
  * result itself (only the tails consume it).  Tails need Cout in {4, 8, 12, 16} (all channels in one workgroup).
  */
 int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride,

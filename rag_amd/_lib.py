@@ -67,6 +67,7 @@ SIGNATURES = {
     "ragmi_conv3d_k1_resample_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                              c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k1_resample_pair_fwd": (c_int, [c_k1r_p, c_k1r_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_down2_tail_supported": (c_int, [c_int, c_int, c_int]),
     "ragmi_upconv3d_c1_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "ragmi_upconv3d_c1_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_void_p]),

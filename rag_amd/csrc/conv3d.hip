@@ -53,11 +53,27 @@ static int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int
   return RAGMI_OK;
 }
 
+// host twin of lin_index for align_corners=True (same fp32 operations): every output o but the last of an axis must read the
+// source pair (2o, 2o+1) — what the down-sampling tails of conv3d_x3.hip rely on (the last may clamp; the kernel honours it)
+static bool down2_pairs_aligned(int in_size) {
+  if (in_size < 2 || in_size % 2) return false;
+  const int out_size = in_size / 2;
+  const float scale = lin_scale(in_size, out_size, 1);
+  for (int o = 0; o + 1 < out_size; ++o) {
+    volatile float src = scale * (float)o;
+    if ((int)src != 2 * o) return false;
+  }
+  volatile float last = scale * (float)(out_size - 1);
+  const int i0 = std::min((int)last, in_size - 1);
+  return i0 == in_size - 2 || i0 == in_size - 1;
+}
+
 static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* tails, int Cout) {
   a.store_main = 1;
   a.ntail = 0;
+  a.ndown = 0;
   if (ntail == 0 && store_main) return RAGMI_OK;
-  RAGMI_REQUIRE(ntail >= 0 && ntail <= 2 && (ntail == 0 || tails != nullptr), RAGMI_EINVAL, "conv3d_k3: 0..2 tails");
+  RAGMI_REQUIRE(ntail >= 0 && ntail <= 4 && (ntail == 0 || tails != nullptr), RAGMI_EINVAL, "conv3d_k3: 0..4 tails");
   RAGMI_REQUIRE(ntail > 0 || store_main, RAGMI_EINVAL, "conv3d_k3: store_main = 0 needs at least one tail");
   const int ngroups = (Cout + 3) / 4;
   RAGMI_REQUIRE(ntail == 0 || (Cout % 4 == 0 && Cout <= 16 && split_groups(ngroups) == ngroups), RAGMI_EUNSUPPORTED,
@@ -66,12 +82,26 @@ static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* 
     RAGMI_REQUIRE(tails[t].weight && tails[t].y && tails[t].cout >= 1 && tails[t].cout <= 4 && tails[t].y_ch0 >= 0 &&
                       ((tails[t].scale == nullptr) == (tails[t].shift == nullptr)),
                   RAGMI_EINVAL, "conv3d_k3: bad tail %d (1..4 output channels)", t);
-    a.tail_w[t] = (const float*)tails[t].weight; a.tail_scale[t] = (const float*)tails[t].scale;
-    a.tail_shift[t] = (const float*)tails[t].shift; a.tail_y[t] = tails[t].y;
-    a.tail_bstride[t] = tails[t].y_bstride; a.tail_ch0[t] = tails[t].y_ch0; a.tail_cout[t] = tails[t].cout;
-    a.tail_relu[t] = tails[t].relu;
+    if (tails[t].relu & 2) {                       // down-sampling tail (ragmi_tail_t.relu bit 1)
+      const int k = a.ndown;
+      RAGMI_REQUIRE(k < 2, RAGMI_EUNSUPPORTED, "conv3d_k3: at most two down-sampling tails");
+      RAGMI_REQUIRE(down2_pairs_aligned(a.D) && down2_pairs_aligned(a.H) && down2_pairs_aligned(a.W), RAGMI_EUNSUPPORTED,
+                    "conv3d_k3: a down-sampling tail needs even D, H, W whose x0.5 source pairs are aligned (got %d x %d x %d)", a.D, a.H, a.W);
+      a.down_w[k] = (const float*)tails[t].weight; a.down_scale[k] = (const float*)tails[t].scale;
+      a.down_shift[k] = (const float*)tails[t].shift; a.down_y[k] = tails[t].y;
+      a.down_bstride[k] = tails[t].y_bstride; a.down_ch0[k] = tails[t].y_ch0; a.down_cout[k] = tails[t].cout;
+      a.down_relu[k] = tails[t].relu & 1;
+      ++a.ndown;
+      continue;
+    }
+    const int k = a.ntail;
+    RAGMI_REQUIRE(k < 2, RAGMI_EUNSUPPORTED, "conv3d_k3: at most two full-resolution tails");
+    a.tail_w[k] = (const float*)tails[t].weight; a.tail_scale[k] = (const float*)tails[t].scale;
+    a.tail_shift[k] = (const float*)tails[t].shift; a.tail_y[k] = tails[t].y;
+    a.tail_bstride[k] = tails[t].y_bstride; a.tail_ch0[k] = tails[t].y_ch0; a.tail_cout[k] = tails[t].cout;
+    a.tail_relu[k] = tails[t].relu & 1;
+    ++a.ntail;
   }
-  a.ntail = ntail;
   a.store_main = store_main ? 1 : 0;
   return RAGMI_OK;
 }
@@ -142,6 +172,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   const bool bf = dtype == RAGMI_BF16;
   if (x3d_eligible(a, 1, dtype)) return x3d_launch(a, 1, dtype, s);
   if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, dtype, s);
+  RAGMI_REQUIRE(a.ndown == 0, RAGMI_EUNSUPPORTED, "conv3d_k3: down-sampling tails need the z-marching split-operand form (ragmi_conv3d_k3_uses_x3)");
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s1_cfg0_bf16(a, ng, s) : launch_k3_s1_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s1_cfg1_bf16(a, ng, s) : launch_k3_s1_cfg1_f32(a, ng, s);
@@ -220,11 +251,16 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   const bool bf = dtype == RAGMI_BF16;
   if (x3d_eligible(a, 2, dtype)) return x3d_launch(a, 2, dtype, s);
   if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, dtype, s);
+  RAGMI_REQUIRE(a.ndown == 0, RAGMI_EUNSUPPORTED, "conv3d_k3_dual: down-sampling tails need the z-marching split-operand form (ragmi_conv3d_k3_uses_x3)");
   switch (choose_cfg(B, D, H, W)) {
     case 0: return bf ? launch_k3_s2_cfg0_bf16(a, ng, s) : launch_k3_s2_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s2_cfg1_bf16(a, ng, s) : launch_k3_s2_cfg1_f32(a, ng, s);
     default: return bf ? launch_k3_s2_cfg2_bf16(a, ng, s) : launch_k3_s2_cfg2_f32(a, ng, s);
   }
+}
+
+extern "C" int ragmi_down2_tail_supported(int D, int H, int W) {
+  return (ragmi::down2_pairs_aligned(D) && ragmi::down2_pairs_aligned(H) && ragmi::down2_pairs_aligned(W)) ? 1 : 0;
 }
 
 extern "C" int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int nset, int has_res, int ntail, int dtype) {

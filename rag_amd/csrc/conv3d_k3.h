@@ -82,6 +82,17 @@ struct K3Args {
   void* tail_y[2];
   int64_t tail_bstride[2];
   int tail_ch0[2], tail_cout[2], tail_relu[2];
+  // DOWN-SAMPLING tails (z-marching split-operand form only, conv3d_x3.hip): y_t = act(bn_t(trilinear x0.5, align_corners=True, of
+  // W_t * out)) written at HALF resolution [D/2, H/2, W/2] — the 1x1x1 ConvBR of a consumer cell that works one level down
+  // (Cell_3d with downup_sample = -1, rag_model.py:146-155), computed conv-first in the producer's epilogue.  They take the slots
+  // ntail .. ntail + ndown - 1 of the tail product (4 output channels each).
+  int ndown;
+  const float* down_w[2];
+  const float* down_scale[2];
+  const float* down_shift[2];
+  void* down_y[2];
+  int64_t down_bstride[2];
+  int down_ch0[2], down_cout[2], down_relu[2];
   int w_in_lds;    // 1: the workgroup's weights (all chunks, both sets) are cached in LDS behind the tile
   int y_ch[RAGMI_MAX_GROUPS];    // destination channel base of each output group
   int res_ch[RAGMI_MAX_GROUPS];

@@ -29,7 +29,8 @@ namespace ragmi {
 // K-slice are in flight under the MFMAs of the current one) and the prefetch registers are static.
 // T = activation storage: float (three MFMAs per product) or bf16_t (the activations ARE bf16: no lo copy, two MFMAs per
 // product — weight hi and lo — and half the LDS operand traffic)
-template <class T, int NCG, int NSET, bool TAILS>
+// TAILS: 0 none, 1 fused consumer 1x1x1 convs at full resolution, 2 also DOWN-SAMPLING ones (see K3Args::ndown and the finishing step)
+template <class T, int NCG, int NSET, int TAILS>
 __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
@@ -49,6 +50,11 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // static scale[2][16] (BatchNorm scale x the weights' 2^-k) | the column's running max |x| (float bits)
   float* const par = reinterpret_cast<float*>(loff + 3 * NSL * 4);
   unsigned* const lmaxp = reinterpret_cast<unsigned*>(par + 128);
+  // down-sampling tails (TAILS == 2): x-blended tail values of two consecutive planes U[plane parity][down slot 2][4 ch][8 rows][16] |
+  // x table [16]{w0, w1, a-from-odd, b-from-odd} | y table [4]{...}
+  float* const ldu = par + 132;
+  float4* const ldxt = reinterpret_cast<float4*>(ldu + 2 * 2 * 4 * X3_TY * (X3_TX / 2));
+  float4* const ldyt = ldxt + X3_TX / 2;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog = blockIdx.y;
   const int HW = a.H * a.W;
@@ -98,6 +104,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const int c = cog * 16 + 4 * kb + j;
       float wv = 0.f;
       if (tl < a.ntail && k < a.tail_cout[tl] && c < a.Cout) wv = a.tail_w[tl][k * a.Cout + c];
+      if constexpr (TAILS == 2) {
+        const int dl = tl - a.ntail;                   // down slot of this row
+        if (dl >= 0 && dl < a.ndown && k < a.down_cout[dl < 2 ? dl : 0] && c < a.Cout) wv = a.down_w[dl < 2 ? dl : 0][k * a.Cout + c];
+      }
       wh[j] = x3_bf16_rn(wv);
       const float r1 = wv - __uint_as_float((unsigned)wh[j] << 16);
       wm[j] = x3_bf16_rn(r1);
@@ -117,6 +127,14 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const bool ok = tk < a.ntail && r < a.tail_cout[tk < 2 ? tk : 0];
       par[64 + tid] = (ok && a.tail_scale[tk < 2 ? tk : 0]) ? a.tail_scale[tk < 2 ? tk : 0][r] : 1.f;
       par[80 + tid] = (ok && a.tail_shift[tk < 2 ? tk : 0]) ? a.tail_shift[tk < 2 ? tk : 0][r] : 0.f;
+      if constexpr (TAILS == 2) {
+        const int dl = tk - a.ntail, d2 = dl >= 0 && dl < 2 ? dl : 0;
+        if (dl >= 0 && dl < a.ndown) {
+          const bool okd = r < a.down_cout[d2] && a.down_scale[d2] != nullptr;
+          par[64 + tid] = okd ? a.down_scale[d2][r] : 1.f;
+          par[80 + tid] = okd ? a.down_shift[d2][r] : 0.f;
+        }
+      }
     }
   }
   float pf[NPF][4];
@@ -209,6 +227,36 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   const int tsel = kb & 1;
   // XCD-aware schedule: workgroup j runs on XCD j % 8 (round-robin dispatch); give every XCD one contiguous chunk of the
   // (x-fastest) work list so that neighbouring columns — which share halo rows and cache lines — meet in the same L2
+  // Down-sampling tails, second half: the planes 2Z (LDS parity 0) and 2Z+1 (parity 1) of the x-blended tail values are complete ->
+  // blend along y, then z (ATen's nesting: x innermost), BatchNorm + ReLU, store the half-resolution tile (4 rows x 16 columns per slot
+  // channel): one output per thread and plane pair.
+  auto down_finish = [&](int zodd, int b, int y0, int x0) {
+    if constexpr (TAILS == 2) {
+      const int Z = zodd >> 1, Do = a.D >> 1, Ho = a.H >> 1, Wo = a.W >> 1;
+      const LinIdx lz = lin_index(min(Z, Do - 1), a.D, Do, e.dsd, 1);            // wave-uniform
+      const bool za = lz.i0 != 2 * Z, zb = lz.i1 != 2 * Z;
+      const int64_t ovol = (int64_t)Do * Ho * Wo;
+      for (int o = tid; o < a.ndown * 256; o += X3_THREADS) {
+        const int dl = o >> 8, r = (o >> 6) & 3, yp = (o >> 4) & 3, xp = o & 15;
+        const float4 yt = ldyt[yp];
+        const float* const u0 = ldu + ((0 * 2 + dl) * 4 + r) * (X3_TY * (X3_TX / 2)) + (2 * yp) * (X3_TX / 2) + xp;
+        const float* const u1 = u0 + 2 * 4 * (X3_TY * (X3_TX / 2));
+        const float e0 = u0[0], e1 = u0[X3_TX / 2], o0 = u1[0], o1 = u1[X3_TX / 2];
+        const float ye = lerp2(yt.x, yt.z != 0.f ? e1 : e0, yt.y, yt.w != 0.f ? e1 : e0);
+        const float yo = lerp2(yt.x, yt.z != 0.f ? o1 : o0, yt.y, yt.w != 0.f ? o1 : o0);
+        const float v = lerp2(lz.w0, za ? yo : ye, lz.w1, zb ? yo : ye);
+        const int slot = a.ntail + dl;
+        const float uu = fmaf(v, par[64 + 4 * slot + r], par[80 + 4 * slot + r]);
+        const int dcout = dl ? a.down_cout[1] : a.down_cout[0], drelu = dl ? a.down_relu[1] : a.down_relu[0];
+        const int Y = (y0 >> 1) + yp, X = (x0 >> 1) + xp;
+        if (r < dcout && Y < Ho && X < Wo && Z < Do) {
+          T* const dy = static_cast<T*>(dl ? a.down_y[1] : a.down_y[0]) + b * (dl ? a.down_bstride[1] : a.down_bstride[0]) +
+                        (int64_t)((dl ? a.down_ch0[1] : a.down_ch0[0]) + r) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
+          st(dy, drelu ? fmaxf(uu, 0.f) : uu);
+        }
+      }
+    }
+  };
   const int chunk = (e.nwork + 7) / 8;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
     const int work = (j & 7) * chunk + (j >> 3);
@@ -230,6 +278,17 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
     locate(y0, x0);
     if constexpr (!BF) { if (tid < 2) lmaxp[tid] = 0u; }  // (ordered before the first atomicMax below by the barrier that follows)
+    if constexpr (TAILS == 2) {
+      // interpolation tables of this column's half-resolution outputs: (w0, w1, first operand from the ODD source, second from the ODD
+      // source) — the source pair of output o is (2o, 2o+1) except where the last output of an axis clamps (host-checked)
+      if (tid < X3_TX / 2 + X3_TY / 2) {
+        const bool isx = tid < X3_TX / 2;
+        const int o = isx ? (x0 >> 1) + tid : (y0 >> 1) + (tid - X3_TX / 2), in = isx ? a.W : a.H;
+        const LinIdx l = lin_index(min(o, (in >> 1) - 1), in, in >> 1, isx ? e.dsw : e.dsh, 1);
+        const float4 ent = make_float4(l.w0, l.w1, l.i0 != 2 * o ? 1.f : 0.f, l.i1 != 2 * o ? 1.f : 0.f);
+        if (isx) ldxt[tid] = ent; else ldyt[tid - X3_TX / 2] = ent;
+      }
+    }
     int zfirst = zs;
     // fp32 storage: the ring (re)starts at plane zfirst with the operand scale chosen from that plane — its largest |x| lands at
     // 2^10..2^11, a factor >= 16 below fp16's range for the planes that follow; one that still does not fit restarts the ring at
@@ -258,6 +317,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       bool again = false;
     for (int z = zfirst; z < ze; ++z) {
       __syncthreads();                                 // plane z-2 (same ring slot as z+1) is no longer read
+      if constexpr (TAILS == 2) { if (z > zs && !(z & 1)) down_finish(z - 1, b, y0, x0); }     // planes z-2, z-1 are complete (segments start even)
       if constexpr (!BF) note_overflow();
       commit((z + 1) % 3);
       __syncthreads();
@@ -352,10 +412,30 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
                 st(pt + r * DHW, trelu ? fmaxf(u, 0.f) : u);
               }
           }
+          if constexpr (TAILS == 2) {
+            // down-sampling tail, first half: blend the raw tail values of the source pair (x = 2X, 2X+1: this lane and the next)
+            // and park the result in the LDS for the finishing step (even lanes: X' = 8 (x half) + n / 2)
+            const int dl = kb - a.ntail;
+            if (dl >= 0 && dl < a.ndown) {
+              const float4 xt = ldxt[8 * (nt & 1) + (n >> 1)];
+              float* const du = ldu + (((z & 1) * 2 + dl) * 4) * (X3_TY * (X3_TX / 2)) + (nt >> 1) * (X3_TX / 2) + 8 * (nt & 1) + (n >> 1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float p0 = tacc[r];
+                const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p0), 0x101, 0xF, 0xF, false));   // row_shl:1: the next lane's
+                const float ux = lerp2(xt.x, xt.z != 0.f ? p1 : p0, xt.y, xt.w != 0.f ? p1 : p0);
+                if (!(n & 1)) du[r * (X3_TY * (X3_TX / 2))] = ux;
+              }
+            }
+          }
         }
       }
     }
       if (!again) break;
+    }
+    if constexpr (TAILS == 2) {
+      __syncthreads();                                 // the segment's last (odd) plane is in the LDS
+      down_finish(ze - 1, b, y0, x0);
     }
   }
 }
@@ -625,7 +705,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
 }
 
 bool x3d_eligible(const K3Args& a, int nset, int dtype) {
-  if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || a.res != nullptr || a.ntail > 0 || !a.store_main) return false;
+  if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || a.res != nullptr || a.ntail > 0 || a.ndown > 0 || !a.store_main) return false;
   const int nc = a.nchunks[0];
   if ((nc != 2 && nc != 4) || (nset == 2 && a.nchunks[1] != nc) || a.Cin != nset * nc * 4 || a.Cout % 4 != 0) return false;
   // volumes only (the depth-1 Feature-Net convolutions would idle half of every 2-deep box), and big enough that the persistent
@@ -736,12 +816,13 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
   if (nset == 1 && ncg > 6) return false;
   // voxels per SAMPLE: the choice of kernel (hence the rounding) must not depend on how a batch is split over ranks
   if ((int64_t)a.D * a.H * a.W < X3_MIN_VOXELS || a.W < 32 || a.D < 8) return false;
-  if (a.ntail > 0 && a.Cout > 16) return false;
+  if ((a.ntail > 0 || a.ndown > 0) && a.Cout > 16) return false;
+  if (a.ndown > 0 && dtype != RAGMI_F32X3) return false;              // down-sampling tails: fp32 storage only
   if ((int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
   return true;
 }
 
-template <class T, int NCG, int NSET, bool TAILS>
+template <class T, int NCG, int NSET, int TAILS>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
   static LaunchState state;     // per device, mutex-guarded (common.h)
   // persistent grid = the workgroups the chip holds at once (occupancy x CUs): measured on the level-3 launches (1664 work items)
@@ -754,7 +835,11 @@ static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t 
 }
 template <class T, int NCG, int NSET>
 static int x3_launch_typed(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
-  return a.ntail > 0 ? x3_launch_tails<T, NCG, NSET, true>(a, e, grid, lds, st) : x3_launch_tails<T, NCG, NSET, false>(a, e, grid, lds, st);
+  if constexpr (std::is_same<T, float>::value && NCG <= 3) {      // down-sampling tails: fp32 storage, the level-3 launches (<= 3 channel groups)
+    if (a.ndown > 0) return x3_launch_tails<T, NCG, NSET, 2>(a, e, grid, lds, st);
+  }
+  if (a.ndown > 0) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: down-sampling tails are built for fp32 storage and <= 12 input channels");
+  return a.ntail > 0 ? x3_launch_tails<T, NCG, NSET, 1>(a, e, grid, lds, st) : x3_launch_tails<T, NCG, NSET, 0>(a, e, grid, lds, st);
 }
 template <int NCG, int NSET>
 static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
@@ -777,6 +862,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   const int64_t cols_seg = dtype == RAGMI_BF16 ? cols : (int64_t)a.tiles_x * a.tiles_y;
   const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(1536, cols_seg * ncog), ceil_div(a.D, 8)));
   e.seg_len = (int)ceil_div(a.D, nseg);
+  if (a.ndown > 0) e.seg_len += e.seg_len & 1;         // down-sampling tails pair the planes (2Z, 2Z+1): segments start and end even
   e.nseg = (int)ceil_div(a.D, e.seg_len);
   // Work items.  The persistent grid holds 64 workgroups per XCD (two per CU) and each XCD walks one contiguous eighth of the list, so a
   // sample's (column, segment) pairs are dealt in 8 groups of `grp`; 208 per group at the headline shape = 3 full rounds of 64 and a
@@ -791,12 +877,17 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
     const int rem = e.grp % 64;
     if (rem > 0 && rem <= 32) e.nsplit = rem;
   }
+  if (a.ndown > 0) {
+    if (e.seg_len % 4 != 0) e.nsplit = 0;               // (the halves of a split segment must be even too)
+    e.dsd = lin_scale(a.D, a.D / 2, 1); e.dsh = lin_scale(a.H, a.H / 2, 1); e.dsw = lin_scale(a.W, a.W / 2, 1);
+  }
   const int64_t nwork = (int64_t)a.B * e.ngrp * (e.grp + e.nsplit);
   RAGMI_REQUIRE(nwork < (1ll << 31) && per_sample < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
   e.bf16 = dtype == RAGMI_BF16 ? 1 : 0;
   const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_HY * x3_row_stride(ncg) * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
-                     3 * 64 * sizeof(uint4) + 132 * sizeof(float);
+                     3 * 64 * sizeof(uint4) + 132 * sizeof(float) +
+                     (a.ndown > 0 ? (size_t)(2 * 2 * 4 * X3_TY * (X3_TX / 2)) * sizeof(float) + (size_t)(X3_TX / 2 + X3_TY / 2) * sizeof(float4) : 0);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
   const dim3 grid((unsigned)std::min<int64_t>(nwork, 1 << 20), ncog);      // x is cut to the resident slots where the kernel is known
   if (nset == 2) {

@@ -170,6 +170,7 @@ struct X3Extra {
   const float* wmul[2];      // fp16 section: per-output-channel multiplier 2^-k that undoes the weight scale (null for bf16 storage)
   int nseg, seg_len, nwork, bf16;   // bf16 != 0: bf16 activation storage (kernel instantiation selector)
   int ngrp, grp, nsplit;     // z-marching form: groups per sample; (column, segment) pairs per group of a sample, of which the last nsplit are two half items
+  float dsd, dsh, dsw;       // down-sampling tails: (in - 1) / (in / 2 - 1) per axis (lin_scale, align_corners=True)
 };
 // fragment words (floats) of ONE section for a conv with these channel counts
 inline int64_t x3_frag_words(int Cout, int Cin) {

@@ -174,6 +174,19 @@ class _ConvBR(nn.Module):
         wk, scale, shift = self.prepared()
         return ops.Tail(wk, scale, shift, self.relu, out, out_ch0)
 
+    def as_down_tails(self, out: torch.Tensor, out_ch0: int) -> List["ops.Tail"]:
+        """This 1x1x1 ConvBR (<= 8 output channels) applied to the x0.5 trilinear down-sampling of the producer's output, as one or
+        two down-sampling tails (4 output channels each) of the kernel that produces its input; `out` is at half resolution."""
+        if self._geometry() != 1 or self.conv.out_channels > 8:
+            raise ValueError("only 1x1x1 ConvBR with <= 8 output channels can be fused as down-sampling tails")
+        wk, scale, shift = self.prepared()
+        tails = []
+        for c0 in range(0, self.conv.out_channels, 4):
+            c1 = min(c0 + 4, self.conv.out_channels)
+            tails.append(ops.Tail(wk[c0:c1], None if scale is None else scale[c0:c1], None if shift is None else shift[c0:c1],
+                                  self.relu, out, out_ch0 + c0, down=True))
+        return tails
+
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_ch0: int = 0,
                 resample_to: Optional[Sequence[int]] = None, tails: Optional[Sequence["ops.Tail"]] = None,
                 store_main: bool = True, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -721,16 +734,38 @@ class MatchingNet(nn.Module):
         ref = x if x is not None else features[0]
         B, dev, adt = ref.shape[0], ref.device, ref.dtype
 
+        def down_ok(i, j):
+            """cell j's 1x1x1 conv on T[i] as DOWN-SAMPLING tails of T[i]'s producer: cell j works at exactly half of T[i]'s size,
+            the source pairs of that x0.5 resampling are aligned, and the producer is a level-3 dual launch on the z-marching
+            split-operand kernel (fp32 storage, default precision) — the only form that takes them"""
+            if i < 0 or adt != torch.float32 or ops.get_conv_precision() != "f16x3":
+                return False
+            src, dst, prod = sizes[i], sizes[j], cells[i]
+            if tuple(2 * v for v in dst) != tuple(src) or not ops.down2_tail_supported(*src):
+                return False
+            cj = cells[j]
+            if cj.C_out > 8 or cj.C_out % 4 != 0:
+                return False
+            # the producer: one dual launch with all its new states (what `_run` calls single_dual), 12 output channels, on the x3 form
+            if prod.downup_sample != 0 or prod.C_out * prod._steps > 16 or prod.C_out != 4:
+                return False
+            return ops.conv3d_k3_uses_x3(2 * prod.C_out, prod.C_out * prod._steps, B, *src, nset=2, ntail=1, dtype=adt)
+
         def fusable(i):
-            """consumers of T[i] that can ride on its producer: [(cell index j, role 0 = pre_preprocess / 1 = preprocess)]"""
+            """consumers of T[i] that can ride on its producer: [(cell index j, role 0 = pre_preprocess / 1 = preprocess, down)]"""
             out = []
             j = i + 1
             if 0 <= j < n and cells[j].downup_sample == 0 and cells[j].C_out <= 4 and cells[j].C_out % 4 == 0:
-                out.append((j, 1))
+                out.append((j, 1, False))
+            elif 0 <= j < n and cells[j].downup_sample == -1 and down_ok(i, j):
+                out.append((j, 1, True))
             j = i + 2
             if (0 <= j < n and cells[j].downup_sample == 0 and cells[j - 1].downup_sample == 0 and cells[j].C_out <= 4
                     and cells[j].C_out % 4 == 0 and cells[j].C_prev_prev != cells[j].C_out):
-                out.append((j, 0))
+                out.append((j, 0, False))
+            elif (0 <= j < n and cells[j].downup_sample == -1 and cells[j - 1].downup_sample == 0 and cells[j].C_prev_prev != cells[j].C_out
+                  and down_ok(i, j)):
+                out.append((j, 0, True))
             return out
 
         def all_consumers(i):
@@ -740,42 +775,48 @@ class MatchingNet(nn.Module):
         has: Dict[int, List[bool]] = {}
 
         def tails_for(i):
+            """[(consumer cell j, role, [Tail, ...])]: one full-resolution tail, or the one / two down-sampling tails of a consumer
+            that works one level down"""
             specs = []
-            for (j, role) in fusable(i):
+            for (j, role, down) in fusable(i):
                 if j not in pre:
                     pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=adt)
                     has[j] = [False, False]
                 mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
-                specs.append((j, role, mod.as_tail(pre[j], cells[j].C_out if role == 1 else 0)))
+                ch0 = cells[j].C_out if role == 1 else 0
+                specs.append((j, role, mod.as_down_tails(pre[j], ch0) if down else [mod.as_tail(pre[j], ch0)]))
             return specs
+
+        def flat(specs):
+            return [t for (_j, _r, ts) in specs for t in ts] or None
 
         def settle(i, specs, applied, tensor):
             """mark fused consumers as done, or run them as plain 1x1x1 launches if the producer could not fuse them"""
-            for (j, role, tail) in specs:
+            for (j, role, ts) in specs:
                 if not applied:
                     mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
-                    mod(tensor, out=pre[j], out_ch0=tail.out_ch0)
+                    mod(tensor, out=pre[j], out_ch0=ts[0].out_ch0, resample_to=sizes[j] if ts[0].down else None)
                 has[j][role] = True
 
         T: Dict[int, Optional[torch.Tensor]] = {}
         # stem3d0: its output also feeds stem3d1 (3x3x3), so it is always materialised
         specs = tails_for(-2)
         if x is None:
-            T[-2] = stem0.forward_costvol(features[0], features[1], self.maxdisp, tails=[s[2] for s in specs] or None)
+            T[-2] = stem0.forward_costvol(features[0], features[1], self.maxdisp, tails=flat(specs))
         else:
-            T[-2] = stem0(x, tails=[s[2] for s in specs] or None)
+            T[-2] = stem0(x, tails=flat(specs))
         settle(-2, specs, True, T[-2])
         # stem3d1
         specs = tails_for(-1)
         need_main = len(specs) < len(all_consumers(-1)) or n == 0
-        out1 = stem1(T[-2], tails=[s[2] for s in specs] or None, store_main=need_main or not specs)
+        out1 = stem1(T[-2], tails=flat(specs), store_main=need_main or not specs)
         T[-1] = out1 if (need_main or not specs) else None
         settle(-1, specs, True, out1)
         for i, c in enumerate(cells):
             specs = tails_for(i)
             need_main = i == n - 1 or len(specs) < len(all_consumers(i))   # the head reads the last cell's output
             cat, applied = c._run(T[i - 2], T[i - 1], pre=pre.get(i), pre_has=tuple(has.get(i, (False, False))),
-                                  tails=[s[2] for s in specs] or None, store_main=need_main, size=sizes[i])
+                                  tails=flat(specs), store_main=need_main, size=sizes[i])
             settle(i, specs, applied, cat)
             T[i] = cat
             T.pop(i - 2, None)

@@ -117,22 +117,28 @@ class Tail:
     out[:, ch0:ch0+cout] = act(bn(weight2d @ producer_output)) (weight2d [cout <= 4, C_producer])."""
 
     def __init__(self, weight2d: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool,
-                 out: torch.Tensor, out_ch0: int):
+                 out: torch.Tensor, out_ch0: int, down: bool = False):
+        """down=True: a DOWN-SAMPLING tail — `out` is at half the producer's resolution and receives
+        act(bn(F.interpolate(weight2d @ producer_output, half size, 'trilinear', align_corners=True))) (ragmi_tail_t.relu bit 1)."""
         _need_gpu(weight2d, scale, shift)
         _act(out)
+        for t in (weight2d, scale, shift):
+            if t is not None and not t.is_contiguous():
+                raise ValueError("Tail: weight / scale / shift must be contiguous (row slices of contiguous tensors are)")
         self.weight2d, self.scale, self.shift, self.relu, self.out, self.out_ch0 = weight2d, scale, shift, relu, out, out_ch0
+        self.down = bool(down)
 
     def spec(self) -> TailSpec:
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        return TailSpec(p(self.weight2d), p(self.scale), p(self.shift), int(self.relu), self.out.data_ptr(),
+        return TailSpec(p(self.weight2d), p(self.scale), p(self.shift), int(self.relu) | (2 if self.down else 0), self.out.data_ptr(),
                         _planes(self.out), int(self.out_ch0), int(self.weight2d.shape[0]))
 
 
 def _tail_array(tails: Optional[Sequence["Tail"]]):
     if not tails:
         return 0, None
-    if len(tails) > 2:
-        raise ValueError("at most two fused tails per conv launch")
+    if sum(1 for t in tails if not t.down) > 2 or sum(1 for t in tails if t.down) > 2:
+        raise ValueError("at most two full-resolution and two down-sampling tails per conv launch")
     arr = (TailSpec * len(tails))(*[t.spec() for t in tails])
     return len(tails), arr
 
@@ -386,6 +392,12 @@ def conv2d_k3_strided(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu:
     check(load_library().ragmi_conv2d_k3_strided_fwd(x.data_ptr(), w.data_ptr(), p(scale), p(shift), int(relu), out.data_ptr(),
                                                      B, Cin, Cout, H, W, int(stride), dt, _stream()), "conv2d_k3_strided")
     return out
+
+
+def down2_tail_supported(D: int, H: int, W: int) -> bool:
+    """True when a x0.5 trilinear down-sampling (align_corners=True) of a [D, H, W] volume reads aligned source pairs (2o, 2o+1) on
+    every axis — what a down-sampling tail needs (ragmi_down2_tail_supported)."""
+    return bool(load_library().ragmi_down2_tail_supported(int(D), int(H), int(W)))
 
 
 def upconv3d_c1_supported(cin: int, di: int, hi: int, wi: int) -> bool:

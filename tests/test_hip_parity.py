@@ -1036,6 +1036,55 @@ def test_x3_deep_form_vs_oracle(ra, x3_on, nset, cs, cout, shape, dtype):
     np.testing.assert_allclose(out.float().cpu().numpy(), exp.numpy(), **tol)
 
 
+@pytest.mark.parametrize("shape,nreg,couts", [((1, 16, 128, 128), 1, (8,)),         # cell 1's launch: one full-resolution tail + a 12 -> 8 down pair
+                                              ((2, 16, 132, 160), 0, (8,)),         # cell 2's launch: down tails only; two samples; partial tiles
+                                              ((1, 32, 128, 64), 2, (4, 4))])       # two regular tails + two separate 4-channel down tails
+def test_x3_down_sampling_tails(ra, x3_on, shape, nreg, couts):
+    """Down-sampling tails of the z-marching split-operand kernel (round 4): the 1x1x1 ConvBR_3d of a consumer cell that works one
+    level down — F.interpolate(x, half size, 'trilinear', align_corners=True) followed by pre_preprocess / preprocess
+    (rag_model.py:146-155) — computed conv-first in the PRODUCER's epilogue, against the reference order (resample, then mix)
+    evaluated by ATen in fp32 / float64.  The producer's own output and its full-resolution tails must be unchanged."""
+    B, D, H, W = shape
+    C, cout = 4, 12
+    g1 = gen(191)
+    x = torch.randn((B, 2 * C, D, H, W), generator=g1)
+    wa, wb = (torch.randn((cout, C, 3, 3, 3), generator=g1) * 0.2 for _ in range(2))
+    sa, sb = (torch.rand(cout, generator=g1) + 0.5 for _ in range(2))
+    ha, hb = (torch.randn(cout, generator=g1) * 0.1 for _ in range(2))
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    main = sum(F.relu(F.conv3d(x[:, i * C:(i + 1) * C].double(), w.double(), padding=1) * v(s.double()) + v(h.double()))
+               for i, (w, s, h) in enumerate(((wa, sa, ha), (wb, sb, hb))))
+    assert ra.ops.down2_tail_supported(D, H, W)
+    half = (D // 2, H // 2, W // 2)
+    tails, checks = [], []
+    for k in range(nreg):
+        tw, ts, th = torch.randn((4, cout), generator=g1) * 0.3, torch.rand(4, generator=g1) + 0.5, torch.randn(4, generator=g1) * 0.1
+        out = torch.full((B, 5, D, H, W), float("nan"), device=DEV)
+        tails.append(ra.ops.Tail(gpu(tw), gpu(ts), gpu(th), True, out, 1))
+        ref = F.relu(torch.einsum("oc,bcdhw->bodhw", tw.double(), main) * v(ts.double()) + v(th.double()))
+        checks.append((out, 1, 4, ref))
+    for k, co in enumerate(couts):
+        tw, ts, th = torch.randn((co, cout), generator=g1) * 0.3, torch.rand(co, generator=g1) + 0.5, torch.randn(co, generator=g1) * 0.1
+        out = torch.full((B, co + 2, ) + half, float("nan"), device=DEV)
+        gw, gs, gh = gpu(tw), gpu(ts), gpu(th)
+        for c0 in range(0, co, 4):
+            tails.append(ra.ops.Tail(gw[c0:c0 + 4], gs[c0:c0 + 4], gh[c0:c0 + 4], k == 0, out, 1 + c0, down=True))
+        low = F.interpolate(main.float(), half, mode="trilinear", align_corners=True).double()      # the reference order: resample first
+        ref = torch.einsum("oc,bcdhw->bodhw", tw.double(), low) * v(ts.double()) + v(th.double())
+        checks.append((out, 1, co, F.relu(ref) if k == 0 else ref))
+    ones = lambda t: gpu(t)  # noqa: E731
+    y = torch.full((B, cout, D, H, W), float("nan"), device=DEV)
+    with ra.ops.conv_precision("f16x3"):
+        assert ra.ops.conv3d_k3_uses_x3(2 * C, cout, B, D, H, W, nset=2, ntail=len(tails))
+        ra.ops.conv3d_k3_dual(gpu(x), C, ra.ops.conv3d_k3_pack(gpu(wa)), ones(sa), ones(ha), ra.ops.conv3d_k3_pack(gpu(wb)), ones(sb), ones(hb),
+                              cout, True, y, tails=tails)
+    np.testing.assert_allclose(y.cpu().double().numpy(), main.numpy(), rtol=2e-4, atol=2e-4)
+    for (out, ch0, co, ref) in checks:
+        got = out.cpu().double()
+        assert torch.isnan(got[:, 0]).all() and torch.isnan(got[:, ch0 + co:]).all()
+        np.testing.assert_allclose(got[:, ch0:ch0 + co].numpy(), ref.numpy(), rtol=3e-4, atol=3e-4)
+
+
 def test_x3_dual_tails_and_headline_epe(ra, x3_on):
     """The level-3 launches of the headline forward (stem3d1 with fused tails and no main store, dual cells) on the f16x3
     kernel: EPE vs the CPU oracle stays within the gate (measured 1.2e-4 px; fp32-MFMA path 1.5e-5 px)."""
