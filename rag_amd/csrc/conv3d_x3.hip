@@ -50,8 +50,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // static scale[2][16] (BatchNorm scale x the weights' 2^-k) | the column's running max |x| (float bits)
   float* const par = reinterpret_cast<float*>(loff + 3 * NSL * 4);
   unsigned* const lmaxp = reinterpret_cast<unsigned*>(par + 128);
-  // down-sampling tails (TAILS == 2): x-blended tail values of two consecutive planes U[plane parity][down slot 2][4 ch][8 rows][16] |
-  // x table [16]{w0, w1, a-from-odd, b-from-odd} | y table [4]{...}
+  // down-sampling tails (TAILS == 2): x-blended tail values of two consecutive planes U[plane parity][down slot 2][8 rows][16][4 ch] |
+  // x table [16]{w0, w1: weights of the source pair (2X, 2X+1)} | y table [4]{...}
   float* const ldu = par + 132;
   float4* const ldxt = reinterpret_cast<float4*>(ldu + 2 * 2 * 4 * X3_TY * (X3_TX / 2));
   float4* const ldyt = ldxt + X3_TX / 2;
@@ -87,39 +87,28 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     par[32 + i] = (ok && a.shift[set]) ? a.shift[set][co] : 0.f;
   }
   if (tid < 2) lmaxp[tid] = 0u;
-  // Fused consumer 1x1x1 convs ("tails") on the matrix cores: out_t[k][voxel] = sum_c W_t[k][c] * v[c][voxel] is a few more
-  // 16x16x32 products whose K slots are laid out so that every lane quarter feeds ITS OWN four channels (slots 8kb..8kb+3 and
-  // 8kb+4..8kb+7 carry two 16-bit parts of channels 4kb..4kb+3), so no value crosses lanes.  Rows: tail 0 -> 0..3, tail 1 -> 4..7.
-  // Operands stay bf16 here (the fp32 exponent range: the epilogue's values have no scale), split in THREE parts each,
-  // v = vh + vm + vl and W = Wh + Wm + Wl (24 significant bits), and the six products of order <= 2 ride three MFMAs:
-  //   ta1 = [Wh | Wh] x [vh | vm],  ta2 = [Wh | Wm] x [vl | vh],  ta3 = [Wm | Wl] x [vm | vh]
-  // (bf16 activation storage: v is rounded to bf16 at the store anyway; the same three products keep the code single)
+  // Fused consumer 1x1x1 convs ("tails") on the matrix cores: out_t[k][voxel] = sum_c W_t[k][c] * v[c][voxel] as four 16x16x4 fp32
+  // products laid out so that every lane quarter feeds ITS OWN four channels (product r: channel 4 kb + r of each quarter), so no
+  // value crosses lanes.  Rows: tail 0 -> 0..3, tail 1 -> 4..7, down-sampling tails after them.
   // (TAILS is compile time; the tail fragments and parameters live in LDS and are fetched in the epilogue — in registers they cost
   // ~20 VGPRs of a 128-VGPR budget and the main loop spilled)
   if constexpr (TAILS) {
-    unsigned short wh[4], wm[4], wl[4];
-    const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = cog * 16 + 4 * kb + j;
-      float wv = 0.f;
-      if (tl < a.ntail && k < a.tail_cout[tl] && c < a.Cout) wv = a.tail_w[tl][k * a.Cout + c];
-      if constexpr (TAILS == 2) {
-        const int dl = tl - a.ntail;                   // down slot of this row
-        if (dl >= 0 && dl < a.ndown && k < a.down_cout[dl < 2 ? dl : 0] && c < a.Cout) wv = a.down_w[dl < 2 ? dl : 0][k * a.Cout + c];
-      }
-      wh[j] = x3_bf16_rn(wv);
-      const float r1 = wv - __uint_as_float((unsigned)wh[j] << 16);
-      wm[j] = x3_bf16_rn(r1);
-      wl[j] = x3_bf16_rn(r1 - __uint_as_float((unsigned)wm[j] << 16));
-    }
-    auto pk2 = [](const unsigned short* p, const unsigned short* q) {
-      return make_uint4(p[0] | ((unsigned)p[1] << 16), p[2] | ((unsigned)p[3] << 16), q[0] | ((unsigned)q[1] << 16), q[2] | ((unsigned)q[3] << 16));
-    };
+    // (round 4: the tail products run on v_mfma_f32_16x16x4_f32 — four EXACT fp32 products, product r taking channel 4 kb + r of
+    // every lane quarter — instead of three bf16 products of three-way split operands: the splits were ~28 vector instructions per
+    // tile in a kernel bound by vector issue; the fp32 MFMA holds the issue port for 8 of its 32 cycles)
     if (tid < 64) {
-      ltail[lane] = pk2(wh, wh);
-      ltail[64 + lane] = pk2(wh, wm);
-      ltail[128 + lane] = pk2(wm, wl);
+      const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = cog * 16 + 4 * kb + j;
+        float wv = 0.f;
+        if (tl < a.ntail && k < a.tail_cout[tl] && c < a.Cout) wv = a.tail_w[tl][k * a.Cout + c];
+        if constexpr (TAILS == 2) {
+          const int dl = tl - a.ntail;                   // down slot of this row
+          if (dl >= 0 && dl < a.ndown && k < a.down_cout[dl < 2 ? dl : 0] && c < a.Cout) wv = a.down_w[dl < 2 ? dl : 0][k * a.Cout + c];
+        }
+        reinterpret_cast<float*>(ltail)[j * 64 + lane] = wv;
+      }
     }
     // this lane's tail outputs after that product: rows 4 kb + r -> tail kb, output r
     if (tid < 16) {
@@ -234,25 +223,30 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     if constexpr (TAILS == 2) {
       const int Z = zodd >> 1, Do = a.D >> 1, Ho = a.H >> 1, Wo = a.W >> 1;
       const LinIdx lz = lin_index(min(Z, Do - 1), a.D, Do, e.dsd, 1);            // wave-uniform
-      const bool za = lz.i0 != 2 * Z, zb = lz.i1 != 2 * Z;
+      const float wz0 = lz.i0 == 2 * Z ? lz.w0 : 0.f, wz1 = lz.i0 == 2 * Z ? lz.w1 : 1.f;
       const int64_t ovol = (int64_t)Do * Ho * Wo;
-      for (int o = tid; o < a.ndown * 256; o += X3_THREADS) {
-        const int dl = o >> 8, r = (o >> 6) & 3, yp = (o >> 4) & 3, xp = o & 15;
+      const int o = tid;                                                          // (slot, row pair, column): 4 channels each
+      if (o < a.ndown * 64) {
+        const int dl = o >> 6, yp = (o >> 4) & 3, xp = o & 15;
         const float4 yt = ldyt[yp];
-        const float* const u0 = ldu + ((0 * 2 + dl) * 4 + r) * (X3_TY * (X3_TX / 2)) + (2 * yp) * (X3_TX / 2) + xp;
-        const float* const u1 = u0 + 2 * 4 * (X3_TY * (X3_TX / 2));
-        const float e0 = u0[0], e1 = u0[X3_TX / 2], o0 = u1[0], o1 = u1[X3_TX / 2];
-        const float ye = lerp2(yt.x, yt.z != 0.f ? e1 : e0, yt.y, yt.w != 0.f ? e1 : e0);
-        const float yo = lerp2(yt.x, yt.z != 0.f ? o1 : o0, yt.y, yt.w != 0.f ? o1 : o0);
-        const float v = lerp2(lz.w0, za ? yo : ye, lz.w1, zb ? yo : ye);
+        const float4* const u0 = reinterpret_cast<const float4*>(ldu) + ((0 * 2 + dl) * X3_TY + 2 * yp) * (X3_TX / 2) + xp;
+        const float4* const u1 = u0 + 2 * X3_TY * (X3_TX / 2);
+        const float4 e0 = u0[0], e1 = u0[X3_TX / 2], o0 = u1[0], o1 = u1[X3_TX / 2];
+        const float ev[4][4] = {{e0.x, e0.y, e0.z, e0.w}, {e1.x, e1.y, e1.z, e1.w}, {o0.x, o0.y, o0.z, o0.w}, {o1.x, o1.y, o1.z, o1.w}};
         const int slot = a.ntail + dl;
-        const float uu = fmaf(v, par[64 + 4 * slot + r], par[80 + 4 * slot + r]);
+        const float4 sc = *reinterpret_cast<const float4*>(par + 64 + 4 * slot), sh = *reinterpret_cast<const float4*>(par + 80 + 4 * slot);
+        const float sc4[4] = {sc.x, sc.y, sc.z, sc.w}, sh4[4] = {sh.x, sh.y, sh.z, sh.w};
         const int dcout = dl ? a.down_cout[1] : a.down_cout[0], drelu = dl ? a.down_relu[1] : a.down_relu[0];
         const int Y = (y0 >> 1) + yp, X = (x0 >> 1) + xp;
-        if (r < dcout && Y < Ho && X < Wo && Z < Do) {
+        if (Y < Ho && X < Wo && Z < Do) {
           T* const dy = static_cast<T*>(dl ? a.down_y[1] : a.down_y[0]) + b * (dl ? a.down_bstride[1] : a.down_bstride[0]) +
-                        (int64_t)((dl ? a.down_ch0[1] : a.down_ch0[0]) + r) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
-          st(dy, drelu ? fmaxf(uu, 0.f) : uu);
+                        (int64_t)(dl ? a.down_ch0[1] : a.down_ch0[0]) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ye = lerp2(yt.x, ev[0][r], yt.y, ev[1][r]), yo = lerp2(yt.x, ev[2][r], yt.y, ev[3][r]);
+            const float uu = fmaf(lerp2(wz0, ye, wz1, yo), sc4[r], sh4[r]);
+            if (r < dcout) st(dy + r * ovol, drelu ? fmaxf(uu, 0.f) : uu);
+          }
         }
       }
     }
@@ -285,7 +279,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         const bool isx = tid < X3_TX / 2;
         const int o = isx ? (x0 >> 1) + tid : (y0 >> 1) + (tid - X3_TX / 2), in = isx ? a.W : a.H;
         const LinIdx l = lin_index(min(o, (in >> 1) - 1), in, in >> 1, isx ? e.dsw : e.dsh, 1);
-        const float4 ent = make_float4(l.w0, l.w1, l.i0 != 2 * o ? 1.f : 0.f, l.i1 != 2 * o ? 1.f : 0.f);
+        // the pair (source 2o, source 2o+1) with weights (w0, w1); where the last output of an axis clamps (i0 = i1 = 2o+1, fp32
+        // source index a hair above in-1) the reference blends the odd source with itself: weights (0, 1)
+        const float4 ent = l.i0 == 2 * o ? make_float4(l.w0, l.w1, 0.f, 0.f) : make_float4(0.f, 1.f, 0.f, 0.f);
         if (isx) ldxt[tid] = ent; else ldyt[tid - X3_TX / 2] = ent;
       }
     }
@@ -391,11 +387,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           for (int r = 0; r < 4; ++r) st(py + r * DHW, v[r]);      // whole 4-channel output groups only (x3_eligible)
         }
         if constexpr (TAILS) {
-          unsigned m01, m23, l01, l23;
-          const unsigned h01 = x3_split3(v[0], v[1], m01, l01), h23 = x3_split3(v[2], v[3], m23, l23);
-          f32x4 tacc = x3_mma<true>(ltail[lane], make_uint4(h01, h23, m01, m23), f32x4{0.f, 0.f, 0.f, 0.f});
-          tacc = x3_mma<true>(ltail[64 + lane], make_uint4(l01, l23, h01, h23), tacc);
-          tacc = x3_mma<true>(ltail[128 + lane], make_uint4(m01, m23, h01, h23), tacc);
+          f32x4 tacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(ltail)[r * 64 + lane], v[r], tacc, 0, 0, 0);
           // destination of this lane quarter's tail: a select between the two (wave-uniform) descriptors, not an indexed load
           const int my_tail_cout = kb < a.ntail ? (tsel ? a.tail_cout[1] : a.tail_cout[0]) : 0;
           if (my_tail_cout > 0 && inside) {
@@ -418,14 +413,16 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
             const int dl = kb - a.ntail;
             if (dl >= 0 && dl < a.ndown) {
               const float4 xt = ldxt[8 * (nt & 1) + (n >> 1)];
-              float* const du = ldu + (((z & 1) * 2 + dl) * 4) * (X3_TY * (X3_TX / 2)) + (nt >> 1) * (X3_TX / 2) + 8 * (nt & 1) + (n >> 1);
+              float ux[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float p0 = tacc[r];
-                const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p0), 0x101, 0xF, 0xF, false));   // row_shl:1: the next lane's
-                const float ux = lerp2(xt.x, xt.z != 0.f ? p1 : p0, xt.y, xt.w != 0.f ? p1 : p0);
-                if (!(n & 1)) du[r * (X3_TY * (X3_TX / 2))] = ux;
+                // w0 * (this lane's value) + w1 * (the next lane's): the row shift rides on the multiply's operand (v_mul_f32_dpp)
+                const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tacc[r]), 0x101, 0xF, 0xF, false));   // row_shl:1
+                ux[r] = lerp2(xt.x, tacc[r], xt.y, p1);
               }
+              if (!(n & 1))
+                reinterpret_cast<float4*>(ldu)[(((z & 1) * 2 + dl) * X3_TY + (nt >> 1)) * (X3_TX / 2) + 8 * (nt & 1) + (n >> 1)] =
+                    make_float4(ux[0], ux[1], ux[2], ux[3]);
             }
           }
         }
