@@ -35,12 +35,13 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
-  constexpr int RS = x3_row_stride(NCG), PLS = X3_HY * RS;       // LDS row stride / plane size in records (staging still enumerates X3_PL voxels)
+  // LDS row / plane / channel-group strides in records (padded against bank conflicts: conv3d_x3_common.h; staging still enumerates X3_PL voxels)
+  constexpr int RS = x3_row_stride(NCG, NSET), PLS = x3_plane_stride(NCG, NSET), CGS = x3_group_stride(NCG, NSET);
   static_assert(NCG % NSET == 0 && NPF <= 32, "bad instantiation");
   extern __shared__ __attribute__((aligned(16))) uint2 x3_lds[];       // hi[NCG][3][PL] | lo[NCG][3][PL] (uint2 = 4 bf16) | weights | offsets | params
   uint2* const lhi = x3_lds;
-  uint2* const llo = x3_lds + NCG * 3 * PLS;                                            // absent for bf16 storage
-  uint4* const lw = reinterpret_cast<uint4*>(x3_lds + (BF ? 1 : 2) * NCG * 3 * PLS);    // [set][slice][hi/lo][64 lanes]
+  uint2* const llo = x3_lds + NCG * CGS;                                            // absent for bf16 storage
+  uint4* const lw = reinterpret_cast<uint4*>(x3_lds + (BF ? 1 : 2) * NCG * CGS);    // [set][slice][hi/lo][64 lanes]
   // operand byte offsets, ready to use: [ring phase 0..2][slice][lane quarter kb] -> (pair 2kb, pair 2kb+1) of that slice with the ring
   // rotation already applied, so the K loop spends no VALU work on addresses (one 8-byte table read per slice instead of two
   // plus ~8 instructions of mod-3 arithmetic)
@@ -61,19 +62,29 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
   asm volatile("" : "+v"(act_floor));      // opaque: otherwise the compiler turns max(u, floor) back into max(u, 0) + a select per value
   const int64_t DHW = (int64_t)HW * a.D;
-  for (int i = tid; i < NSL * 2 * 64; i += X3_THREADS) {
-    const int set = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
-    lw[i] = e.wf[set][(int64_t)cog * NSLS * 2 * 64 + r];
+  // weight fragments, 8 bytes (one pair's four channels) at a time: lane quarter q of slice s holds the pairs x3_pair_perm(.., 2q + j)
+  // of the packed slice (packed: quarter p >> 1, half p & 1)
+  for (int i = tid; i < NSL * 2 * 64 * 2; i += X3_THREADS) {
+    const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, set = sh / (NSLS * 2), s = (sh >> 1) % NSLS;
+    const int p = x3_pair_perm(NCGS, s, 2 * (ln >> 4) + j);
+    const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set] + (int64_t)cog * NSLS * 2 * 64);
+    reinterpret_cast<uint2*>(lw)[i] = src[(((sh % (NSLS * 2)) * 64) + (p >> 1) * 16 + (ln & 15)) * 2 + (p & 1)];
   }
   for (int i = tid; i < 3 * NSL * 4; i += X3_THREADS) {
     const int ring = i / (NSL * 4), q = i % (NSL * 4), set = q / (NSLS * 4);
+    const int sl = (q % (NSLS * 4)) >> 2, qt = q & 3;
+    auto pair_offset = [&](int quarter, int j) {
+      const int P = 8 * sl + x3_pair_perm(NCGS, sl, 2 * quarter + j), cgl = P % NCGS, tap = P / NCGS;      // tap-major pairs (x3_pack_one)
+      const int slot = (ring + tap / 9) % 3;          // plane z+dz-1 sits in slot (ring + dz) % 3
+      return tap < 27 ? ((set * NCGS + cgl) * CGS + slot * PLS + ((tap / 3) % 3) * RS + tap % 3) * (int)sizeof(uint2) : -1;
+    };
     int o[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int P = (q % (NSLS * 4)) * 2 + j, cgl = P % NCGS, tap = P / NCGS;      // tap-major pairs (x3_pack_one)
-      const int slot = (ring + tap / 9) % 3;          // plane z+dz-1 sits in slot (ring + dz) % 3
-      // (padding pairs — zero weights — read offset 0: a voxel of one of the three planes in the ring, inside the 3x3x3 window)
-      o[j] = tap < 27 ? (((set * NCGS + cgl) * 3 + slot) * PLS + ((tap / 3) % 3) * RS + tap % 3) * (int)sizeof(uint2) : 0;
+      // (padding pairs — zero weights — read what the quarter they share the pass with reads: a voxel inside the 3x3x3 window, and
+      // no bank conflict; offset 0 — also inside the window — when that one is padding too)
+      o[j] = pair_offset(qt, j);
+      if (o[j] < 0) o[j] = max(pair_offset(qt ^ 1, j), 0);
     }
     loff[i] = make_int2(o[0], o[1]);
   }
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       unsigned l01, l23, h01, h23;
       if constexpr (BF) { h01 = x3_split2(v[0], v[1], l01); h23 = x3_split2(v[2], v[3], l23); }
       else { h01 = x3_split2h(v[0], v[1], mul, l01); h23 = x3_split2h(v[2], v[3], mul, l23); }
-      const int d = (cg * 3 + slot) * PLS + (r / X3_HX) * RS + r % X3_HX;
+      const int d = cg * CGS + slot * PLS + (r / X3_HX) * RS + r % X3_HX;
       lhi[d] = make_uint2(h01, h23);
       if constexpr (!BF) llo[d] = make_uint2(l01, l23);
     }
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     asm volatile("" : "+v"(vbt[i]));
   }
   const char* const lbytes = reinterpret_cast<const char*>(x3_lds);
-  constexpr int LO_BYTES = NCG * 3 * PLS * (int)sizeof(uint2);
+  constexpr int LO_BYTES = NCG * CGS * (int)sizeof(uint2);
   const int g = cog * 4 + kb, ngroups = (a.Cout + 3) >> 2;
   // per-lane destinations, read ONCE: indexing the kernel-argument arrays with a lane-dependent index inside the loop is a
   // vector memory load per use, and its s_waitcnt vmcnt drains the prefetch that is supposed to fly under the MFMAs
@@ -882,7 +893,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   RAGMI_REQUIRE(nwork < (1ll << 31) && per_sample < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3: too many tiles");
   e.nwork = (int)nwork;
   e.bf16 = dtype == RAGMI_BF16 ? 1 : 0;
-  const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * 3 * X3_HY * x3_row_stride(ncg) * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
+  const size_t lds = (size_t)(dtype == RAGMI_BF16 ? 1 : 2) * ncg * x3_group_stride(ncg, nset) * sizeof(uint2) + (size_t)nsl * 2 * 64 * sizeof(uint4) + (size_t)3 * nsl * 4 * sizeof(int2) +
                      3 * 64 * sizeof(uint4) + 132 * sizeof(float) +
                      (a.ndown > 0 ? (size_t)(2 * 2 * 4 * X3_TY * (X3_TX / 2)) * sizeof(float) + (size_t)(X3_TX / 2 + X3_TY / 2) * sizeof(float4) : 0);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");

@@ -15,12 +15,33 @@ typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
 constexpr int X3_TY = 8, X3_TX = 32;
 constexpr int64_t X3_MIN_VOXELS = 1 << 18;      // below this the z-marching columns do not fill the chip
 constexpr int X3_HY = X3_TY + 2, X3_HX = X3_TX + 2, X3_PL = X3_HY * X3_HX;   // one halo plane: 340 voxels
-// LDS row stride of a halo plane, in 8-byte records.  The two lane quarters of a 32-lane half read operand pairs two taps apart:
-// in the same halo row their addresses overlap (broadcast), but two of three such pairs wrap to the next row, a distance of
-// RS - 1 records — with RS = 34 that is 8 bytes mod 256: the same banks, different addresses, a 2-way conflict on every such read
-// (22 % of the LDS-active cycles of the dual launch, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  (RS - 1) * 8 = 128 mod 256
-// puts the two quarters on opposite bank halves: RS = 49.  Affordable where it leaves two workgroups per CU (<= 2 channel groups).
-constexpr int x3_row_stride(int ncg) { return ncg <= 2 ? 49 : X3_HX; }
+// LDS geometry of the halo ring, in 8-byte records: [channel group][ring slot][y][x].  A ds_read_b64 is served 32 lanes at a time,
+// i.e. TWO lane quarters (16 lanes = 128 contiguous bytes each) share the 64 banks: they pass in one go only if their addresses are
+// 128 bytes apart mod 256, or overlap with IDENTICAL addresses (two taps of one halo row).  Which two operand pairs meet in a pass
+// is a free choice per K-slice — the pairs of a slice can sit in any lane quarter as long as the weight fragments sit there too — so
+// the strides below are padded and the pairs permuted (x3_pair_perm) for the fewest conflicted passes over the three ring phases
+// (search: tools/x3_bank_search.py):
+//  * one channel group per set (the level-3 dual cells): pairs as packed — quarters two taps apart; rows of 49 records put the row
+//    wraps 128 bytes apart, 9 records behind every plane do the same for the plane wraps: 3 of 48 passes conflicted (round 3: 9);
+//  * more groups: rows of 34, 20 records (160 B) behind every group (group stride = 128 mod 256) and quarters (0,1) / (2,3) reading
+//    the SAME tap of neighbouring groups wherever the slice allows: stem3d1 (3 groups) 6 of 132 passes conflicted — as packed it was
+//    120 of 132, every operand read of that launch at half rate; even group counts 0.
+constexpr int x3_row_stride(int ncg, int nset) { return ncg == nset ? 49 : X3_HX; }
+constexpr int x3_plane_stride(int ncg, int nset) { return X3_HY * x3_row_stride(ncg, nset) + (ncg == nset ? 9 : 0); }
+constexpr int x3_group_stride(int ncg, int nset) { return 3 * x3_plane_stride(ncg, nset) + (ncg == nset ? 0 : 20); }
+// pair (0..7, position in the packed K-slice `s` of a set with `ncgs` channel groups) that lane quarter i >> 1 holds as its operand i & 1
+__host__ __device__ inline int x3_pair_perm(int ncgs, int s, int i) {
+  static constexpr unsigned char even[8] = {0, 2, 1, 3, 4, 6, 5, 7};
+  static constexpr unsigned char three[11][8] = {{0,2,1,5,3,6,4,7}, {0,1,2,7,3,4,6,5}, {0,2,1,3,4,5,7,6}, {0,2,1,3,4,6,5,7}, {0,1,3,2,4,5,7,6}, {0,2,1,3,4,6,5,7},
+                                                 {0,2,1,5,3,6,4,7}, {0,1,6,4,2,5,3,7}, {0,2,1,3,4,5,7,6}, {0,2,1,5,3,6,4,7}, {0,2,1,3,4,6,5,7}};
+  static constexpr unsigned char five[17][8] = {{0,2,1,7,3,5,4,6}, {0,2,1,3,4,6,5,7}, {0,2,1,3,4,6,5,7}, {0,1,5,2,3,6,4,7}, {0,2,1,7,3,5,4,6}, {0,2,1,3,4,6,5,7},
+                                                {0,2,1,7,3,5,4,6}, {0,2,1,3,4,6,5,7}, {0,1,5,2,3,6,4,7}, {0,2,1,3,4,6,5,7}, {0,2,1,7,3,5,4,6}, {0,2,1,7,3,5,4,6},
+                                                {0,2,1,3,4,6,5,7}, {0,2,1,3,4,6,5,7}, {0,2,1,7,3,5,4,6}, {0,2,1,7,3,5,4,6}, {0,2,1,3,4,6,5,7}};
+  if (ncgs == 1) return i;
+  if (ncgs == 3) return three[s][i];
+  if (ncgs == 5) return five[s][i];
+  return even[i];
+}
 constexpr int X3_THREADS = 512, X3_WAVES = X3_THREADS / 64;
 // 8 waves per workgroup, two column tiles each: at <= 128 VGPRs two workgroups (4 waves per SIMD) share a CU, which hides the
 // LDS-read latency in front of every MFMA group far better than 4 waves x 4 tiles at 248 VGPRs did (557 -> 601 maps/s)
