@@ -62,6 +62,11 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
   asm volatile("" : "+v"(act_floor));      // opaque: otherwise the compiler turns max(u, floor) back into max(u, 0) + a select per value
   const int64_t DHW = (int64_t)HW * a.D;
+#ifdef RAGMI_DIAG
+  const bool dg_nostore = (a.relu & 0x100) != 0, dg_nomfma = (a.relu & 0x200) != 0, dg_nocommit = (a.relu & 0x400) != 0, dg_noload = (a.relu & 0x800) != 0, dg_noread = (a.relu & 0x1000) != 0;
+#else
+  constexpr bool dg_nostore = false, dg_nomfma = false, dg_nocommit = false, dg_noload = false, dg_noread = false;
+#endif
   // weight fragments, 8 bytes (one pair's four channels) at a time: lane quarter q of slice s holds the pairs x3_pair_perm(.., 2q + j)
   // of the packed slice (packed: quarter p >> 1, half p & 1)
   for (int i = tid; i < NSL * 2 * 64 * 2; i += X3_THREADS) {
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   };
   // issue the loads of input plane gz of the located column: unconditional, the plane index clamped into the volume
   auto prefetch = [&](const T* xb, int gz) {
+    if (dg_noload) return;
     valid = (unsigned)gz < (unsigned)a.D ? vmask : 0u;
     const T* const pb = xb + (int64_t)min(max(gz, 0), a.D - 1) * HW;
 #pragma unroll
@@ -172,6 +178,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   };
   float mul = 1.f;                       // fp32 storage: the column's operand scale 2^-e (wave-uniform)
   auto commit = [&](int slot) {          // registers -> ring plane `slot` (16-bit hi / lo halves), zeros outside the volume / past Cin
+    if (dg_nocommit) return;
 #pragma unroll
     for (int p = 0; p < NPF; ++p) {
       const int el = p * X3_THREADS + tid;
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         for (int i = 0; i < X3_NT; ++i) acc[st][i] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int ring = (z - 1 + 3) % 3;                // slot of plane z-1; plane z+dz-1 (dz = 0..2) sits in slot (ring + dz) % 3
       const int2* const lo_r = loff + ring * (NSL * 4) + kb;      // this lane's offset pairs for the current ring phase
+      if (!dg_nomfma)
 #pragma unroll
       for (int s = 0; s < NSL; ++s) {
         const int st = s / NSLS;                        // compile time after unrolling
@@ -356,8 +364,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           // per-tile base registers whose relation the compiler cannot see (vbt): at a visible constant distance it fuses the
           // SAME pair of two tiles into one ds_read2_b64 — half rate, and its result lands as (tile 0, tile 1) where the MFMA
           // operand wants (pair 0, pair 1) of ONE tile: 96 of the 258 VALU instructions of a plane were the v_movs that undo it
-          const char* const a0 = lbytes + vbt[i] + po.x;
-          const char* const a1 = lbytes + vbt[i] + po.y;
+          const char* const a0 = lbytes + (dg_noread ? 0 : vbt[i] + po.x);
+          const char* const a1 = lbytes + (dg_noread ? 0 : vbt[i] + po.y);
           const uint2 h0 = *reinterpret_cast<const uint2*>(a0), h1 = *reinterpret_cast<const uint2*>(a1);
           bh[i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
           if constexpr (!BF) {
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           }
           v[r] = sum;
         }
-        if (a.store_main && inside && g < ngroups) {
+        if (a.store_main && inside && g < ngroups && !(dg_nostore && v[0] != 12345.f)) {
           T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)my_ych * DHW + vox;
 #pragma unroll
           for (int r = 0; r < 4; ++r) st(py + r * DHW, v[r]);      // whole 4-channel output groups only (x3_eligible)
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
             tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(ltail)[r * 64 + lane], v[r], tacc, 0, 0, 0);
           // destination of this lane quarter's tail: a select between the two (wave-uniform) descriptors, not an indexed load
           const int my_tail_cout = kb < a.ntail ? (tsel ? a.tail_cout[1] : a.tail_cout[0]) : 0;
-          if (my_tail_cout > 0 && inside) {
+          if (my_tail_cout > 0 && inside && !(dg_nostore && tacc[0] != 12345.f)) {
             T* const my_tail = static_cast<T*>(tsel ? a.tail_y[1] : a.tail_y[0]);
             const int64_t tb = tsel ? a.tail_bstride[1] : a.tail_bstride[0];
             const int tch0 = tsel ? a.tail_ch0[1] : a.tail_ch0[0], trelu = tsel ? a.tail_relu[1] : a.tail_relu[0];
@@ -856,6 +864,10 @@ static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t ld
 
 // a: as filled for the fp32 kernel (wp[s] = packed weights: fp32-MFMA section followed by the bf16x3 fragments)
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
+#ifdef RAGMI_DIAG
+  static const int diag_x3 = [] { const char* v = getenv("RAGMI_X3_DIAG"); return v ? atoi(v) : 0; }();   // 1 no stores, 2 no MFMA block, 4 no commit, 8 no loads, 16 operand reads at one address
+  a.relu |= diag_x3 << 8;
+#endif
   X3Extra e{};
   x3_weight_sections(e, a, nset, dtype);
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0), ncgs = ncg / nset, nsls = (ncgs * 27 + 7) / 8, nsl = nset * nsls;
