@@ -704,10 +704,20 @@ def main():
                                     "floor (input once + output once at 8 TB/s) is above its MFMA floor (3 16x16x32 MFMAs per product at "
                                     "the 2.5 PFLOP/s dense peak), so HBM is the roof it is priced against; `mfma` = ALGORITHMIC fp32 "
                                     f"flops / time against the bf16 dense peak ({ach / PEAK_FP32_MFMA_TFLOPS:.2f} of the fp32 matrix peak 157.3). "
-                                    "Measured limits on this chip (DESIGN.md 4.3, NOTES.md 4.6): one 16x16x32 MFMA per 8.2 ns per SIMD puts the issue "
-                                    "floor of the dual level-3 launch at 51 us; PMC counters put its LDS-active cycles at ~55 % of the launch "
-                                    "and the matrix pipe at about a third: no unit is saturated; instruction issue is (per plane and wave 48 MFMAs x 16 "
-                                    "cycles + 157 VALU x 4 + 92 LDS reads + scalar work = ~1900 issue cycles, four waves per SIMD)")
+                                    "What actually bounds it is neither roof but the SIMDs' issue port (DESIGN.md 4.3): vector and matrix instructions of "
+                                    "the four waves of a SIMD issue one after the other; see `issue_model`.")
+                if groups[0] == 2 and nset == 2 and args.dtype != "bf16" and args.batch == 1 and args.hw is None:
+                    # per wave and plane step of the shipped dual-cell loop (tools/isa_mix.py "conv3d_x3_kernel<float, 2, 2, 1>" --loop):
+                    # vector instructions, split-product MFMAs (16x16x32, ~20 cycles of a 2.4 GHz clock sustained: tools/probe_mfma_bf16.hip),
+                    # fp32 tail MFMAs (16x16x4, ~40 cycles); 4 waves per SIMD; plane steps per workgroup = depth segment + 3 ring planes
+                    vec, mf16, mf32 = 183, 48, 8
+                    cyc = 4 * (vec * 4 + mf16 * 20 + mf32 * 40)
+                    steps_per_wg = 32 + 3
+                    t_issue = cyc * steps_per_wg / 2.4e9
+                    roofline["issue_model"] = {"vector_per_wave_step": vec, "mfma_16x16x32_per_wave_step": mf16, "mfma_16x16x4_f32_per_wave_step": mf32,
+                                               "cycles_per_plane_step_per_simd": cyc, "plane_steps_per_workgroup": steps_per_wg,
+                                               "floor_us": round(t_issue * 1e6, 1), "frac": round(t_issue / (secs / nlaunch), 3),
+                                               "what": "issue cycles of one SIMD for one launch at the headline shape (one work item per resident workgroup) / measured launch time"}
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
                 log(f"  conv3d {'x3 (split operands) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
