@@ -170,6 +170,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  if (x2d_eligible(a, 1, dtype)) return x2d_launch(a, 1, dtype, s);
   if (x3d_eligible(a, 1, dtype)) return x3d_launch(a, 1, dtype, s);
   if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, dtype, s);
   RAGMI_REQUIRE(a.ndown == 0, RAGMI_EUNSUPPORTED, "conv3d_k3: down-sampling tails need the z-marching split-operand form (ragmi_conv3d_k3_uses_x3)");
@@ -249,6 +250,7 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  if (x2d_eligible(a, 2, dtype)) return x2d_launch(a, 2, dtype, s);
   if (x3d_eligible(a, 2, dtype)) return x3d_launch(a, 2, dtype, s);
   if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, dtype, s);
   RAGMI_REQUIRE(a.ndown == 0, RAGMI_EUNSUPPORTED, "conv3d_k3_dual: down-sampling tails need the z-marching split-operand form (ragmi_conv3d_k3_uses_x3)");

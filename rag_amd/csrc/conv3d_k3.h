@@ -612,6 +612,9 @@ int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin
 bool x3_eligible(const K3Args& a, int nset, int dtype);
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
 // deep-level bf16x3 form (8 / 16 input channels per set, box tiles): levels 6 and 12
+// depth-1 volumes (the Feature Net's 2-D convolutions) on the split-operand form: conv2d_x3.hip
+bool x2d_eligible(const K3Args& a, int nset, int dtype);
+int x2d_launch(K3Args a, int nset, int dtype, hipStream_t st);
 bool x3d_eligible(const K3Args& a, int nset, int dtype);
 int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st);
 int launch_k3_valu_f32(const K3Args& a, int cfg, hipStream_t s);          // Cout <= 2, raw weights

@@ -996,6 +996,48 @@ def test_x3_conv_vs_oracle(ra, x3_on, cin, cout, shape):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("nset,cs,cout,shape", [
+    (1, 12, 12, (2, 128, 416)),       # Feature Net stem1 at the headline shape (both images as one batch)
+    (2, 8, 24, (2, 64, 208)),         # Cell_2d dual launch at half resolution: two output blocks
+    (2, 4, 12, (2, 128, 416)),        # Cell_2d dual launch at full resolution
+    (1, 16, 8, (1, 37, 50)),          # four channel groups, partial tiles
+    (1, 4, 20, (3, 19, 33)),          # one group, a partial second output block, ragged
+    (1, 8, 4, (1, 2, 16))])           # the smallest eligible plane
+def test_x2d_depth1_split_operand_conv(ra, x3_on, nset, cs, cout, shape):
+    """conv2d_x3_kernel (round 4): depth-1 volumes under f16x3 — the Feature Net's ConvBR_2d / Cell_2d launches — through the 3x3x3
+    entry points with FULL 3x3x3 weights (the taps dz != 1 meet only zero padding, whatever their weights), against F.conv3d in
+    float64; destination-channel permutation per group of four."""
+    B, H, W = shape
+    cin = nset * cs
+    x = torch.randn((B, cin, 1, H, W), generator=gen(201)) * 3.0
+    ws = [torch.randn((cout, cs, 3, 3, 3), generator=gen(202 + i)) * (2.0 / (9 * cs)) ** 0.5 for i in range(nset)]
+    sc = [torch.rand(cout, generator=gen(205 + i)) + 0.5 for i in range(nset)]
+    sh = [torch.randn(cout, generator=gen(208 + i)) * 0.1 for i in range(nset)]
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    ref = sum(F.relu(F.conv3d(x[:, i * cs:(i + 1) * cs].double(), ws[i].double(), padding=1) * v(sc[i].double()) + v(sh[i].double()))
+              for i in range(nset))
+    ng = cout // 4
+    perm = [4 * ((g * 7 + 1) % ng) for g in range(ng)]
+    out = torch.full((B, cout, 1, H, W), float("nan"), device=DEV)
+    pk = [ra.ops.conv3d_k3_pack(gpu(w)) for w in ws]
+    if nset == 2:
+        ra.ops.conv3d_k3_dual(gpu(x), cs, pk[0], gpu(sc[0]), gpu(sh[0]), pk[1], gpu(sc[1]), gpu(sh[1]), cout, True, out, perm)
+    else:
+        ra.ops.conv3d_k3(gpu(x), pk[0], cout, gpu(sc[0]), gpu(sh[0]), True, out, perm)
+    exp = torch.empty_like(ref)
+    for g in range(ng):
+        exp[:, perm[g]:perm[g] + 4] = ref[:, 4 * g:4 * g + 4]
+    np.testing.assert_allclose(out.cpu().double().numpy(), exp.numpy(), rtol=2e-4, atol=2e-4)
+    # and the same call under strict fp32 (the fp32 matrix-core kernel) agrees with it to the split form's error bound
+    with ra.ops.conv_precision("fp32"):
+        out32 = torch.empty_like(out)
+        if nset == 2:
+            ra.ops.conv3d_k3_dual(gpu(x), cs, pk[0], gpu(sc[0]), gpu(sh[0]), pk[1], gpu(sc[1]), gpu(sh[1]), cout, True, out32, perm)
+        else:
+            ra.ops.conv3d_k3(gpu(x), pk[0], cout, gpu(sc[0]), gpu(sh[0]), True, out32, perm)
+    assert float((out - out32).abs().max()) <= 2e-5 * float(exp.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("nset,cs,cout,shape,dtype", [
     (2, 16, 48, (1, 16, 32, 104), "f32"),      # a level-12 cell launch of the headline forward
     (2, 8, 24, (2, 8, 40, 56), "f32"),         # level-6 shape class: two output blocks over blockIdx.y, two batches
