@@ -338,11 +338,13 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
                            int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
 
 /* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) called with this
- * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the 16-bit matrix cores (fp16 / bf16 operands), 0 when it runs on the fp32-MFMA kernel.  Two forms
- * (conv3d_x3.hip), both without a residual input and with whole 4-channel groups in and out (Cin % 4 == 0, Cout % 4 == 0): the z-marching form for
+ * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the 16-bit matrix cores (fp16 / bf16 operands), 0 when it runs on the fp32-MFMA kernel.  Three forms
+ * (conv3d_x3.hip, conv2d_x3.hip), all without a residual input and with whole 4-channel groups in and out (Cin % 4 == 0, Cout % 4 == 0): the z-marching form for
  * D*H*W >= 2^18 voxels PER SAMPLE, W >= 32, D >= 8, <= 24 input channels; the deep-level form for 8 or 16 input channels per
- * set, no fused tails, D >= 2 and D*H*W >= 2^14 voxels per sample.  B never enters: the kernel (hence the rounding) a sample gets
- * does not depend on how a batch is split over ranks.  Always 0 for RAGMI_F32. */
+ * set, no fused tails, D >= 2 and D*H*W >= 2^14 voxels per sample; the depth-1 form (RAGMI_F32X3 only: the Feature Net's 2-D
+ * convolutions, rag_model.py:285-323) for D == 1, W >= 16, H >= 2, no fused tails and 4..16 input channels (4 or 8 per set of a
+ * dual launch) — there the taps dz != 1 meet only zero padding and only the middle slice of the packed fragments is issued.
+ * B never enters: the kernel (hence the rounding) a sample gets does not depend on how a batch is split over ranks.  Always 0 for RAGMI_F32. */
 int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, int W, int nset, int has_res, int ntail, int dtype);
 
 /* ragmi_conv3d_k3_pack with two options used by the training step: transpose != 0 packs the DATA-GRADIENT conv of a forward

@@ -274,7 +274,7 @@ extern "C" int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, i
   if (nset == 2) { if (Cin % (2 * CK)) return 0; a.nchunks[0] = a.nchunks[1] = Cin / (2 * CK); }
   else a.nchunks[0] = (Cin + CK - 1) / CK;
   a.store_main = 1;
-  return (x3d_eligible(a, nset, dtype) || x3_eligible(a, nset, dtype)) ? 1 : 0;
+  return (x2d_eligible(a, nset, dtype) || x3d_eligible(a, nset, dtype) || x3_eligible(a, nset, dtype)) ? 1 : 0;
 }
 
 extern "C" int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int nset, int32_t* log_tx,
