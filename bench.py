@@ -191,6 +191,20 @@ def try_capture(fn, census_out=None):
         return None, None
 
 
+# Untimed replays of a freshly captured hipGraph in front of every timed region.  tools/replay_ramp.py (round 4): after the idle time of
+# a capture (or any synchronize) the first replays of the headline graph take 1.19-1.22 ms and converge to the steady 1.04 ms only
+# after ~25 of them (clock / power management ramp; the same with 0, 5 or 50 ms of idle time in front) — a constant ~1.1 ms per timed
+# region, 5 % of a 20-step region and none of a production stream's.  They are warm-up in the contract's sense: untimed, and reported
+# in the line (`warmup_detail`).
+RAMP_REPLAYS = 30
+
+
+def ramp(graph, n=RAMP_REPLAYS):
+    if graph is not None:
+        for _ in range(n):
+            graph.replay()
+
+
 def measure(step, steps, use_graph=True, warm=2):
     """(seconds per step, output of the measured launches, 'hipGraph' | 'eager'): `warm` eager passes, capture, `steps` replays
     bracketed by device syncs.  Used by the legs that ride along after the headline's timed region."""
@@ -202,6 +216,8 @@ def measure(step, steps, use_graph=True, warm=2):
         graph, cap = try_capture(step)
         if graph is not None:
             out = cap
+    ramp(graph)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         if graph is not None:
@@ -269,6 +285,8 @@ def end_to_end(device, steps, seed=0, use_graph=True):
         if use_graph:
             graph, _ = try_capture(lambda: net(left, right, 0, net.arch_init))
             use_graph = graph is not None
+        ramp(graph)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             if graph is not None:
@@ -651,7 +669,8 @@ def main():
             holder["out"] = step()
 
     prof.enabled = graph is None and rank == 0
-    dt = timed_region(timed_step, args.steps, 0, dist, torch.cuda.synchronize, device)   # warm-up was done above
+    # (the W warm-up steps ran above, eagerly: one-time costs; the replays below are the clock ramp, RAMP_REPLAYS above)
+    dt = timed_region(timed_step, args.steps, RAMP_REPLAYS if graph is not None else 0, dist, torch.cuda.synchronize, device)
     prof.enabled = False
     out = holder.get("out", out)
 
@@ -737,6 +756,8 @@ def main():
                 torch.cuda.synchronize()
                 g32, cap32 = try_capture(step) if args.graph else (None, None)
                 n32 = min(args.steps, 10)
+                ramp(g32)
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(n32):
                     if g32 is not None:
@@ -790,6 +811,9 @@ def main():
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
                        "global_batch": n_gpus * B, "sharding": "batch split, no collective",
                        "launch": "hipGraph" if graph is not None else "eager",
+                       "warmup_detail": (f"{max(args.warmup, 1)} eager steps (one-time costs), capture + 1 replay, then {RAMP_REPLAYS} replays (clock ramp: "
+                                         "tools/replay_ramp.py) — all untimed, in front of the barrier + synchronize that opens the timed region"
+                                         if graph is not None else f"{max(args.warmup, 1)} eager steps"),
                        "ranks_seen": dist.get_world_size() if dist is not None else 1,
                        "dist_backend": dist.get_backend() if dist is not None else None},
             "roofline": roofline, "cpu_baseline": cpu, "strict_fp32": strict, "epe_bf16_vs_fp32": epe_bf16_vs_fp32, "end_to_end": e2e,
