@@ -255,6 +255,34 @@ int ragmi_conv3d_k1_resample_pair_fwd(const ragmi_k1r_t* a, const ragmi_k1r_t* b
                                       int B, int Do, int Ho, int Wo, int align_corners, int dtype, void* stream);
 
 /*
+ * One launch per Cell_2d of the Feature Net (src/models/rag_model.py:143-177 with the 2-D operations of
+ * src/automl/operations_2d.py; the cells built by rag_model.py:236-247), for cells in which every new state is the sum of one
+ * 3x3 ConvBR_2d of s0 and one of s1 (the all-conv genotype):
+ *     s0 = pre_preprocess(F.interpolate(prev_prev, (H, W), mode='bilinear', align_corners=True))      (1x1 ConvBR_2d)
+ *     s1 = preprocess(F.interpolate(prev, (H, W), ...))                                                (1x1 ConvBR_2d)
+ *     y[:, group g] = relu(bnA(convA(s0))) + relu(bnB(convB(s1)))          (the stacked sibling convs, as ragmi_conv3d_k3_dual_fwd)
+ * s0 / s1 and the interpolated tensors are never written: the two 1x1 convs (resample first, then an fmaf chain over the input
+ * channels in order, folded BatchNorm, ReLU — the arithmetic of ragmi_conv3d_k1_resample_fwd) run in the staging of the 3x3 launch.
+ * An input already at (H, W) is read as is.  packedA / packedB: ragmi_conv3d_k3_pack(_ex) of the [Cout, C, 3, 3] weights
+ * (planar2d) or of any [Cout, C, 3, 3, 3] weight (depth 1: only the middle slice acts).  dtype: RAGMI_F32X3 only (fp32 storage,
+ * split products — the contract of ragmi_conv3d_k3_fwd on depth-1 volumes); C = 4 or 8 channels per set, Cin <= 48 per input,
+ * W >= 16: ragmi_cell2d_supported answers 1 for what is built, and the host runs the separate launches otherwise.
+ */
+typedef struct {
+  const void* x; /* [B, Cin, Hi, Wi] */
+  int64_t x_bstride;
+  int32_t Cin, Hi, Wi;
+  const void* weight; /* [C][Cin] */
+  const void* scale;  /* folded BatchNorm [C], or NULL */
+  const void* shift;
+  int32_t relu;
+} ragmi_cell2d_in_t;
+int ragmi_cell2d_supported(int C, int Cin0, int Cin1, int Cout, int H, int W, int dtype);
+int ragmi_cell2d_fwd(const ragmi_cell2d_in_t* s0, const ragmi_cell2d_in_t* s1, int C, const void* packedA, const void* scaleA,
+                     const void* shiftA, const void* packedB, const void* scaleB, const void* shiftB, int relu, void* y,
+                     int64_t y_bstride, const int32_t* y_group_ch, int B, int Cout, int H, int W, int dtype, void* stream);
+
+/*
  * Trilinear resample, F.interpolate(mode='trilinear') with ATen's source-index
  * rule for align_corners = 1 (rag_model.py:150-153, 357-358) or 0.
  * x: [B, C, Di, Hi, Wi] -> y: [B, C, Do, Ho, Wo] (contiguous).

@@ -28,6 +28,15 @@ class K1RSpec(ctypes.Structure):
 
 c_k1r_p = ctypes.POINTER(K1RSpec)
 
+
+class Cell2dIn(ctypes.Structure):
+    """ragmi_cell2d_in_t of include/rag_amd.h: one input of a fused Cell_2d launch (tensor + its 1x1 ConvBR_2d)."""
+    _fields_ = [("x", c_void_p), ("x_bstride", c_int64), ("Cin", ctypes.c_int32), ("Hi", ctypes.c_int32), ("Wi", ctypes.c_int32),
+                ("weight", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("relu", ctypes.c_int32)]
+
+
+c_cell2d_p = ctypes.POINTER(Cell2dIn)
+
 # name -> (restype, argtypes); mirrors include/rag_amd.h one-to-one
 SIGNATURES = {
     "ragmi_version": (c_int, []),
@@ -68,6 +77,9 @@ SIGNATURES = {
                                              c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k1_resample_pair_fwd": (c_int, [c_k1r_p, c_k1r_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_down2_tail_supported": (c_int, [c_int, c_int, c_int]),
+    "ragmi_cell2d_supported": (c_int, [c_int] * 7),
+    "ragmi_cell2d_fwd": (c_int, [c_cell2d_p, c_cell2d_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_int64, c_int32_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_upconv3d_c1_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "ragmi_upconv3d_c1_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_void_p]),

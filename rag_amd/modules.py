@@ -473,6 +473,23 @@ class _Cell(nn.Module):
         if not pre_has[0] and s0.shape[1] == C and tuple(s0.shape[2:]) != size:
             s0 = ops.trilinear3d(s0, size, True)     # no pre_preprocess to fuse into (never the case in Network)
         D, H, W = size
+        if (D == 1 and pre is None and not tails and store_main and s0.shape[1] != C and s1.dtype == torch.float32 and s0.dtype == torch.float32
+                and ops.get_conv_precision() == "f16x3" and self.block_multiplier == self._steps):
+            # A Cell_2d in which every new state is conv(s0) + conv(s1) (the all-conv genotype): ONE launch — the two 1x1 ConvBRs and
+            # their bilinear resamples run in the staging of the dual 3x3 launch (ragmi_cell2d_fwd); s0 / s1 are never written
+            contribs = self._contributions()
+            from_ = {j: [(k, op) for k, lst in contribs.items() for (src, op) in lst if src == j and isinstance(op, _ConvBR)] for j in (0, 1)}
+            if (len(from_[0]) == self._steps and [k for k, _ in from_[0]] == [k for k, _ in from_[1]]
+                    and all(len(contribs[k]) == 2 for k, _ in from_[0])
+                    and ops.cell2d_supported(C, s0.shape[1], s1.shape[1], C * self._steps, H, W)):
+                cat = torch.empty((s1.shape[0], self.block_multiplier * C, D, H, W), device=s1.device, dtype=s1.dtype)
+                pa, sa, ha = self._fused([op for _k, op in from_[0]])
+                pb, sb, hb = self._fused([op for _k, op in from_[1]])
+                first = 2 + self._steps - self.block_multiplier
+                groups = [(k - first) * C + 4 * g for k, _op in from_[0] for g in range(C // 4)]
+                ops.cell2d(s0, self.pre_preprocess.prepared() + (self.pre_preprocess.relu,), s1,
+                           self.preprocess.prepared() + (self.preprocess.relu,), C, pa, sa, ha, pb, sb, hb, C * self._steps, True, cat, groups)
+                return cat, False
         if pre is None:
             B, dev = s1.shape[0], s1.device
             pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=s1.dtype)

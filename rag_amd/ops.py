@@ -378,6 +378,41 @@ def conv3d_k1_resample_pair(specs, size: Sequence[int], out: torch.Tensor) -> to
     return out
 
 
+def cell2d_supported(C: int, cin0: int, cin1: int, cout: int, H: int, W: int, dtype=torch.float32) -> bool:
+    """True when ragmi_cell2d_fwd is built for this Cell_2d shape under the CURRENT conv precision (f16x3, fp32 storage)."""
+    if dtype != torch.float32:
+        return False
+    return bool(load_library().ragmi_cell2d_supported(int(C), int(cin0), int(cin1), int(cout), int(H), int(W), _conv_dt(_DT[dtype])))
+
+
+def cell2d(s0: torch.Tensor, pre0, s1: torch.Tensor, pre1, C: int, packed_a: torch.Tensor, scale_a, shift_a,
+           packed_b: torch.Tensor, scale_b, shift_b, cout: int, relu: bool, out: torch.Tensor,
+           out_group_ch: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """A whole Cell_2d (rag_model.py:143-177, every new state = conv(s0) + conv(s1)) as ONE launch: see ragmi_cell2d_fwd in
+    include/rag_amd.h.  s0 / s1: [B, Cin, 1, Hi, Wi] (depth-1 volumes) or [B, Cin, Hi, Wi]; pre0 / pre1 = (weight2d [C, Cin], scale,
+    shift, relu) of pre_preprocess / preprocess; out: [B, C*, 1, H, W] (or 4-D), group g of 4 output channels at out_group_ch[g]."""
+    from ._lib import Cell2dIn
+    _need_gpu(packed_a, packed_b, scale_a, shift_a, scale_b, shift_b)
+    dt = _act(s0, s1, out)
+    H, W = int(out.shape[-2]), int(out.shape[-1])
+    B = out.shape[0]
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    ins = []
+    for x, (w2d, sc, sh, rl) in ((s0, pre0), (s1, pre1)):
+        _need_gpu(w2d, sc, sh)
+        if x.shape[0] != B or w2d.shape != (C, x.shape[1]) or not w2d.is_contiguous():
+            raise ValueError("cell2d: input / 1x1 weight shapes do not match")
+        ins.append(Cell2dIn(x.data_ptr(), _planes(x), x.shape[1], x.shape[-2], x.shape[-1], w2d.data_ptr(), p(sc), p(sh), int(bool(rl))))
+    groups = list(out_group_ch) if out_group_ch is not None else [4 * g for g in range(cout // 4)]
+    if len(groups) != cout // 4 or cout % 4 or any(g < 0 or g + 4 > out.shape[1] for g in groups):
+        raise ValueError("cell2d: bad destination channel groups")
+    garr = (ctypes.c_int32 * len(groups))(*groups)
+    check(load_library().ragmi_cell2d_fwd(ctypes.byref(ins[0]), ctypes.byref(ins[1]), int(C), packed_a.data_ptr(), p(scale_a), p(shift_a),
+                                          packed_b.data_ptr(), p(scale_b), p(shift_b), int(bool(relu)), out.data_ptr(), _planes(out), garr,
+                                          B, int(cout), H, W, _conv_dt(dt), _stream()), "cell2d")
+    return out
+
+
 def conv2d_k3_strided(x: torch.Tensor, weight: torch.Tensor, scale, shift, relu: bool, stride: int) -> torch.Tensor:
     """2-D 3x3 / pad 1 / stride-s ConvBR of the Feature-Net stem: x[B,Cin,H,W] -> [B,Cout,Ho,Wo]."""
     _need_gpu(weight, scale, shift)

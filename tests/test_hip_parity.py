@@ -1038,6 +1038,47 @@ def test_x2d_depth1_split_operand_conv(ra, x3_on, nset, cs, cout, shape):
     assert float((out - out32).abs().max()) <= 2e-5 * float(exp.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("C,cin0,size0,cin1,size1,size,B", [
+    (8, 12, (128, 416), 12, (128, 416), (64, 208), 2),     # Feature Net cell 0: both inputs down-sampled x0.5
+    (4, 12, (128, 416), 24, (64, 208), (128, 416), 2),     # cell 1: s0 at the cell's size, s1 up-sampled x2
+    (8, 24, (64, 208), 12, (128, 416), (64, 208), 2),      # cell 2: s0 as is, s1 down-sampled
+    (4, 9, (21, 50), 17, (41, 99), (41, 99), 3),           # ragged: odd channel counts, odd sizes, partial tiles, up + identity
+    (8, 48, (10, 17), 5, (37, 33), (19, 17), 1)])          # 48 input channels; non-integer resample ratios
+def test_cell2d_fused_launch(ra, x3_on, C, cin0, size0, cin1, size1, size, B):
+    """ragmi_cell2d_fwd (round 4): a Cell_2d of the all-conv genotype as ONE launch — pre_preprocess / preprocess (1x1 ConvBR_2d on the
+    bilinear align_corners=True resample of each input, rag_model.py:146-155) computed in the staging of the dual 3x3 launch —
+    against the reference's order of operations evaluated by ATen in float64 (interpolation in fp32: its index rule is fp32)."""
+    g1 = gen(211)
+    steps = 3
+    cout = steps * C
+    xs = [torch.randn((B, cin0) + size0, generator=g1) * 2.0, torch.randn((B, cin1) + size1, generator=g1) * 2.0]
+    w1 = [torch.randn((C, cin0), generator=g1) * 0.4, torch.randn((C, cin1), generator=g1) * 0.4]
+    s1 = [torch.rand(C, generator=g1) + 0.5 for _ in range(2)]
+    h1 = [torch.randn(C, generator=g1) * 0.2 for _ in range(2)]
+    w3 = [torch.randn((cout, C, 3, 3), generator=g1) * (2.0 / (9 * C)) ** 0.5 for _ in range(2)]
+    s3 = [torch.rand(cout, generator=g1) + 0.5 for _ in range(2)]
+    h3 = [torch.randn(cout, generator=g1) * 0.1 for _ in range(2)]
+    v = lambda t: t.view(1, -1, 1, 1)  # noqa: E731
+    ref = 0
+    for i in range(2):
+        xi = xs[i] if tuple(xs[i].shape[2:]) == size else F.interpolate(xs[i], size, mode="bilinear", align_corners=True)
+        si = F.relu(torch.einsum("oc,bchw->bohw", w1[i].double(), xi.double()) * v(s1[i].double()) + v(h1[i].double()))
+        ref = ref + F.relu(F.conv2d(si, w3[i].double(), padding=1) * v(s3[i].double()) + v(h3[i].double()))
+    assert ra.ops.cell2d_supported(C, cin0, cin1, cout, *size)
+    ng = cout // 4
+    perm = [4 * ((g * 7 + 1) % ng) for g in range(ng)]
+    out = torch.full((B, cout) + size, float("nan"), device=DEV)
+    pk = [ra.ops.conv3d_k3_pack(gpu(w)) for w in w3]
+    ra.ops.cell2d(gpu(xs[0]), (gpu(w1[0]), gpu(s1[0]), gpu(h1[0]), True), gpu(xs[1]), (gpu(w1[1]), gpu(s1[1]), gpu(h1[1]), True), C,
+                  pk[0], gpu(s3[0]), gpu(h3[0]), pk[1], gpu(s3[1]), gpu(h3[1]), cout, True, out, perm)
+    exp = torch.empty_like(ref)
+    for g in range(ng):
+        exp[:, perm[g]:perm[g] + 4] = ref[:, 4 * g:4 * g + 4]
+    np.testing.assert_allclose(out.cpu().double().numpy(), exp.numpy(), rtol=3e-4, atol=3e-4)
+    with ra.ops.conv_precision("fp32"):
+        assert not ra.ops.cell2d_supported(C, cin0, cin1, cout, *size)       # strict fp32 keeps the separate launches
+
+
 @pytest.mark.parametrize("nset,cs,cout,shape,dtype", [
     (2, 16, 48, (1, 16, 32, 104), "f32"),      # a level-12 cell launch of the headline forward
     (2, 8, 24, (2, 8, 40, 56), "f32"),         # level-6 shape class: two output blocks over blockIdx.y, two batches
