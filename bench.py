@@ -138,7 +138,9 @@ def pmc_traffic_bytes(kernel_name: str):
     import re
     base = re.sub(r"[<(].*", "", kernel_name)
     targs = kernel_name[len(base):].strip("<>").replace(" ", "")
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+    # newest first: tags run r04a .. r04z, r04aa .. (a longer tag is a later one)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")),
+                       key=lambda q: (len(os.path.basename(q).split("_")[0]), os.path.basename(q)), reverse=True):
         try:
             with open(path) as f:
                 table = json.load(f)
