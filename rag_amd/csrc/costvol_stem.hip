@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
       int oa = 0, sa = 0;
       bool ha = false;
       if (tc == 2) { oa = a.off_afull[cls] + y * a.W + x; sa = a.H * a.W; ha = true; }
-      else if (tc > -3) { oa = a.off_aband[cls] + (tc + 2) * Cout * a.H * a.wband + y * a.wband + x; sa = a.H * a.wband; ha = true; }
+      else if (tc > -3) { oa = a.off_aband[cls] + (tc + 2) * Cout * a.H * a.wband + y * a.wband + x - (tc == 1 ? 1 : 0); sa = a.H * a.wband; ha = true; }
 #pragma unroll
       for (int co = 0; co < MC; ++co) {
         const float wa = co < Cout ? ws[oa + co * sa] : 0.f;
@@ -450,7 +450,9 @@ struct StemLayout {
   bool used[CS_NCLS];
 };
 static void stem_layout(int C, int Cout, int D, int H, int W, StemLayout& l) {
-  l.wband = std::min(W, D + 1);                 // band columns x = i + tc <= D
+  // band columns: class tc is read at x = i + tc only, i.e. x in [max(tc, 0), min(D - 1 + tc, W - 1)] — min(W, D) columns from
+  // x = max(tc, 0) on (round 4: D + 1 columns from 0 made every band plane a 64-column tile plus a one-column tile)
+  l.wband = std::min(W, D);
   l.u1_0 = std::max(W - D, -2);                 // right-border variant: u = W-1-i
   l.wb1 = W - l.u1_0;
   l.na = (int64_t)CS_NCLS * CS_NTC * C * 9 * Cout;
@@ -528,7 +530,7 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
     if (!l.used[c]) continue;
     pa.d[n++] = PlaneDesc{(c * CS_NTC + 4) * sa, (int)l.off_afull[c], W, 0, 0, c * CS_NTC + 4};                       // tc = 2
     for (int k = 0; k < 4; ++k)                                                                       // tc = -2..1
-      pa.d[n++] = PlaneDesc{(c * CS_NTC + k) * sa, (int)(l.off_aband[c] + (int64_t)k * Cout * H * l.wband), l.wband, 0, 0, c * CS_NTC + k};
+      pa.d[n++] = PlaneDesc{(c * CS_NTC + k) * sa, (int)(l.off_aband[c] + (int64_t)k * Cout * H * l.wband), l.wband, k == 3 ? 1 : 0, 0, c * CS_NTC + k};
     pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 0) * sb, (int)l.off_b0[c], W + 2, -2, 1, CS_NVA + c * 2 + 0};
     pa.d[n++] = PlaneDesc{(int)l.na + (c * 2 + 1) * sb, (int)l.off_b1[c], l.wb1, l.u1_0, 1, CS_NVA + c * 2 + 1};
   }
