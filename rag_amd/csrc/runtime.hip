@@ -24,7 +24,7 @@ int check_launch(const char* what) {
 
 }  // namespace ragmi
 
-extern "C" int ragmi_version(void) { return 200; }
+extern "C" int ragmi_version(void) { return 400; }   // round 4: + ragmi_cell2d_fwd, ragmi_upconv3d_c1_fwd, ragmi_down2_tail_supported, down-sampling tails
 
 #include <vector>
 extern "C" int ragmi_graph_node_census(void* graph, int32_t* n_kernel, int32_t* n_memcpy, int32_t* n_memset, int32_t* n_other) {
