@@ -253,6 +253,12 @@ typedef struct {
 } ragmi_k1r_t;
 int ragmi_conv3d_k1_resample_pair_fwd(const ragmi_k1r_t* a, const ragmi_k1r_t* b, void* y, int64_t y_bstride,
                                       int B, int Do, int Ho, int Wo, int align_corners, int dtype, void* stream);
+/* the same with up to three descriptors and ONE DESTINATION BUFFER PER DESCRIPTOR (ys[i], y_bstrides[i]; y_ch0 inside it), all at
+ * the output size (Do, Ho, Wo): a cell's pre_preprocess + preprocess together with the NEXT cell's pre_preprocess when that one
+ * resamples the same tensor to the same size (rag_model.py:146-155 of two consecutive cells: the level-6 tensor both level-12
+ * cells 6 and 7 read) — the tensor is gathered by both in one launch instead of once per launch. */
+int ragmi_conv3d_k1_resample_multi_fwd(const ragmi_k1r_t* const* specs, void* const* ys, const int64_t* y_bstrides, int n, int B,
+                                       int Do, int Ho, int Wo, int align_corners, int dtype, void* stream);
 
 /*
  * One launch per Cell_2d of the Feature Net (src/models/rag_model.py:143-177 with the 2-D operations of

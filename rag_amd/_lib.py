@@ -76,6 +76,8 @@ SIGNATURES = {
     "ragmi_conv3d_k1_resample_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                              c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k1_resample_pair_fwd": (c_int, [c_k1r_p, c_k1r_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ragmi_conv3d_k1_resample_multi_fwd": (c_int, [ctypes.POINTER(c_k1r_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int, c_int,
+                                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_down2_tail_supported": (c_int, [c_int, c_int, c_int]),
     "ragmi_cell2d_supported": (c_int, [c_int] * 7),
     "ragmi_cell2d_fwd": (c_int, [c_cell2d_p, c_cell2d_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

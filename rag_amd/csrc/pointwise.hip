@@ -98,11 +98,12 @@ struct K1RArgs {
   int align;
 };
 
-// up to two such convs that write into the same buffer at the same output size (a cell's pre_preprocess and
-// preprocess) run as ONE launch: blockIdx.z = conv * splits + output-channel slab
+// up to three such convs at the same output size (a cell's pre_preprocess and preprocess; round 4: also the NEXT cell's
+// pre_preprocess when it resamples the same tensor to the same size — the second gather of that tensor then hits the L2 the first
+// one filled) run as ONE launch: blockIdx.z = conv's first slab + output-channel slab
 struct K1RPair {
-  K1RArgs c[2];
-  int splits[2];
+  K1RArgs c[3];
+  int splits[3];
 };
 
 template <class T, int NCO>
@@ -111,13 +112,14 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
   // global memory they are NCO scalar loads per input channel, each behind its own branch and wait: on the small (level-12)
   // launches that scalar traffic, not the gathers, was the kernel
   extern __shared__ __attribute__((aligned(16))) float k1r_w[];
-  const int which = (int)blockIdx.z >= pr.splits[0] ? 1 : 0;
-  K1RArgs& r = pr.c[which];
-  K1Args& a = r.k;
+  const int which = (int)blockIdx.z >= pr.splits[0] + pr.splits[1] ? 2 : ((int)blockIdx.z >= pr.splits[0] ? 1 : 0);
+  // (read-only views of the kernel arguments: a modified copy indexed by `which` would live in scratch memory)
+  const K1RArgs& r = pr.c[which];
+  const K1Args& a = r.k;
   const int64_t ovol = (int64_t)r.Do * r.Ho * r.Wo;
-  a.co0 = ((int)blockIdx.z - (which ? pr.splits[0] : 0)) * NCO;
+  const int co0 = ((int)blockIdx.z - (which == 2 ? pr.splits[0] + pr.splits[1] : (which ? pr.splits[0] : 0))) * NCO;
   for (int i = threadIdx.x; i < a.Cin * NCO; i += 256) {
-    const int ci = i / NCO, co = a.co0 + i % NCO;
+    const int ci = i / NCO, co = co0 + i % NCO;
     k1r_w[i] = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
   }
   __syncthreads();
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
   T* yp = static_cast<T*>(a.y) + b * a.y_bstride + o;
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
-    const int co = a.co0 + j;
+    const int co = co0 + j;
     if (co >= a.Cout) break;
     float v = a.scale ? fmaf(acc[j], a.scale[co], a.shift[co]) : acc[j];
     st(yp + (int64_t)(a.y_ch0 + co) * ovol, a.relu ? fmaxf(v, 0.f) : v);
@@ -216,12 +218,15 @@ template <class T, int NCO>
 static void launch_k1r_nco(const K1RArgs* r, int n, int B, hipStream_t s) {
   const int64_t ovol = (int64_t)r[0].Do * r[0].Ho * r[0].Wo;
   K1RPair pr{};
-  pr.c[0] = r[0];
-  pr.c[1] = r[n - 1];
-  pr.splits[0] = (int)ceil_div(r[0].k.Cout, NCO);
-  pr.splits[1] = n == 2 ? (int)ceil_div(r[1].k.Cout, NCO) : 0;
-  dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)(pr.splits[0] + pr.splits[1]));
-  const size_t wlds = (size_t)std::max(r[0].k.Cin, r[n - 1].k.Cin) * NCO * sizeof(float);
+  int nz = 0, cin_max = 0;
+  for (int i = 0; i < 3; ++i) {
+    pr.c[i] = r[i < n ? i : n - 1];
+    pr.splits[i] = i < n ? (int)ceil_div(r[i].k.Cout, NCO) : 0;
+    nz += pr.splits[i];
+    cin_max = std::max(cin_max, pr.c[i].k.Cin);
+  }
+  dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)nz);
+  const size_t wlds = (size_t)cin_max * NCO * sizeof(float);
   hipLaunchKernelGGL((conv_k1_resample_kernel<T, NCO>), grid, dim3(256), wlds, s, pr);
 }
 
@@ -247,7 +252,8 @@ static int launch_k1r(const K1RArgs* r, int n, int B, hipStream_t s) {
   // launch has threads to spare or is HBM-bound (>= 128 MB of input: re-reading it costs more than the parallelism buys —
   // cell 4 at the headline shape: 25.6 us with 16 vs 30.2 with 12); otherwise the widest EVEN split that yields enough threads
   // (cell 6: 26.0 us with 8 vs 29.9 with 12, whose second slab carries 4 of 16 channels at the full gather cost)
-  const int cmax = n == 2 ? (r[0].k.Cout > r[1].k.Cout ? r[0].k.Cout : r[1].k.Cout) : r[0].k.Cout;
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) cmax = std::max(cmax, r[i].k.Cout);
   const int64_t threads = (int64_t)B * r[0].Do * r[0].Ho * r[0].Wo * n, want = 256 * 256 * 2;
   int64_t in_bytes = 0;
   for (int i = 0; i < n; ++i) in_bytes += (int64_t)B * r[i].k.Cin * r[i].Di * r[i].Hi * r[i].Wi * (int64_t)sizeof(T);
@@ -384,6 +390,23 @@ extern "C" int ragmi_conv3d_k1_resample_pair_fwd(const ragmi_k1r_t* a, const rag
   }
   return dtype == RAGMI_BF16 ? launch_k1r<bf16_t>(r, 2, B, static_cast<hipStream_t>(stream))
                              : launch_k1r<float>(r, 2, B, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ragmi_conv3d_k1_resample_multi_fwd(const ragmi_k1r_t* const* specs, void* const* ys, const int64_t* y_bstrides, int n, int B,
+                                                  int Do, int Ho, int Wo, int align_corners, int dtype, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(specs && ys && y_bstrides && n >= 1 && n <= 3, RAGMI_EINVAL, "conv3d_k1_resample_multi: 1..3 descriptors");
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1_resample_multi: dtype %d not built", dtype);
+  K1RArgs r[3]{};
+  for (int i = 0; i < n; ++i) {
+    RAGMI_REQUIRE(specs[i], RAGMI_EINVAL, "conv3d_k1_resample_multi: null descriptor");
+    const ragmi_k1r_t* d = specs[i];
+    const int rc = fill_k1r(r[i], d->x, d->x_bstride, d->Di, d->Hi, d->Wi, d->weight, d->scale, d->shift, d->relu, ys[i], y_bstrides[i],
+                            d->y_ch0, B, d->Cin, d->Cout, Do, Ho, Wo, align_corners);
+    if (rc != RAGMI_OK) return rc;
+  }
+  return dtype == RAGMI_BF16 ? launch_k1r<bf16_t>(r, n, B, static_cast<hipStream_t>(stream))
+                             : launch_k1r<float>(r, n, B, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ragmi_add_fwd(const void* a, int64_t a_bstride, int a_ch0, const void* b, int64_t b_bstride, int b_ch0,

@@ -829,7 +829,31 @@ class MatchingNet(nn.Module):
         out1 = stem1(T[-2], tails=flat(specs), store_main=need_main or not specs)
         T[-1] = out1 if (need_main or not specs) else None
         settle(-1, specs, True, out1)
+        def shared_pre(i):
+            """Cells i and i+1 both resample T[i-1] (the `prev` of one, the `prev_prev` of the other) to the SAME size: cell i's two
+            1x1x1 convs and cell i+1's pre_preprocess as ONE launch — T[i-1] is gathered by both in the same launch (the second gather
+            hits the L2 the first one filled) and cell i+1 keeps a plain 1x1x1 launch for its other input."""
+            j = i + 1
+            if j >= n or any(has.get(i, (False, False))) or has.get(j, [False, False])[0] or sizes[i] != sizes[j]:
+                return
+            s0, s1 = T.get(i - 2), T.get(i - 1)
+            ci, cj = cells[i], cells[j]
+            if s0 is None or s1 is None or s0.shape[1] == ci.C_out or s1.shape[1] == cj.C_out or tuple(s1.shape[2:]) == sizes[i]:
+                return
+            if any(_volume(sizes[i]) > _volume(t.shape[2:]) for t in (s0, s1)):
+                return        # an up-sampling input runs conv-first (two launches): stays with its cell
+            for k in (i, j):
+                if k not in pre:
+                    pre[k] = torch.empty((B, 2 * cells[k].C_out) + sizes[k], device=dev, dtype=adt)
+                    has[k] = [False, False]
+            ops.conv3d_k1_resample_multi([(s0,) + ci.pre_preprocess.prepared() + (ci.pre_preprocess.relu, pre[i], 0),
+                                          (s1,) + ci.preprocess.prepared() + (ci.preprocess.relu, pre[i], ci.C_out),
+                                          (s1,) + cj.pre_preprocess.prepared() + (cj.pre_preprocess.relu, pre[j], 0)], sizes[i])
+            has[i] = [True, True]
+            has[j][0] = True
+
         for i, c in enumerate(cells):
+            shared_pre(i)
             specs = tails_for(i)
             need_main = i == n - 1 or len(specs) < len(all_consumers(i))   # the head reads the last cell's output
             cat, applied = c._run(T[i - 2], T[i - 1], pre=pre.get(i), pre_has=tuple(has.get(i, (False, False))),

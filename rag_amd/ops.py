@@ -378,6 +378,30 @@ def conv3d_k1_resample_pair(specs, size: Sequence[int], out: torch.Tensor) -> to
     return out
 
 
+def conv3d_k1_resample_multi(specs, size: Sequence[int]) -> None:
+    """Up to three resample(align_corners=True) + 1x1x1 ConvBR_3d at the same output `size` as one launch, each into its own buffer
+    (ragmi_conv3d_k1_resample_multi_fwd).  specs: tuples (x, weight2d, scale, shift, relu, out, out_ch0)."""
+    if not 1 <= len(specs) <= 3:
+        raise ValueError("conv3d_k1_resample_multi: 1..3 specs")
+    dt = _act(*[s[0] for s in specs], *[s[5] for s in specs])
+    Do, Ho, Wo = [int(v) for v in size]
+    arr, ys, bs = [], [], []
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    for (x, w2d, scale, shift, relu, out, ch0) in specs:
+        _need_gpu(w2d, scale, shift)
+        if tuple(out.shape[2:]) != (Do, Ho, Wo) or ch0 + w2d.shape[0] > out.shape[1] or out.shape[0] != x.shape[0]:
+            raise ValueError("conv3d_k1_resample_multi: output buffer too small / wrong size")
+        arr.append(K1RSpec(x.data_ptr(), _planes(x), x.shape[2], x.shape[3], x.shape[4], w2d.data_ptr(), p(scale), p(shift),
+                           int(relu), int(ch0), x.shape[1], w2d.shape[0]))
+        ys.append(out.data_ptr())
+        bs.append(_planes(out))
+    n = len(arr)
+    from ._lib import c_k1r_p
+    parr = (c_k1r_p * n)(*[ctypes.pointer(a) for a in arr])
+    check(load_library().ragmi_conv3d_k1_resample_multi_fwd(parr, (ctypes.c_void_p * n)(*ys), (ctypes.c_int64 * n)(*bs), n, specs[0][0].shape[0],
+                                                            Do, Ho, Wo, 1, dt, _stream()), "conv3d_k1_resample_multi")
+
+
 def cell2d_supported(C: int, cin0: int, cin1: int, cout: int, H: int, W: int, dtype=torch.float32) -> bool:
     """True when ragmi_cell2d_fwd is built for this Cell_2d shape under the CURRENT conv precision (f16x3, fp32 storage)."""
     if dtype != torch.float32:

@@ -1038,6 +1038,31 @@ def test_x2d_depth1_split_operand_conv(ra, x3_on, nset, cs, cout, shape):
     assert float((out - out32).abs().max()) <= 2e-5 * float(exp.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_k1_resample_multi_equals_separate_launches(ra, dtype):
+    """ragmi_conv3d_k1_resample_multi_fwd (round 4): a cell's two 1x1x1 convs and the next cell's pre_preprocess of the same tensor as
+    ONE launch, each into its own buffer — bit for bit what three separate ragmi_conv3d_k1_resample_fwd launches write."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g1 = gen(221)
+    size = (5, 9, 26)
+    a = torch.randn((2, 48) + size, generator=g1).to(td)                 # already at the output size
+    b = torch.randn((2, 24, 10, 18, 52), generator=g1).to(td)            # x0.5
+    ws = [torch.randn((16, c), generator=g1) * 0.3 for c in (48, 24, 24)]
+    sc = [torch.rand(16, generator=g1) + 0.5 for _ in range(3)]
+    sh = [torch.randn(16, generator=g1) * 0.1 for _ in range(3)]
+    outs = [torch.full((2, 34) + size, float("nan"), device=DEV, dtype=td) for _ in range(2)]
+    refs = [torch.full((2, 34) + size, float("nan"), device=DEV, dtype=td) for _ in range(2)]
+    xa, xb = gpu(a), gpu(b)
+    specs = [(xa, 0, 0, 1), (xb, 1, 0, 17), (xb, 2, 1, 2)]               # (input, weight set, destination buffer, first channel)
+    ra.ops.conv3d_k1_resample_multi([(x, gpu(ws[k]), gpu(sc[k]), gpu(sh[k]), True, outs[d], ch) for (x, k, d, ch) in specs], size)
+    for (x, k, d, ch) in specs:
+        ra.ops.conv3d_k1_resample(x, size, True, gpu(ws[k]), gpu(sc[k]), gpu(sh[k]), True, refs[d], ch)
+    for o, r in zip(outs, refs):
+        on, rn = o.float().cpu().numpy(), r.float().cpu().numpy()
+        assert np.array_equal(np.isnan(on), np.isnan(rn))
+        assert np.array_equal(on[~np.isnan(on)], rn[~np.isnan(rn)])
+
+
 @pytest.mark.parametrize("C,cin0,size0,cin1,size1,size,B", [
     (8, 12, (128, 416), 12, (128, 416), (64, 208), 2),     # Feature Net cell 0: both inputs down-sampled x0.5
     (4, 12, (128, 416), 24, (64, 208), (128, 416), 2),     # cell 1: s0 at the cell's size, s1 up-sampled x2
