@@ -68,18 +68,6 @@ __device__ __forceinline__ unsigned x3_split2(float v0, float v1, unsigned& lo) 
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{r0, r1}, x3_bf16x2));
   return hb;
 }
-// three bf16 parts (24 significant bits: exact up to the last fp32 bit) of two values: the fused tails' operand split, which keeps
-// the fp32 exponent range without a scale
-__device__ __forceinline__ unsigned x3_split3(float v0, float v1, unsigned& mid, unsigned& lo) {
-  const x3_bf16x2 h = __builtin_convertvector(x3_f32x2{v0, v1}, x3_bf16x2);
-  const unsigned hb = __builtin_bit_cast(unsigned, h);
-  const float r0 = v0 - __uint_as_float(hb << 16), r1 = v1 - __uint_as_float(hb & 0xffff0000u);
-  const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{r0, r1}, x3_bf16x2));
-  const float q0 = r0 - __uint_as_float(mb << 16), q1 = r1 - __uint_as_float(mb & 0xffff0000u);
-  mid = mb;
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x3_f32x2{q0, q1}, x3_bf16x2));
-  return hb;
-}
 // fp16 halves of two values scaled by the power of two `mul`: hi = fp16(v * mul), lo = fp16(v * mul - hi) (the difference is exact)
 __device__ __forceinline__ unsigned x3_split2h(float v0, float v1, float mul, unsigned& lo) {
   const float s0 = v0 * mul, s1 = v1 * mul;
