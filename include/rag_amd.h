@@ -141,7 +141,7 @@ typedef struct {
  * works one level down (Cell_3d with downup_sample = -1: F.interpolate(x, half size, 'trilinear', align_corners=True) followed by
  * pre_preprocess / preprocess, rag_model.py:146-155), computed conv-first in the producer's epilogue: y is [B, *, D/2, H/2, W/2].
  * Up to two of them (4 output channels each) beside up to two full-resolution tails; only the z-marching split-operand form takes
- * them (ragmi_conv3d_k3_uses_x3 with RAGMI_F32X3, fp32 storage, <= 12 input channels) and only for even D, H, W whose x0.5 source
+ * them (ragmi_conv3d_k3_uses_x3 with RAGMI_F32X3 or RAGMI_BF16, <= 12 input channels) and only for even D, H, W whose x0.5 source
  * pairs are aligned (ragmi_down2_tail_supported: output o reads inputs (2o, 2o+1) on every axis; the last may clamp). */
 int ragmi_down2_tail_supported(int D, int H, int W);
 

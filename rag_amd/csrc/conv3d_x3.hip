@@ -833,7 +833,6 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
   // voxels per SAMPLE: the choice of kernel (hence the rounding) must not depend on how a batch is split over ranks
   if ((int64_t)a.D * a.H * a.W < X3_MIN_VOXELS || a.W < 32 || a.D < 8) return false;
   if ((a.ntail > 0 || a.ndown > 0) && a.Cout > 16) return false;
-  if (a.ndown > 0 && dtype != RAGMI_F32X3) return false;              // down-sampling tails: fp32 storage only
   if ((int64_t)a.Cin * a.D * a.H * a.W >= (1ll << 31)) return false;
   return true;
 }
@@ -851,10 +850,10 @@ static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t 
 }
 template <class T, int NCG, int NSET>
 static int x3_launch_typed(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
-  if constexpr (std::is_same<T, float>::value && NCG <= 3) {      // down-sampling tails: fp32 storage, the level-3 launches (<= 3 channel groups)
+  if constexpr (NCG <= 3) {      // down-sampling tails: the level-3 launches (<= 3 channel groups)
     if (a.ndown > 0) return x3_launch_tails<T, NCG, NSET, 2>(a, e, grid, lds, st);
   }
-  if (a.ndown > 0) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: down-sampling tails are built for fp32 storage and <= 12 input channels");
+  if (a.ndown > 0) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: down-sampling tails are built for <= 12 input channels");
   return a.ntail > 0 ? x3_launch_tails<T, NCG, NSET, 1>(a, e, grid, lds, st) : x3_launch_tails<T, NCG, NSET, 0>(a, e, grid, lds, st);
 }
 template <int NCG, int NSET>

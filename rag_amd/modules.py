@@ -754,8 +754,8 @@ class MatchingNet(nn.Module):
         def down_ok(i, j):
             """cell j's 1x1x1 conv on T[i] as DOWN-SAMPLING tails of T[i]'s producer: cell j works at exactly half of T[i]'s size,
             the source pairs of that x0.5 resampling are aligned, and the producer is a level-3 dual launch on the z-marching
-            split-operand kernel (fp32 storage, default precision) — the only form that takes them"""
-            if i < 0 or adt != torch.float32 or ops.get_conv_precision() != "f16x3":
+            split-operand kernel (fp32 storage under the default precision, or bf16 storage) — the only form that takes them"""
+            if i < 0 or (adt == torch.float32 and ops.get_conv_precision() != "f16x3"):
                 return False
             src, dst, prod = sizes[i], sizes[j], cells[i]
             if tuple(2 * v for v in dst) != tuple(src) or not ops.down2_tail_supported(*src):

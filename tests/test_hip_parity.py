@@ -1193,6 +1193,36 @@ def test_x3_down_sampling_tails(ra, x3_on, shape, nreg, couts):
         np.testing.assert_allclose(got[:, ch0:ch0 + co].numpy(), ref.numpy(), rtol=3e-4, atol=3e-4)
 
 
+def test_x3_down_sampling_tails_bf16_storage(ra):
+    """The same down-sampling tails under bf16 activation storage (BASELINE configs[2]): bf16 in and out, fp32 on chip — against the
+    reference order evaluated in float64 from the SAME bf16 inputs, to the storage format's rounding (2^-8 relative per stored value)."""
+    B, D, H, W = 1, 16, 128, 128
+    C, cout = 4, 12
+    g1 = gen(231)
+    x = torch.randn((B, 2 * C, D, H, W), generator=g1).to(torch.bfloat16)
+    wa, wb = (torch.randn((cout, C, 3, 3, 3), generator=g1) * 0.2 for _ in range(2))
+    sa, sb = (torch.rand(cout, generator=g1) + 0.5 for _ in range(2))
+    ha, hb = (torch.randn(cout, generator=g1) * 0.1 for _ in range(2))
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    main = sum(F.relu(F.conv3d(x[:, i * C:(i + 1) * C].double(), w.double(), padding=1) * v(s.double()) + v(h.double()))
+               for i, (w, s, h) in enumerate(((wa, sa, ha), (wb, sb, hb))))
+    half = (D // 2, H // 2, W // 2)
+    tw, ts, th = torch.randn((8, cout), generator=g1) * 0.3, torch.rand(8, generator=g1) + 0.5, torch.randn(8, generator=g1) * 0.1
+    out = torch.full((B, 10) + half, float("nan"), device=DEV, dtype=torch.bfloat16)
+    gw, gs, gh = gpu(tw), gpu(ts), gpu(th)
+    tails = [ra.ops.Tail(gw[c0:c0 + 4], gs[c0:c0 + 4], gh[c0:c0 + 4], True, out, 1 + c0, down=True) for c0 in (0, 4)]
+    low = F.interpolate(main.float(), half, mode="trilinear", align_corners=True).double()
+    ref = F.relu(torch.einsum("oc,bcdhw->bodhw", tw.double(), low) * v(ts.double()) + v(th.double()))
+    y = torch.full((B, cout, D, H, W), float("nan"), device=DEV, dtype=torch.bfloat16)
+    assert ra.ops.conv3d_k3_uses_x3(2 * C, cout, B, D, H, W, nset=2, ntail=len(tails), dtype=torch.bfloat16)
+    ra.ops.conv3d_k3_dual(gpu(x), C, ra.ops.conv3d_k3_pack(gpu(wa)), gpu(sa), gpu(ha), ra.ops.conv3d_k3_pack(gpu(wb)), gpu(sb), gpu(hb),
+                          cout, True, y, tails=tails)
+    np.testing.assert_allclose(y.float().cpu().double().numpy(), main.numpy(), rtol=1e-2, atol=2e-2)
+    got = out.float().cpu().double()
+    assert torch.isnan(got[:, 0]).all() and torch.isnan(got[:, 9:]).all()
+    np.testing.assert_allclose(got[:, 1:9].numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
+
+
 def test_x3_dual_tails_and_headline_epe(ra, x3_on):
     """The level-3 launches of the headline forward (stem3d1 with fused tails and no main store, dual cells) on the f16x3
     kernel: EPE vs the CPU oracle stays within the gate (measured 1.2e-4 px; fp32-MFMA path 1.5e-5 px)."""
