@@ -29,6 +29,10 @@ namespace ragmi {
 // tile shape: widest x-tile whose padding waste is small; rows per lane sized so the grid still
 // fills 256 CUs a few times over.  0: TX=32,R=4   1: TX=16,R=2   2: TX=8,R=1
 static int choose_cfg(int B, int D, int H, int W) {
+#ifdef RAGMI_DIAG
+  static const int forced = [] { const char* v = getenv("RAGMI_K3_CFG"); return v ? atoi(v) : -1; }();      // tuning sweeps only
+  if (forced >= 0) return forced;
+#endif
   const int64_t vol = (int64_t)B * D * H * W;
   auto waste = [&](int tx) { return (double)(ceil_div(W, tx) * tx) / W; };
   if (W > 16 && waste(32) <= waste(16) + 1e-9 && vol >= (1 << 20)) return 0;
