@@ -482,14 +482,18 @@ constexpr int XD_THREADS = 512;                        // 8 waves: wave w owns r
 // COGS = output-channel blocks of 16 per workgroup (they share every operand read).  WS = the weight fragments of ONE set live in
 // LDS and are re-staged with every stage's box (from L2, 37 KB) instead of all sets' staying resident: what lets two blocks
 // per workgroup (8 channels per set) still fit two workgroups per CU.
-template <class T, int CH8, int NSET, int COGS, bool WS>
-__global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Args a, X3Extra e) {
+// W16 = 16 waves per workgroup, ONE column tile each (wave w: row w & 7 of plane w >> 3) instead of 8 waves with two: for the
+// level-12 cells, whose 103 KB of LDS allow one workgroup per CU — 8 waves, two per SIMD, nothing to hide a stage's latencies
+// behind; with 16 the same box is staged by twice the threads and every wave's MFMA chain is half as long.
+template <class T, int CH8, int NSET, int COGS, bool WS, bool W16 = false>
+__global__ __launch_bounds__(W16 ? 1024 : XD_THREADS, W16 ? 1 : (WS ? 4 : 2)) void conv3d_x3d_kernel(K3Args a, X3Extra e) {
+  constexpr int THREADS = W16 ? 1024 : XD_THREADS;
   static_assert(!WS || NSET == 2, "per-stage weights only pay with two sets");
-  constexpr int XD_TZ = 2, XD_HZ = XD_TZ + 2, XD_PL = XD_HZ * XD_HY * XD_HX, XD_NT = XD_TZ;
+  constexpr int XD_TZ = 2, XD_HZ = XD_TZ + 2, XD_PL = XD_HZ * XD_HY * XD_HX, XD_NT = W16 ? 1 : XD_TZ;
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr int NCG4 = 2 * CH8;                         // 4-channel groups per set: the staging unit and the packed fragments' unit
   constexpr int NSLS = (NCG4 * 27 + 7) / 8;             // K-slices per set, as packed: 7 (8 channels: 4 taps each) or 14 (16: 2 taps)
-  constexpr int NPF = (NCG4 * XD_PL + XD_THREADS - 1) / XD_THREADS;
+  constexpr int NPF = (NCG4 * XD_PL + THREADS - 1) / THREADS;
   constexpr int REC = CH8 * XD_PL;                      // 16-byte records per copy (hi or lo)
   extern __shared__ __attribute__((aligned(16))) uint4 xd_lds[];
   uint4* const lw = xd_lds + (BF ? 1 : 2) * REC;        // [set][block][slice][hi/lo][64 lanes]
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
   // 8 (kb & 1) .. +7 of tap 2 s + (kb >> 1) for 16 channels per set, all 8 channels of tap 4 s + kb for 8)
   constexpr int NWS = COGS * NSLS * 2 * 64;              // uint4 words of one set's fragments
   auto wcopy = [&](int set, int region) {
-    for (int i = tid; i < NWS; i += XD_THREADS) {
+    for (int i = tid; i < NWS; i += THREADS) {
       const int cl = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
       lw[region * NWS + i] = cog0 + cl < ncog ? e.wf[set][(int64_t)(cog0 + cl) * NSLS * 2 * 64 + r] : make_uint4(0u, 0u, 0u, 0u);
     }
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
 #pragma unroll
     for (int set = 0; set < NSET; ++set) wcopy(set, set);
   }
-  for (int i = tid; i < NSET * COGS * 16; i += XD_THREADS) {
+  for (int i = tid; i < NSET * COGS * 16; i += THREADS) {
     const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
     float sc = (co < a.Cout && a.scale[set]) ? a.scale[set][co] : 1.f;
     if constexpr (!BF) sc *= (co < a.Cout ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
     valid = 0;
 #pragma unroll
     for (int p = 0; p < NPF; ++p) {
-      const int el = p * XD_THREADS + tid, cg4 = el / XD_PL, r = el % XD_PL;
+      const int el = p * THREADS + tid, cg4 = el / XD_PL, r = el % XD_PL;
       const int xx = r % XD_HX, yy = (r / XD_HX) % XD_HY, zz = r / (XD_HX * XD_HY);
       const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + xx;
       const bool ok = cg4 < NCG4 && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
   auto commit = [&](float mul) {
 #pragma unroll
     for (int p = 0; p < NPF; ++p) {
-      const int el = p * XD_THREADS + tid;
+      const int el = p * THREADS + tid;
       if (el >= NCG4 * XD_PL) continue;
       const int cg4 = el / XD_PL, r = el % XD_PL;
       const bool ok = (valid >> p) & 1u;
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(XD_THREADS, WS ? 4 : 2) void conv3d_x3d_kernel(K3Ar
     }
   };
   // this wave's two column tiles: rows (tz, ty0) and (tz, ty0 + 1) of the box; lane quarter -> (channel half, dx shift)
-  const int tz = wave >> 2, ty0 = (wave & 3) * 2;
+  const int tz = W16 ? wave >> 3 : wave >> 2, ty0 = W16 ? (wave & 7) : (wave & 3) * 2;
   const int vb0 = (((CH8 == 2 ? (kb & 1) : 0) * XD_PL) + (tz * XD_HY + ty0) * XD_HX + n) * (int)sizeof(uint4);
   // this lane quarter's operand record of every K-slice: its tap's (dz, dy, dx) offset in the box, fixed for the launch
   int vsl[NSLS];
@@ -731,8 +735,9 @@ bool x3d_eligible(const K3Args& a, int nset, int dtype) {
   return true;
 }
 
-template <class T, int CH8, int NSET, int COGS, bool WS>
+template <class T, int CH8, int NSET, int COGS, bool WS, bool W16 = false>
 static int x3d_launch_one(K3Args a, X3Extra e, hipStream_t st) {
+  constexpr int THREADS = W16 ? 1024 : XD_THREADS;
   constexpr int PL = 4 * XD_HY * XD_HX;
   constexpr size_t lds = (size_t)(std::is_same<T, bf16_t>::value ? 1 : 2) * CH8 * PL * sizeof(uint4) +
                          (size_t)(WS ? 1 : NSET) * COGS * ((2 * CH8 * 27 + 7) / 8) * 2 * 64 * sizeof(uint4) + (size_t)(2 * NSET * COGS * 16 + 4) * sizeof(float);
@@ -742,12 +747,12 @@ static int x3d_launch_one(K3Args a, X3Extra e, hipStream_t st) {
   RAGMI_REQUIRE(nwork < (1ll << 28), RAGMI_EUNSUPPORTED, "conv3d_x3d: too many tiles");
   e.nwork = (int)nwork;
   static LaunchState state;
-  const int slots = state.slots((const void*)conv3d_x3d_kernel<T, CH8, NSET, COGS, WS>, XD_THREADS, lds, 160 * 1024);
+  const int slots = state.slots((const void*)conv3d_x3d_kernel<T, CH8, NSET, COGS, WS, W16>, THREADS, lds, 160 * 1024);
   if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_x3d: cannot raise the dynamic LDS limit");
   const int ny = (int)ceil_div((a.Cout + 15) / 16, COGS);
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(e.nwork, slots / ny));
   if (gx >= 8) gx -= gx % 8;
-  hipLaunchKernelGGL((conv3d_x3d_kernel<T, CH8, NSET, COGS, WS>), dim3((unsigned)gx, (unsigned)ny), dim3(XD_THREADS), lds, st, a, e);
+  hipLaunchKernelGGL((conv3d_x3d_kernel<T, CH8, NSET, COGS, WS, W16>), dim3((unsigned)gx, (unsigned)ny), dim3(THREADS), lds, st, a, e);
   return check_launch("conv3d_x3d");
 }
 
@@ -774,6 +779,10 @@ int x3d_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   if (ch8 == 1 && nset == 2 && a.Cout > 16) return RAGMI_XD(1, 2, 2, false);
 #endif
   if (ch8 == 1) return nset == 2 ? RAGMI_XD(1, 2, 1, false) : RAGMI_XD(1, 1, 1, false);
+  // 16 channels per set, two sets (the level-12 dual cells): one workgroup per CU by LDS -> 16 waves (W16 above)
+#ifndef RAGMI_XD_NOW16
+  if (nset == 2) return bf ? x3d_launch_one<bf16_t, 2, 2, 1, false, true>(a, e, st) : x3d_launch_one<float, 2, 2, 1, false, true>(a, e, st);
+#endif
   return nset == 2 ? RAGMI_XD(2, 2, 1, false) : RAGMI_XD(2, 1, 1, false);
 #undef RAGMI_XD
 }
