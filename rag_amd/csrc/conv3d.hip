@@ -28,7 +28,7 @@ namespace ragmi {
 // W'[co][ci][tap] = W[ci][co][taps-1-tap].  planar: the source has 9 taps (a 2-D 3x3 weight) living in the dz = 1 plane.
 // tile shape: widest x-tile whose padding waste is small; rows per lane sized so the grid still
 // fills 256 CUs a few times over.  0: TX=32,R=4   1: TX=16,R=2   2: TX=8,R=1
-static int choose_cfg(int B, int D, int H, int W) {
+static int choose_cfg(int B, int D, int H, int W, int Cout = 0) {
 #ifdef RAGMI_DIAG
   static const int forced = [] { const char* v = getenv("RAGMI_K3_CFG"); return v ? atoi(v) : -1; }();      // tuning sweeps only
   if (forced >= 0) return forced;
@@ -36,7 +36,9 @@ static int choose_cfg(int B, int D, int H, int W) {
   const int64_t vol = (int64_t)B * D * H * W;
   auto waste = [&](int tx) { return (double)(ceil_div(W, tx) * tx) / W; };
   if (W > 16 && waste(32) <= waste(16) + 1e-9 && vol >= (1 << 20)) return 0;
-  if (W > 8 && waste(16) <= waste(8) + 1e-9 && vol >= (1 << 17)) return 1;
+  // (round 4 sweep, tools/bench_deep.py under RAGMI_K3_CFG: the level-6 dual cell — 24 output channels on 2^18.7 voxels — runs 123.7 us
+  // on the narrow tile against 129.3 on the middle one; the 8-channel launches of that volume prefer the middle one)
+  if (W > 8 && waste(16) <= waste(8) + 1e-9 && vol >= (1 << 17) && !(Cout >= 20 && vol < (1 << 19))) return 1;
   return 2;
 }
 static int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int64_t y_bstride,
@@ -178,7 +180,7 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   if (x3d_eligible(a, 1, dtype)) return x3d_launch(a, 1, dtype, s);
   if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, dtype, s);
   RAGMI_REQUIRE(a.ndown == 0, RAGMI_EUNSUPPORTED, "conv3d_k3: down-sampling tails need the z-marching split-operand form (ragmi_conv3d_k3_uses_x3)");
-  switch (choose_cfg(B, D, H, W)) {
+  switch (choose_cfg(B, D, H, W, Cout)) {
     case 0: return bf ? launch_k3_s1_cfg0_bf16(a, ng, s) : launch_k3_s1_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s1_cfg1_bf16(a, ng, s) : launch_k3_s1_cfg1_f32(a, ng, s);
     default: return bf ? launch_k3_s1_cfg2_bf16(a, ng, s) : launch_k3_s1_cfg2_f32(a, ng, s);
@@ -258,7 +260,7 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   if (x3d_eligible(a, 2, dtype)) return x3d_launch(a, 2, dtype, s);
   if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, dtype, s);
   RAGMI_REQUIRE(a.ndown == 0, RAGMI_EUNSUPPORTED, "conv3d_k3_dual: down-sampling tails need the z-marching split-operand form (ragmi_conv3d_k3_uses_x3)");
-  switch (choose_cfg(B, D, H, W)) {
+  switch (choose_cfg(B, D, H, W, Cout)) {
     case 0: return bf ? launch_k3_s2_cfg0_bf16(a, ng, s) : launch_k3_s2_cfg0_f32(a, ng, s);
     case 1: return bf ? launch_k3_s2_cfg1_bf16(a, ng, s) : launch_k3_s2_cfg1_f32(a, ng, s);
     default: return bf ? launch_k3_s2_cfg2_bf16(a, ng, s) : launch_k3_s2_cfg2_f32(a, ng, s);
@@ -288,7 +290,7 @@ extern "C" int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int ns
   RAGMI_REQUIRE(Cout > 0 && B > 0 && D > 0 && H > 0 && W > 0 && max_launches > 0 && (nset == 1 || nset == 2), RAGMI_EINVAL,
                 "conv3d_k3_plan: bad argument");
   static const int cfgs[3][2] = {{5, 4}, {4, 2}, {3, 1}};
-  const int c = choose_cfg(B, D, H, W);
+  const int c = choose_cfg(B, D, H, W, Cout);
   *log_tx = cfgs[c][0];
   *rows_per_lane = (nset == 2 && c == 0) ? 2 : cfgs[c][1];   // the level-3 dual kernel uses 2 rows/lane (register budget)
   launch_groups[0] = split_groups((Cout + 3) / 4);   // one launch; blockIdx.y covers ngroups / G splits
