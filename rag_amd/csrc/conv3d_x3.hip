@@ -521,20 +521,6 @@ __global__ __launch_bounds__(W16 ? 1024 : XD_THREADS, W16 ? 1 : (WS ? 4 : 2)) vo
 #else
   constexpr bool diag_nowcopy = false;
 #endif
-  if constexpr (!WS) {
-    if (!diag_nowcopy)
-#pragma unroll
-    for (int set = 0; set < NSET; ++set) wcopy(set, set);
-  }
-  for (int i = tid; i < NSET * COGS * 16; i += THREADS) {
-    const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
-    float sc = (co < a.Cout && a.scale[set]) ? a.scale[set][co] : 1.f;
-    if constexpr (!BF) sc *= (co < a.Cout ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
-    par[i] = sc;
-    par[NSET * COGS * 16 + i] = (co < a.Cout && a.shift[set]) ? a.shift[set][co] : 0.f;
-  }
-  if (tid < 3) lmaxp[tid] = 0u;
-  __syncthreads();      // the slots are zero before any wave's first atomicMax (waves that skip the loops above arrive there early)
   float pf[NPF][4];
   unsigned valid = 0;
   const T* const x = static_cast<const T*>(a.x);
@@ -616,6 +602,21 @@ __global__ __launch_bounds__(W16 ? 1024 : XD_THREADS, W16 ? 1 : (WS ? 4 : 2)) vo
     locate(z0, y0, x0);
     prefetch(x + b * a.x_bstride, 0);
   }
+  // (the first box's loads are in flight: the weight fragments and parameters travel L2 -> LDS beside them, not in front of them)
+  if constexpr (!WS) {
+    if (!diag_nowcopy)
+#pragma unroll
+    for (int set = 0; set < NSET; ++set) wcopy(set, set);
+  }
+  for (int i = tid; i < NSET * COGS * 16; i += THREADS) {
+    const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
+    float sc = (co < a.Cout && a.scale[set]) ? a.scale[set][co] : 1.f;
+    if constexpr (!BF) sc *= (co < a.Cout ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
+    par[i] = sc;
+    par[NSET * COGS * 16 + i] = (co < a.Cout && a.shift[set]) ? a.shift[set][co] : 0.f;
+  }
+  if (tid < 3) lmaxp[tid] = 0u;
+  __syncthreads();      // the slots are zero before any wave's first atomicMax (waves that skip the loops above arrive there early)
 #ifdef RAGMI_DIAG
   const bool diag_nostore = (a.relu & 0x100) != 0, diag_nomfma = (a.relu & 0x200) != 0, diag_nostage = (a.relu & 0x400) != 0;
 #else
