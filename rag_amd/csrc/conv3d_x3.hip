@@ -243,28 +243,25 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const LinIdx lz = lin_index(min(Z, Do - 1), a.D, Do, e.dsd, 1);            // wave-uniform
       const float wz0 = lz.i0 == 2 * Z ? lz.w0 : 0.f, wz1 = lz.i0 == 2 * Z ? lz.w1 : 1.f;
       const int64_t ovol = (int64_t)Do * Ho * Wo;
-      const int o = tid;                                                          // (slot, row pair, column): 4 channels each
+      // one output VALUE per thread: (slot, row pair, column) x channel — all eight waves take part (round 4, first form: one thread
+      // per four channels, i.e. two waves worked while six waited at the next barrier)
+      const int o = tid >> 2, r = tid & 3;
       if (o < a.ndown * 64) {
         const int dl = o >> 6, yp = (o >> 4) & 3, xp = o & 15;
         const float4 yt = ldyt[yp];
-        const float4* const u0 = reinterpret_cast<const float4*>(ldu) + ((0 * 2 + dl) * X3_TY + 2 * yp) * (X3_TX / 2) + xp;
-        const float4* const u1 = u0 + 2 * X3_TY * (X3_TX / 2);
-        const float4 e0 = u0[0], e1 = u0[X3_TX / 2], o0 = u1[0], o1 = u1[X3_TX / 2];
-        const float ev[4][4] = {{e0.x, e0.y, e0.z, e0.w}, {e1.x, e1.y, e1.z, e1.w}, {o0.x, o0.y, o0.z, o0.w}, {o1.x, o1.y, o1.z, o1.w}};
+        const float* const u0 = ldu + (((0 * 2 + dl) * X3_TY + 2 * yp) * (X3_TX / 2) + xp) * 4 + r;
+        const float* const u1 = u0 + 2 * X3_TY * (X3_TX / 2) * 4;
+        const float e0 = u0[0], e1 = u0[(X3_TX / 2) * 4], o0 = u1[0], o1 = u1[(X3_TX / 2) * 4];
         const int slot = a.ntail + dl;
-        const float4 sc = *reinterpret_cast<const float4*>(par + 64 + 4 * slot), sh = *reinterpret_cast<const float4*>(par + 80 + 4 * slot);
-        const float sc4[4] = {sc.x, sc.y, sc.z, sc.w}, sh4[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float sc = par[64 + 4 * slot + r], sh = par[80 + 4 * slot + r];
         const int dcout = dl ? a.down_cout[1] : a.down_cout[0], drelu = dl ? a.down_relu[1] : a.down_relu[0];
         const int Y = (y0 >> 1) + yp, X = (x0 >> 1) + xp;
-        if (Y < Ho && X < Wo && Z < Do) {
+        if (Y < Ho && X < Wo && Z < Do && r < dcout) {
           T* const dy = static_cast<T*>(dl ? a.down_y[1] : a.down_y[0]) + b * (dl ? a.down_bstride[1] : a.down_bstride[0]) +
-                        (int64_t)(dl ? a.down_ch0[1] : a.down_ch0[0]) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ye = lerp2(yt.x, ev[0][r], yt.y, ev[1][r]), yo = lerp2(yt.x, ev[2][r], yt.y, ev[3][r]);
-            const float uu = fmaf(lerp2(wz0, ye, wz1, yo), sc4[r], sh4[r]);
-            if (r < dcout) st(dy + r * ovol, drelu ? fmaxf(uu, 0.f) : uu);
-          }
+                        (int64_t)((dl ? a.down_ch0[1] : a.down_ch0[0]) + r) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
+          const float ye = lerp2(yt.x, e0, yt.y, e1), yo = lerp2(yt.x, o0, yt.y, o1);
+          const float uu = fmaf(lerp2(wz0, ye, wz1, yo), sc, sh);
+          st(dy, drelu ? fmaxf(uu, 0.f) : uu);
         }
       }
     }
