@@ -311,7 +311,7 @@ template <class T, bool VEC>
 static void launch_k1(const K1Args& a, int B, hipStream_t s) {
   constexpr int V = VEC ? 4 : 1;
   const int64_t threads = (int64_t)B * ceil_div(a.dhw, V);
-  const int64_t want = 256 * 256 * 2;   // ~2 workgroups per CU
+  const int64_t want = 256 * 256 * 4;   // ~4 workgroups per CU (round 4 sweep at the headline shapes: 1.5 per CU +6 us over the small launches, 2 -> 4: -1 us)
   static const int widths[5] = {24, 16, 12, 8, 4};
   int cover = 24;   // smallest slab covering Cout (Cout > 24 runs in slabs of 24)
   for (int w : widths)
