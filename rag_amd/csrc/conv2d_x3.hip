@@ -232,8 +232,9 @@ __global__ __launch_bounds__(C2_THREADS) void cell2d_x3_kernel(K3Args a, X3Extra
   const bool item_on[NI] = {true, true, tid < 2 * NREST};
   // All three items of a thread advance TOGETHER through the input channels, U channels x 4 taps of each in flight per trip: a thread's
   // staging is a chain of memory round trips and nothing else (first version, one item after the other, U = 4: 18 trips for 24
-  // channels, 27-30 us per cell — slower than the separate launches; this form: 3 trips).  An input already at the cell's size goes
-  // through the same four-tap code (lin_index gives it the pair (i, i) with weights (1, 0): the loads repeat an address).
+  // channels, 27-30 us per cell — slower than the separate launches; this form: 3 trips).  An input already at the cell's size is
+  // read with ONE load per channel in the two full rounds (a workgroup-uniform test); the mixed last round takes the four-tap code
+  // for both sets (lin_index gives such an input the pair (i, i) with weights (1, 0): the loads repeat an address).
   constexpr int U = 8;
   const float* xp[NI];
   int o4[NI][4], cin[NI], ivol[NI];
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(C2_THREADS) void cell2d_x3_kernel(K3Args a, X3Extra
     for (int j = 0; j < C; ++j) sv[p][j] = 0.f;
   }
   const int cmax = max(in0.Cin, in1.Cin);
+  const bool ident[NI] = {in0.Hi == a.H && in0.Wi == a.W, in1.Hi == a.H && in1.Wi == a.W, false};      // workgroup-uniform
   for (int c0 = 0; c0 < cmax; c0 += U) {
     float t[NI][U][4];
 #pragma unroll
@@ -263,8 +265,11 @@ __global__ __launch_bounds__(C2_THREADS) void cell2d_x3_kernel(K3Args a, X3Extra
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const float* const pc = xp[p] + (int64_t)min(c0 + u, cin[p] - 1) * ivol[p];
+        t[p][u][0] = pc[o4[p][0]];
+        if (!ident[p]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[p][u][k] = pc[o4[p][k]];
+          for (int k = 1; k < 4; ++k) t[p][u][k] = pc[o4[p][k]];
+        }
       }
 #pragma unroll
     for (int p = 0; p < NI; ++p) {
@@ -273,7 +278,8 @@ __global__ __launch_bounds__(C2_THREADS) void cell2d_x3_kernel(K3Args a, X3Extra
       for (int u = 0; u < U; ++u) {
         if (c0 + u < cin[p]) {
           // x innermost, then y (ATen's nesting; the depth axis of these depth-1 volumes interpolates with weights (1, 0))
-          const float xv = lerp2(wy[p][0], lerp2(wx[p][0], t[p][u][0], wx[p][1], t[p][u][1]), wy[p][1], lerp2(wx[p][0], t[p][u][2], wx[p][1], t[p][u][3]));
+          const float xv = ident[p] ? t[p][u][0]
+                                    : lerp2(wy[p][0], lerp2(wx[p][0], t[p][u][0], wx[p][1], t[p][u][1]), wy[p][1], lerp2(wx[p][0], t[p][u][2], wx[p][1], t[p][u][3]));
 #pragma unroll
           for (int j = 0; j < C; j += 4) {
             const float4 w4 = *reinterpret_cast<const float4*>(wv + (c0 + u) * C + j);
