@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
 #pragma unroll
   for (int co = 0; co < MC; ++co) av[co] = 0.f;
   int key = -1;                                                   // (cls, tc) the registers in av belong to
-#pragma unroll 2
+#pragma unroll 1
   for (int i = i0; i < i1; ++i) {
     const int cls = (i == 0 ? 1 : 0) + (i == a.D - 1 ? 2 : 0);
     const int t = x - i, tc = min(max(t, -3), 2);
