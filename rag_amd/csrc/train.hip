@@ -602,7 +602,42 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(TriBwdArgs a) {
   tap_range(iz, a.Di, a.Do, a.sd, a.align, z0, z1);
   tap_range(iy, a.Hi, a.Ho, a.sh, a.align, y0, y1);
   tap_range(ix, a.Wi, a.Wo, a.sw, a.align, x0, x1);
-  // channels per thread: the tap ranges / weights depend on the voxel only, so a thread reuses them over `cpt` channels
+  // channels per thread: the tap ranges / weights depend on the voxel only, so a thread reuses them over `cpt` channels.  With at
+  // most four taps per axis (every x2 / x0.5 / x3 resample of the networks) the weights are evaluated ONCE per voxel into registers
+  // (round 4: they were re-derived — a lin_index each — inside the tap loops of every channel: most of the kernel's instructions);
+  // same values, same order of products and sums.
+  constexpr int MT = 4;
+  const int nz = z1 - z0 + 1, ny = y1 - y0 + 1, nx = x1 - x0 + 1;
+  if (nz <= MT && ny <= MT && nx <= MT) {
+    float wz[MT], wy[MT], wx[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+      wz[k] = k < nz ? tap_weight(z0 + k, iz, a.Di, a.Do, a.sd, a.align) : 0.f;
+      wy[k] = k < ny ? tap_weight(y0 + k, iy, a.Hi, a.Ho, a.sh, a.align) : 0.f;
+      wx[k] = k < nx ? tap_weight(x0 + k, ix, a.Wi, a.Wo, a.sw, a.align) : 0.f;
+    }
+    for (int c = blockIdx.z * a.cpt; c < min(a.C, (int)(blockIdx.z + 1) * a.cpt); ++c) {
+      const float* pc = a.dy + ((int64_t)b * a.C + c) * ovol;
+      float acc = 0.f;
+#pragma unroll
+      for (int kz = 0; kz < MT; ++kz) {
+        if (kz >= nz) break;
+#pragma unroll
+        for (int ky = 0; ky < MT; ++ky) {
+          if (ky >= ny) break;
+          const float wzy = wz[kz] * wy[ky];
+          const float* pr = pc + ((int64_t)(z0 + kz) * a.Ho + (y0 + ky)) * a.Wo + x0;
+#pragma unroll
+          for (int kx = 0; kx < MT; ++kx) {
+            if (kx >= nx) break;
+            acc = fmaf(pr[kx], wzy * wx[kx], acc);
+          }
+        }
+      }
+      a.dx[((int64_t)b * a.C + c) * ivol + p] = acc;
+    }
+    return;
+  }
   for (int c = blockIdx.z * a.cpt; c < min(a.C, (int)(blockIdx.z + 1) * a.cpt); ++c) {
     const float* pc = a.dy + ((int64_t)b * a.C + c) * ovol;
     float acc = 0.f;
