@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — disparity maps/sec of the Matching-Net forward (left_fea, right_fea) -> disp.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
-torch.distributed.run with one rank per GPU.  A "step" is one pass of the hot path
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 either launched by
+torch.distributed.run with one rank per GPU, or — WORLD_SIZE unset — this script starts its own N ranks (launch_ranks: N child
+processes, started before anything touches the GPU; rank 0's line is relayed).  A "step" is one pass of the hot path
 (cost volume -> 3-D conv aggregation -> soft-argmin) over one batch of synthetic stereo
 features already resident in HBM.  Workload at every N: BASELINE.json configs[1] per GPU
 (B=1, 384x1248, D=192, fp32, all-conv genotype, seeded weights with randomised BN —
@@ -156,12 +157,17 @@ def pmc_traffic_bytes(kernel_name: str):
     return None, None
 
 
+GPU_ERROR = []      # messages of synchronizes that failed inside an error handler: a sticky GPU error (fault, abort)
+
+
 def safe_sync():
     """torch.cuda.synchronize() for error handlers: after a sticky GPU error the synchronize itself raises again — swallowed here,
-    so that a failed rider leg is recorded under its key and never costs the headline its line."""
+    so that a failed rider leg is recorded under its key and never costs the headline its line.  Such a failure is NOT a green run:
+    it is remembered (GPU_ERROR), the JSON line carries "gpu_error" and the process exits non-zero after printing it."""
     try:
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001
+        GPU_ERROR.append(f"{type(exc).__name__}: {exc}")
         log(f"bench: synchronize in an error handler failed too ({type(exc).__name__}: {exc})")
 
 
@@ -582,6 +588,85 @@ def other_configs(net, lf, rf, out_f32, ref, device, use_graph, dist):
     return res
 
 
+def rank_env(args_gpus: int):
+    """Rank plumbing of one process: (world, rank, local_rank, n_gpus, seed) from the environment a launcher sets
+    (torch.distributed.run, or launch_ranks below).  Touches no GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = world if world > 1 else 1
+    return world, rank, local_rank, n_gpus, 1234 + rank
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process — which has made NO HIP call and never
+    touches the GPU — starts N fresh child processes of this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    the way torch.distributed.run sets them), waits for all of them, relays rank 0's JSON line on stdout and returns non-zero if any
+    child failed.  No exec: the children are ordinary subprocesses."""
+    import subprocess
+    import tempfile
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # wait for all; a rank that dies takes the job with it (its peers would wait for it in a collective until the timeout):
+        # the survivors — exactly the processes started above — are terminated after a short grace period
+        failed_at = None
+        while any(q.poll() is None for q in procs):
+            if failed_at is None and any(q.poll() not in (None, 0) for q in procs):
+                failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > 5.0:
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
+            time.sleep(0.1)
+        codes = [q.returncode for q in procs]
+        out0.seek(0)
+        lines = [ln for ln in out0.read().splitlines() if ln.strip()]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if lines and not bad:
+        print(lines[-1], flush=True)
+        return 0
+    log(f"bench: launcher: ranks failed (rank, exit code): {bad}; rank 0 printed {len(lines)} line(s)")
+    if lines:
+        print(lines[-1], flush=True)
+    return 1
+
+
+def dry_ranks(args_gpus: int) -> None:
+    """--dry-ranks: the rank plumbing of main() without a GPU — every rank reports (rank, world, local rank -> device, seed), the
+    ranks meet in a gloo group (barrier + gather), rank 0 prints one JSON line.  What tests/test_bench_sharding.py runs through
+    the launcher above."""
+    import torch.distributed as dist
+    world, rank, local_rank, n_gpus, seed = rank_env(args_gpus)
+    if os.environ.get("RAGMI_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the group forms
+        sys.exit(7)
+    me = {"rank": rank, "world": world, "local_rank": local_rank, "device": f"cuda:{local_rank}", "seed": seed}
+    everyone = [me]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_ranks": True, "n_gpus": n_gpus, "ranks_seen": len(everyone), "dist_backend": "gloo" if world > 1 else None,
+                          "ranks": everyone}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -599,7 +684,14 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (configs object)")
     ap.add_argument("--hw", default=None, help="HxW of the stereo pairs, multiples of 12 (default 384x1248 = configs[1]; configs[3]: "
                                                "480x960 with --batch 8)")
+    ap.add_argument("--dry-ranks", action="store_true", help="rank plumbing only (no GPU): every rank reports rank / world / device / seed")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: be the launcher (before anything touches the GPU: `import torch` above makes no HIP call)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_ranks:
+        dry_ranks(args.gpus)
+        return
     if args.graph is None:
         args.graph = 1
     global H, W
@@ -608,19 +700,13 @@ def main():
         if H % 12 or W % 12:
             ap.error("--hw: H and W must be multiples of 12 (rag_model.py:317-323)")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank, n_gpus, seed = rank_env(args.gpus)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if world > 1 else args.gpus
-    if world == 1 and args.gpus > 1:
-        log(f"bench: --gpus {args.gpus} without a torch.distributed launcher: running 1 rank")
-        n_gpus = 1
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     # everything (eager launches, hipGraph replays, timing events) on ONE explicit stream rather than the legacy null stream
@@ -640,7 +726,7 @@ def main():
         return
     net = build_net(device)
     B, h, w = args.batch, H // 3, W // 3
-    g = torch.Generator().manual_seed(1234 + rank)
+    g = torch.Generator().manual_seed(seed)
     act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lf = torch.randn((B, FEA_C, h, w), generator=g).to(device).to(act)
     rf = torch.randn((B, FEA_C, h, w), generator=g).to(device).to(act)
@@ -821,7 +907,11 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "strict_fp32": strict, "epe_bf16_vs_fp32": epe_bf16_vs_fp32, "end_to_end": e2e,
             "configs": configs, "library": rag_amd.lib_path(), "graph_nodes": graph_nodes or None,
         }
+        if GPU_ERROR:
+            line["gpu_error"] = GPU_ERROR
         print(json.dumps(line), flush=True)
+        if GPU_ERROR:
+            sys.exit(3)      # a sticky GPU error in a rider leg must not pass as a successful run
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

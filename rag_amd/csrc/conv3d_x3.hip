@@ -904,7 +904,10 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
     if (rem > 0 && rem <= 32) e.nsplit = rem;
   }
   if (a.ndown > 0) {
-    if (e.seg_len % 4 != 0) e.nsplit = 0;               // (the halves of a split segment must be even too)
+    // the halves of a split item must start and end on even planes too (down_finish pairs the planes 2Z, 2Z+1): EVERY item's length
+    // a multiple of 4 — also the last segment's, which is D - (nseg - 1) * seg_len planes (D % 4 == 2 left it at 2 mod 4,
+    // its odd mid-point made both halves finish the same half-resolution voxel from a stale slot)
+    if (e.seg_len % 4 != 0 || (a.D - (e.nseg - 1) * e.seg_len) % 4 != 0) e.nsplit = 0;
     e.dsd = lin_scale(a.D, a.D / 2, 1); e.dsh = lin_scale(a.H, a.H / 2, 1); e.dsw = lin_scale(a.W, a.W / 2, 1);
   }
   const int64_t nwork = (int64_t)a.B * e.ngrp * (e.grp + e.nsplit);

@@ -777,10 +777,13 @@ class MatchingNet(nn.Module):
             elif 0 <= j < n and cells[j].downup_sample == -1 and down_ok(i, j):
                 out.append((j, 1, True))
             j = i + 2
-            if (0 <= j < n and cells[j].downup_sample == 0 and cells[j - 1].downup_sample == 0 and cells[j].C_out <= 4
+            # (the cell between producer and consumer keeps the size: for j == 0 that "cell" is stem3d1 — same size by construction —
+            # not cells[-1], the LAST cell)
+            mid_same = j - 1 < 0 or cells[j - 1].downup_sample == 0
+            if (0 <= j < n and cells[j].downup_sample == 0 and mid_same and cells[j].C_out <= 4
                     and cells[j].C_out % 4 == 0 and cells[j].C_prev_prev != cells[j].C_out):
                 out.append((j, 0, False))
-            elif (0 <= j < n and cells[j].downup_sample == -1 and cells[j - 1].downup_sample == 0 and cells[j].C_prev_prev != cells[j].C_out
+            elif (0 <= j < n and cells[j].downup_sample == -1 and mid_same and cells[j].C_prev_prev != cells[j].C_out
                   and down_ok(i, j)):
                 out.append((j, 0, True))
             return out

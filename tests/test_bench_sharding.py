@@ -103,3 +103,52 @@ def test_grad_bucket_allreduce_two_ranks_gloo():
     assert n0 == n1
     for u, v in zip(p0, p1):
         np.testing.assert_array_equal(u, v)
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset): the parent starts 2 children before touching any GPU, each
+    goes through main()'s rank plumbing (RANK / LOCAL_RANK -> device, seed 1234 + rank), they meet in a process group, and rank 0's
+    JSON line is relayed with ranks_seen == 2.  --dry-ranks: the plumbing without a GPU (gloo)."""
+    import json
+    r = _run_bench("--gpus", "2", "--dry-ranks")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_ranks"] and d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dist_backend"] == "gloo"
+    assert [q["rank"] for q in d["ranks"]] == [0, 1]
+    assert [q["device"] for q in d["ranks"]] == ["cuda:0", "cuda:1"]
+    assert [q["seed"] for q in d["ranks"]] == [1234, 1235]
+    assert all(q["world"] == 2 for q in d["ranks"])
+
+
+def test_bench_one_rank_needs_no_launcher():
+    import json
+    r = _run_bench("--gpus", "1", "--dry-ranks")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["dist_backend"] is None and d["ranks"][0]["device"] == "cuda:0"
+
+
+def test_bench_under_an_external_launcher_does_not_relaunch():
+    """With WORLD_SIZE set (torch.distributed.run's environment) the script is a rank, never a launcher."""
+    import json
+    r = _run_bench("--gpus", "2", "--dry-ranks", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["ranks_seen"] == 1 and d["ranks"][0]["world"] == 1
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A child that dies makes the launcher exit non-zero (rank 1 exits before the group forms; rank 0's rendezvous then fails too)."""
+    r = _run_bench("--gpus", "2", "--dry-ranks", env={"RAGMI_BENCH_DRY_FAIL_RANK": "1", "TORCH_DIST_INIT_BARRIER": "0"})
+    assert r.returncode != 0

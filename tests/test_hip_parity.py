@@ -1146,7 +1146,9 @@ def test_x3_deep_form_vs_oracle(ra, x3_on, nset, cs, cout, shape, dtype):
 
 @pytest.mark.parametrize("shape,nreg,couts", [((1, 16, 128, 128), 1, (8,)),         # cell 1's launch: one full-resolution tail + a 12 -> 8 down pair
                                               ((2, 16, 132, 160), 0, (8,)),         # cell 2's launch: down tails only; two samples; partial tiles
-                                              ((1, 32, 128, 64), 2, (4, 4))])       # two regular tails + two separate 4-channel down tails
+                                              ((1, 32, 128, 64), 2, (4, 4)),        # two regular tails + two separate 4-channel down tails
+                                              ((1, 14, 128, 160), 1, (8,)),         # D % 4 == 2: last depth segment of 6 planes, 20 pairs per group
+                                              ((1, 26, 64, 192), 0, (4, 4))])       # eligible for the half-item split; last segment 2
 def test_x3_down_sampling_tails(ra, x3_on, shape, nreg, couts):
     """Down-sampling tails of the z-marching split-operand kernel (round 4): the 1x1x1 ConvBR_3d of a consumer cell that works one
     level down — F.interpolate(x, half size, 'trilinear', align_corners=True) followed by pre_preprocess / preprocess
