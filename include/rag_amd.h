@@ -145,6 +145,24 @@ typedef struct {
  * pairs are aligned (ragmi_down2_tail_supported: output o reads inputs (2o, 2o+1) on every axis; the last may clamp). */
 int ragmi_down2_tail_supported(int D, int H, int W);
 
+/* Channel-group-interleaved tensors ("G4"): [B][C/4][D][H][W][4] fp32 — the four channels of a group of a voxel are 16 contiguous
+ * bytes — instead of channel planes [B][C][D][H][W].  A PRIVATE layout of the fused executor (rag_amd.MatchingNet._run_chain) for
+ * the level-3 tensors its own kernels exchange (the 8-channel s0|s1 inputs of the dual cells, stem3d0's output): every module
+ * boundary of the reference (rag_model.py:143-177, 325-366) keeps channel planes.  Why: on gfx950 the vector memory path costs per
+ * INSTRUCTION; in G4 a halo voxel of a group is one 16-byte load and a fused tail one 16-byte store instead of four 4-byte ones into
+ * four planes (profiles/r05_x3_stamps.md).  Flags (fp32 storage only; RAGMI_EUNSUPPORTED where the kernel a call lands on does not
+ * take them — ask ragmi_conv3d_k3_g4_caps first):
+ *   `relu` argument of ragmi_conv3d_k3_fwd_ex / _dual_fwd_ex:  bit 1 (RAGMI_CONV_X_G4): x is G4 (x_bstride in floats, as ever);
+ *   ragmi_tail_t.relu bit 2 (RAGMI_TAIL_G4): the tail's destination y is G4; y_ch0 (a multiple of 4) names the group y_ch0 / 4; the
+ *                  tail must have exactly 4 output channels.  All full-resolution tails of a call agree; down-sampling tails are planes.
+ *   `relu` argument of ragmi_costvol_stem_fwd: bit 2 (RAGMI_CONV_Y_G4): y (Cout a multiple of 4) is G4; its tails as above. */
+#define RAGMI_CONV_RELU 1
+#define RAGMI_CONV_X_G4 2
+#define RAGMI_CONV_Y_G4 4
+#define RAGMI_TAIL_G4 4
+/* bit mask: 1 = this call accepts a G4 input, 2 = it can write G4 full-resolution tails (arguments as ragmi_conv3d_k3_uses_x3) */
+int ragmi_conv3d_k3_g4_caps(int Cin, int Cout, int B, int D, int H, int W, int nset, int ntail, int ndown, int dtype);
+
 /*
  * ragmi_conv3d_k3_fwd / ragmi_conv3d_k3_dual_fwd with up to two full-resolution tails (plus up to two down-sampling ones).  store_main = 0 skips writing the 3x3x3
  * result itself (only the tails consume it).  Tails need Cout in {4, 8, 12, 16} (all channels in one workgroup).

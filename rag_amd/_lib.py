@@ -49,6 +49,7 @@ SIGNATURES = {
     "ragmi_costvol_stem_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p,
                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_tail_p, c_int, c_void_p]),
     "ragmi_conv3d_k3_uses_x3": (c_int, [c_int] * 10),
+    "ragmi_conv3d_k3_g4_caps": (c_int, [c_int] * 10),
     "ragmi_conv3d_k3_packed_elems": (c_int64, [c_int, c_int]),
     "ragmi_conv3d_k3_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k3_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,

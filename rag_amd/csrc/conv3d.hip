@@ -78,6 +78,7 @@ static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* 
   a.store_main = 1;
   a.ntail = 0;
   a.ndown = 0;
+  a.tail_g4 = 0;
   if (ntail == 0 && store_main) return RAGMI_OK;
   RAGMI_REQUIRE(ntail >= 0 && ntail <= 4 && (ntail == 0 || tails != nullptr), RAGMI_EINVAL, "conv3d_k3: 0..4 tails");
   RAGMI_REQUIRE(ntail > 0 || store_main, RAGMI_EINVAL, "conv3d_k3: store_main = 0 needs at least one tail");
@@ -102,6 +103,10 @@ static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* 
     }
     const int k = a.ntail;
     RAGMI_REQUIRE(k < 2, RAGMI_EUNSUPPORTED, "conv3d_k3: at most two full-resolution tails");
+    const int g4 = (tails[t].relu & RAGMI_TAIL_G4) ? 1 : 0;
+    RAGMI_REQUIRE(k == 0 || g4 == a.tail_g4, RAGMI_EUNSUPPORTED, "conv3d_k3: the full-resolution tails of a call share one layout");
+    RAGMI_REQUIRE(!g4 || (tails[t].cout == 4 && tails[t].y_ch0 % 4 == 0), RAGMI_EINVAL, "conv3d_k3: a G4 tail has 4 output channels and a group-aligned y_ch0");
+    a.tail_g4 = g4;
     a.tail_w[k] = (const float*)tails[t].weight; a.tail_scale[k] = (const float*)tails[t].scale;
     a.tail_shift[k] = (const float*)tails[t].shift; a.tail_y[k] = tails[t].y;
     a.tail_bstride[k] = tails[t].y_bstride; a.tail_ch0[k] = tails[t].y_ch0; a.tail_cout[k] = tails[t].cout;
@@ -176,6 +181,12 @@ extern "C" int ragmi_conv3d_k3_fwd_ex(const void* x, int64_t x_bstride, const vo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  {
+    const int want = ((relu & RAGMI_CONV_X_G4) ? 1 : 0) | (a.tail_g4 ? 2 : 0);
+    RAGMI_REQUIRE(!(relu & RAGMI_CONV_Y_G4), RAGMI_EUNSUPPORTED, "conv3d_k3: the main output is channel planes (RAGMI_CONV_Y_G4 not built here)");
+    RAGMI_REQUIRE((x3_g4_caps(a, 1, dtype) & want) == want, RAGMI_EUNSUPPORTED,
+                  "conv3d_k3: this shape / dtype does not take G4 tensors (ragmi_conv3d_k3_g4_caps)");
+  }
   if (x2d_eligible(a, 1, dtype)) return x2d_launch(a, 1, dtype, s);
   if (x3d_eligible(a, 1, dtype)) return x3d_launch(a, 1, dtype, s);
   if (x3_eligible(a, 1, dtype)) return x3_launch(a, 1, dtype, s);
@@ -256,6 +267,12 @@ extern "C" int ragmi_conv3d_k3_dual_fwd_ex(const void* x, int64_t x_bstride, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ng = (Cout + 3) / 4;
   const bool bf = dtype == RAGMI_BF16;
+  {
+    const int want = ((relu & RAGMI_CONV_X_G4) ? 1 : 0) | (a.tail_g4 ? 2 : 0);
+    RAGMI_REQUIRE(!(relu & RAGMI_CONV_Y_G4), RAGMI_EUNSUPPORTED, "conv3d_k3_dual: the main output is channel planes (RAGMI_CONV_Y_G4 not built here)");
+    RAGMI_REQUIRE((x3_g4_caps(a, 2, dtype) & want) == want, RAGMI_EUNSUPPORTED,
+                  "conv3d_k3_dual: this shape / dtype does not take G4 tensors (ragmi_conv3d_k3_g4_caps)");
+  }
   if (x2d_eligible(a, 2, dtype)) return x2d_launch(a, 2, dtype, s);
   if (x3d_eligible(a, 2, dtype)) return x3d_launch(a, 2, dtype, s);
   if (x3_eligible(a, 2, dtype)) return x3_launch(a, 2, dtype, s);
@@ -281,6 +298,19 @@ extern "C" int ragmi_conv3d_k3_uses_x3(int Cin, int Cout, int B, int D, int H, i
   else a.nchunks[0] = (Cin + CK - 1) / CK;
   a.store_main = 1;
   return (x2d_eligible(a, nset, dtype) || x3d_eligible(a, nset, dtype) || x3_eligible(a, nset, dtype)) ? 1 : 0;
+}
+
+extern "C" int ragmi_conv3d_k3_g4_caps(int Cin, int Cout, int B, int D, int H, int W, int nset, int ntail, int ndown, int dtype) {
+  using namespace ragmi;
+  if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || (nset != 1 && nset != 2)) return 0;
+  K3Args a{};
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.ntail = ntail; a.ndown = ndown;
+  for (int t = 0; t < 2; ++t) a.tail_cout[t] = a.down_cout[t] = 4;
+  for (int g = 0; g < (Cout + 3) / 4 && g < RAGMI_MAX_GROUPS; ++g) a.y_ch[g] = 4 * g;
+  if (nset == 2) { if (Cin % (2 * CK)) return 0; a.nchunks[0] = a.nchunks[1] = Cin / (2 * CK); }
+  else a.nchunks[0] = (Cin + CK - 1) / CK;
+  a.store_main = 1;
+  return x3_g4_caps(a, nset, dtype);
 }
 
 extern "C" int ragmi_conv3d_k3_plan(int Cout, int B, int D, int H, int W, int nset, int32_t* log_tx,

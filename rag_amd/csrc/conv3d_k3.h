@@ -93,6 +93,7 @@ struct K3Args {
   void* down_y[2];
   int64_t down_bstride[2];
   int down_ch0[2], down_cout[2], down_relu[2];
+  int tail_g4;     // 1: the full-resolution tails write channel-group-interleaved tensors (RAGMI_TAIL_G4; include/rag_amd.h)
   int w_in_lds;    // 1: the workgroup's weights (all chunks, both sets) are cached in LDS behind the tile
   int y_ch[RAGMI_MAX_GROUPS];    // destination channel base of each output group
   int res_ch[RAGMI_MAX_GROUPS];
@@ -610,6 +611,7 @@ bool c1_eligible(const K3Args& a, int dtype, int y_dtype);
 int c1_launch(const K3Args& k, int dtype, int y_dtype, hipStream_t st);
 int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, bool all, hipStream_t s);
 bool x3_eligible(const K3Args& a, int nset, int dtype);
+int x3_g4_caps(const K3Args& a, int nset, int dtype);      // G4 forms (include/rag_amd.h) the kernel this call lands on takes
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
 // deep-level bf16x3 form (8 / 16 input channels per set, box tiles): levels 6 and 12
 // depth-1 volumes (the Feature Net's 2-D convolutions) on the split-operand form: conv2d_x3.hip

@@ -24,15 +24,31 @@
 
 namespace ragmi {
 
+#ifdef RAGMI_DIAG
+// In-kernel stamps of the z-marching kernel (profiling builds only, RAGMI_X3_DIAG bit 32): per wave the shader cycles (s_memtime) spent in
+// each phase of its plane steps, summed over the launch, plus the wave's first / last s_memtime and s_memrealtime (100 MHz): the clock
+// the chip actually held is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).  The values go to a buffer of
+// their own (ragmi_diag_x3_stamp_buffer) that no kernel reads; nothing is computed from them.
+__device__ unsigned long long* x3_stamp_buf = nullptr;
+constexpr int X3_STAMP_WORDS = 16;
+#define X3_STAMP(k) do { if (dg_stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                                         dg_sum[k] += t_ - dg_last; dg_last = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define X3_STAMP(k) do { } while (0)
+#endif
+
 // NCG = input-channel groups of 4 over all sets, NSET accumulator sets (2: out = act(bnA(convA(x[:, :C]))) + act(bnB(convB(x[:, C:]))),
 // the Cell_3d sibling fusion of conv3d_k3).  Compile-time so that the K loop is fully unrolled (the LDS reads of the next
 // K-slice are in flight under the MFMAs of the current one) and the prefetch registers are static.
 // T = activation storage: float (three MFMAs per product) or bf16_t (the activations ARE bf16: no lo copy, two MFMAs per
 // product — weight hi and lo — and half the LDS operand traffic)
 // TAILS: 0 none, 1 fused consumer 1x1x1 convs at full resolution, 2 also DOWN-SAMPLING ones (see K3Args::ndown and the finishing step)
-template <class T, int NCG, int NSET, int TAILS>
+// G4X: x is a channel-group-interleaved tensor [B][C/4][D][H][W][4] (include/rag_amd.h, "G4"; fp32 storage): the four channels of
+// a halo voxel are ONE 16-byte load.  The tails write G4 destinations when a.tail_g4 says so (one 16-byte store per voxel).
+template <class T, int NCG, int NSET, int TAILS, bool G4X = false>
 __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
+  static_assert(!G4X || !BF, "G4 tensors are fp32");
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
   // LDS row / plane / channel-group strides in records (padded against bank conflicts: conv3d_x3_common.h; staging still enumerates X3_PL voxels)
@@ -64,6 +80,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   const int64_t DHW = (int64_t)HW * a.D;
 #ifdef RAGMI_DIAG
   const bool dg_nostore = (a.relu & 0x100) != 0, dg_nomfma = (a.relu & 0x200) != 0, dg_nocommit = (a.relu & 0x400) != 0, dg_noload = (a.relu & 0x800) != 0, dg_noread = (a.relu & 0x1000) != 0;
+  const bool dg_stamp = (a.relu & 0x2000) != 0 && x3_stamp_buf != nullptr;
+  unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_last = 0, dg_t0 = 0, dg_r0 = 0;
+  unsigned dg_steps = 0;
+  if (dg_stamp) { dg_t0 = dg_last = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
 #else
   constexpr bool dg_nostore = false, dg_nomfma = false, dg_nocommit = false, dg_noload = false, dg_noread = false;
 #endif
@@ -161,22 +181,31 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const bool ok = cg < NCG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
       vmask |= (ok ? 1u : 0u) << p;
       // whole 4-channel groups only (x3_eligible): the group's channels are c * DHW apart, a wave-uniform step.  Cin * DHW < 2^31.
-      voff[p] = (int)(min(cg, NCG - 1) * 4 * DHW) + min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
+      voff[p] = (int)(min(cg, NCG - 1) * 4 * DHW) + (min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1)) * (G4X ? 4 : 1);
     }
   };
   // issue the loads of input plane gz of the located column: unconditional, the plane index clamped into the volume
   auto prefetch = [&](const T* xb, int gz) {
     if (dg_noload) return;
     valid = (unsigned)gz < (unsigned)a.D ? vmask : 0u;
-    const T* const pb = xb + (int64_t)min(max(gz, 0), a.D - 1) * HW;
+    const T* const pb = xb + (int64_t)min(max(gz, 0), a.D - 1) * HW * (G4X ? 4 : 1);
+    if constexpr (G4X) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const T* const pc = pb + c * DHW;            // wave-uniform
+      for (int p = 0; p < NPF; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(pb + voff[p]);
+        pf[p][0] = v.x; pf[p][1] = v.y; pf[p][2] = v.z; pf[p][3] = v.w;
+      }
+    } else {
 #pragma unroll
-      for (int p = 0; p < NPF; ++p) pf[p][c] = ld(pc + voff[p]);
+      for (int c = 0; c < 4; ++c) {
+        const T* const pc = pb + c * DHW;            // wave-uniform
+#pragma unroll
+        for (int p = 0; p < NPF; ++p) pf[p][c] = ld(pc + voff[p]);
+      }
     }
   };
   float mul = 1.f;                       // fp32 storage: the column's operand scale 2^-e (wave-uniform)
+  unsigned cap_bits = 0x7f7fffffu;       // bit pattern of X3_F16_CAP / mul: an element above it does not fit the column's scale
   auto commit = [&](int slot) {          // registers -> ring plane `slot` (16-bit hi / lo halves), zeros outside the volume / past Cin
     if (dg_nocommit) return;
 #pragma unroll
@@ -211,9 +240,22 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // a plane that does not fit the column's scale: record its magnitude; the workgroup restarts its ring behind the next barrier
   // (lmaxp[1], never the word the scale is derived from: lmaxp[0] only changes between the two barriers that open a ring pass, so
   // `mul` and the restart test below are workgroup-uniform by construction)
+  // Fast test first (this runs once per plane step, in a loop bound by vector issue): the largest |bit pattern| of the thread's valid
+  // elements against the pattern of CAP / mul (mul is a power of two: exact) — 8 ands, a max tree and one compare instead of the
+  // ~50 instructions of the filtered maximum.  Only a thread that holds an element above the threshold (an overflow, or an
+  // unscalable element: Inf, NaN, >= 2^115) takes the slow path, which decides exactly as before.
   auto note_overflow = [&]() {
-    const float m = local_max();
-    if (m * mul > X3_F16_CAP) atomicMax(lmaxp + 1, __float_as_uint(m));
+    unsigned mb = 0u;
+#pragma unroll
+    for (int p = 0; p < NPF; ++p) {
+      const unsigned mp = max(max(__float_as_uint(pf[p][0]) & 0x7fffffffu, __float_as_uint(pf[p][1]) & 0x7fffffffu),
+                              max(__float_as_uint(pf[p][2]) & 0x7fffffffu, __float_as_uint(pf[p][3]) & 0x7fffffffu));
+      mb = max(mb, ((valid >> p) & 1u) ? mp : 0u);
+    }
+    if (mb > cap_bits) {
+      const float m = local_max();
+      if (m * mul > X3_F16_CAP) atomicMax(lmaxp + 1, __float_as_uint(m));
+    }
   };
   // this wave's column tiles of a plane: nt = wave * X3_NT + i -> (row y = nt / 2, x half = nt % 2); X3_NT is even, so tile i
   // sits a compile-time distance behind tile 0 (an immediate offset of the LDS read)
@@ -316,6 +358,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         if (lane == 0) atomicMax(lmaxp, __float_as_uint(wm));
         __syncthreads();
         mul = x3_pow2_scale(__uint_as_float(lmaxp[0]), X3_ACT_TARGET);
+        cap_bits = __float_as_uint(X3_F16_CAP / mul);      // (mul in [2^-101, 2^99]: finite)
         if (tid < 32) par[tid] = par[96 + tid] * (1.f / mul);       // the epilogue's scale undoes the column's 2^-e
         commit(zfirst % 3);
         prefetch(xb, zfirst - 1); note_overflow(); commit((zfirst - 1 + 3) % 3);
@@ -327,11 +370,15 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       }
       bool again = false;
     for (int z = zfirst; z < ze; ++z) {
+      X3_STAMP(6);                                     // (profiling builds: everything outside the plane steps — ring start, item decode)
       __syncthreads();                                 // plane z-2 (same ring slot as z+1) is no longer read
+      X3_STAMP(0);
       if constexpr (TAILS == 2) { if (z > zs && !(z & 1)) down_finish(z - 1, b, y0, x0); }     // planes z-2, z-1 are complete (segments start even)
       if constexpr (!BF) note_overflow();
       commit((z + 1) % 3);
+      X3_STAMP(1);
       __syncthreads();
+      X3_STAMP(2);
       if constexpr (!BF) {
         // (workgroup-uniform.  No restart once the scale sits at its floor: an Inf — or an operand above ~2^110 — can never be made
         // to fit, and restarting for it would never end; such inputs give non-finite outputs, as include/rag_amd.h says)
@@ -341,6 +388,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       // MFMA block, a branch here made the compiler drain them (s_waitcnt vmcnt(0)) before the first LDS read
       prefetch(xb, z + 2);
       __builtin_amdgcn_sched_barrier(0);               // ...and the scheduler must not sink them below the MFMAs either
+      X3_STAMP(3);
       f32x4 acc[NSET][X3_NT];
 #pragma unroll
       for (int st = 0; st < NSET; ++st)
@@ -379,6 +427,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 #pragma unroll
         for (int i = 0; i < X3_NT; ++i) acc[st][i] = x3_mma<BF>(al, bh[i], acc[st][i]);
       }
+      X3_STAMP(4);
       // epilogue: lane holds channels 4 g + reg (g = cog*4 + kb) of voxel n of each column tile
 #pragma unroll
       for (int i = 0; i < X3_NT; ++i) {
@@ -415,13 +464,21 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
             const int tch0 = tsel ? a.tail_ch0[1] : a.tail_ch0[0], trelu = tsel ? a.tail_relu[1] : a.tail_relu[0];
             const float4 tsc = *reinterpret_cast<const float4*>(par + 64 + 4 * kb), tsh = *reinterpret_cast<const float4*>(par + 80 + 4 * kb);
             const float sc4[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, sh4[4] = {tsh.x, tsh.y, tsh.z, tsh.w};
-            T* pt = my_tail + b * tb + (int64_t)tch0 * DHW + vox;
+            if (!BF && a.tail_g4) {      // G4 destination (four output channels: fill_tails): one 16-byte store per voxel
+              float u4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (r < my_tail_cout) {
-                float u = fmaf(tacc[r], sc4[r], sh4[r]);
-                st(pt + r * DHW, trelu ? fmaxf(u, 0.f) : u);
-              }
+              for (int r = 0; r < 4; ++r) { const float u = fmaf(tacc[r], sc4[r], sh4[r]); u4[r] = trelu ? fmaxf(u, 0.f) : u; }
+              if constexpr (!BF)
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(my_tail) + b * tb + ((int64_t)(tch0 >> 2) * DHW + vox) * 4) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+            } else {
+              T* pt = my_tail + b * tb + (int64_t)tch0 * DHW + vox;
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (r < my_tail_cout) {
+                  float u = fmaf(tacc[r], sc4[r], sh4[r]);
+                  st(pt + r * DHW, trelu ? fmaxf(u, 0.f) : u);
+                }
+            }
           }
           if constexpr (TAILS == 2) {
             // down-sampling tail, first half: blend the raw tail values of the source pair (x = 2X, 2X+1: this lane and the next)
@@ -443,6 +500,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           }
         }
       }
+      X3_STAMP(5);
+#ifdef RAGMI_DIAG
+      ++dg_steps;
+#endif
     }
       if (!again) break;
     }
@@ -451,6 +512,18 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       down_finish(ze - 1, b, y0, x0);
     }
   }
+#ifdef RAGMI_DIAG
+  if (dg_stamp) {
+    X3_STAMP(6);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* const o = x3_stamp_buf + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * X3_WAVES + wave) * X3_STAMP_WORDS;
+      for (int k = 0; k < 7; ++k) o[k] = dg_sum[k];
+      o[7] = dg_steps; o[8] = dg_t0; o[9] = t1; o[10] = dg_r0; o[11] = r1;
+      o[12] = __builtin_amdgcn_s_getreg((4 << 11) | 20);      // HW_REG_XCC_ID (speed diagnostics only)
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -844,15 +917,28 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
   return true;
 }
 
-template <class T, int NCG, int NSET, int TAILS>
+// which G4 forms (include/rag_amd.h) the kernel this call lands on takes: bit 0 a G4 input, bit 1 G4 full-resolution tails
+int x3_g4_caps(const K3Args& a, int nset, int dtype) {
+  if (dtype != RAGMI_F32X3 || x2d_eligible(a, nset, dtype) || x3d_eligible(a, nset, dtype) || !x3_eligible(a, nset, dtype)) return 0;
+#ifndef RAGMI_NO_X3Q
+  if (xq_takes(a, nset, dtype)) return 3;
+#endif
+  const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
+  return (a.Cout <= 16 ? 2 : 0) | ((nset == 1 && ncg == 3 && a.ndown == 0) ? 1 : 0);
+}
+
+template <class T, int NCG, int NSET, int TAILS, bool G4X = false>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
+  if constexpr (!G4X && std::is_same<T, float>::value && NCG == 3 && NSET == 1 && TAILS < 2) {
+    if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, true>(a, e, grid, lds, st);      // stem3d1 on a G4 input
+  }
   static LaunchState state;     // per device, mutex-guarded (common.h)
   // persistent grid = the workgroups the chip holds at once (occupancy x CUs): measured on the level-3 launches (1664 work items)
   // with both on one box: 512 workgroups 1.219 ms per step, 1024 1.226, 768 1.296, 1536 1.250
-  const int slots = state.slots((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS>, X3_THREADS, lds, 160 * 1024);
+  const int slots = state.slots((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS, G4X>, X3_THREADS, lds, 160 * 1024);
   if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
   grid.x = (unsigned)std::max<int64_t>(1, std::min<int64_t>(grid.x, std::max(256, slots) / (int)grid.y));
-  hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET, TAILS>), grid, dim3(X3_THREADS), lds, st, a, e);
+  hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET, TAILS, G4X>), grid, dim3(X3_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3");
 }
 template <class T, int NCG, int NSET>
@@ -868,10 +954,18 @@ static int x3_launch_one(const K3Args& a, const X3Extra& e, dim3 grid, size_t ld
   return e.bf16 ? x3_launch_typed<bf16_t, NCG, NSET>(a, e, grid, lds, st) : x3_launch_typed<float, NCG, NSET>(a, e, grid, lds, st);
 }
 
+#ifdef RAGMI_DIAG
+// profiling builds: where the stamps of the next z-marching launches go (X3_STAMP_WORDS 64-bit words per wave, grid x 8 waves); null = off
+extern "C" __attribute__((visibility("default"))) int ragmi_diag_x3_stamp_buffer(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(x3_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // a: as filled for the fp32 kernel (wp[s] = packed weights: fp32-MFMA section followed by the bf16x3 fragments)
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
 #ifdef RAGMI_DIAG
-  static const int diag_x3 = [] { const char* v = getenv("RAGMI_X3_DIAG"); return v ? atoi(v) : 0; }();   // 1 no stores, 2 no MFMA block, 4 no commit, 8 no loads, 16 operand reads at one address
+  static const int diag_x3 = [] { const char* v = getenv("RAGMI_X3_DIAG"); return v ? atoi(v) : 0; }();   // 1 no stores, 2 no MFMA block, 4 no commit, 8 no loads, 16 operand reads at one address, 32 in-kernel stamps
   a.relu |= diag_x3 << 8;
 #endif
   X3Extra e{};
@@ -919,6 +1013,9 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
                      (a.ndown > 0 ? (size_t)(2 * 2 * 4 * X3_TY * (X3_TX / 2)) * sizeof(float) + (size_t)(X3_TX / 2 + X3_TY / 2) * sizeof(float4) : 0);
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
   const dim3 grid((unsigned)std::min<int64_t>(nwork, 1 << 20), ncog);      // x is cut to the resident slots where the kernel is known
+#ifndef RAGMI_NO_X3Q
+  if (xq_takes(a, nset, dtype)) return xq_launch(a, e, nset, grid, st);     // one 4-channel group per set, fp32 storage: conv3d_x3q.hip
+#endif
   if (nset == 2) {
     switch (ncg) {
       case 2: return x3_launch_one<2, 2>(a, e, grid, lds, st);

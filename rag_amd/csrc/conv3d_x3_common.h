@@ -198,6 +198,10 @@ inline void x3_weight_sections(X3Extra& e, const K3Args& a, int nset, int dtype)
 }
 
 
+// conv3d_x3q.hip: the level-3 dual-cell form (four-slot ring, one barrier per plane step, immediate operand addresses)
+bool xq_takes(const K3Args& a, int nset, int dtype);
+int xq_launch(const K3Args& a, const X3Extra& e, int nset, dim3 grid, hipStream_t st);
+
 // (the plane-stationary form measured in rounds 2-3 and not shipped is in the history: git show e045bcd:tools/experiments/conv3d_x3p.hip;
 // its numbers are profiles/r03_x3p_investigation.md)
 

@@ -416,27 +416,49 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
         const float wb = ws[ob + co * sb];
         float s = (hb ? wb : 0.f) + av[co];                        // A + B; an absent plane's (unconditional) load is discarded
         s = fmaf(s, par[co], par[CS_MAXC + co]);
-        v[co] = a.relu ? fmaxf(s, 0.f) : s;
+        v[co] = (a.relu & 1) ? fmaxf(s, 0.f) : s;
       } else {
         v[co] = 0.f;
       }
     }
     const int64_t vox = (int64_t)i * HW + pix;
-    T* py = static_cast<T*>(a.y) + b * a.y_bstride + vox;
+    // G4 destinations (include/rag_amd.h: [B][C/4][D][H][W][4], fp32; the host checks Cout % 4 == 0 and 4-channel tails): a thread
+    // owns every channel of its voxel, so a group is ONE 16-byte store (a wave: 1 KB contiguous) instead of four 4-byte stores into
+    // four planes
+    if constexpr (std::is_same<T, float>::value && NC > 0) {
+      if (a.relu & RAGMI_CONV_Y_G4) {
+        float* const py4 = static_cast<float*>(a.y) + b * a.y_bstride + vox * 4;
 #pragma unroll
-    for (int co = 0; co < MC; ++co)
-      if (co < Cout) st(py + co * DHW, v[co]);
+        for (int g = 0; g < MC / 4; ++g)
+          *reinterpret_cast<float4*>(py4 + g * DHW * 4) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+      } else {
+        T* py = static_cast<T*>(a.y) + b * a.y_bstride + vox;
+#pragma unroll
+        for (int co = 0; co < MC; ++co) st(py + co * DHW, v[co]);
+      }
+    } else {
+      T* py = static_cast<T*>(a.y) + b * a.y_bstride + vox;
+#pragma unroll
+      for (int co = 0; co < MC; ++co)
+        if (co < Cout) st(py + co * DHW, v[co]);
+    }
     for (int tl = 0; tl < a.ntail; ++tl) {
       const float* p = par + 2 * CS_MAXC + tl * (4 * CS_MAXC + 8);
       const ragmi_tail_t& td = a.tail[tl];
       T* pt = static_cast<T*>(td.y) + b * td.y_bstride + (int64_t)td.y_ch0 * DHW + vox;
+      float u4[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool g4 = std::is_same<T, float>::value && (td.relu & RAGMI_TAIL_G4) != 0;
       for (int k = 0; k < td.cout; ++k) {
         float s = 0.f;
 #pragma unroll
         for (int co = 0; co < MC; ++co)
           if (co < Cout) s = fmaf(p[k * Cout + co], v[co], s);
         s = fmaf(s, p[4 * CS_MAXC + k], p[4 * CS_MAXC + 4 + k]);
-        st(pt + k * DHW, td.relu ? fmaxf(s, 0.f) : s);
+        s = (td.relu & 1) ? fmaxf(s, 0.f) : s;
+        if (g4) u4[k & 3] = s; else st(pt + k * DHW, s);
+      }
+      if constexpr (std::is_same<T, float>::value) {
+        if (g4) *reinterpret_cast<float4*>(static_cast<float*>(td.y) + b * td.y_bstride + ((int64_t)(td.y_ch0 >> 2) * DHW + vox) * 4) = make_float4(u4[0], u4[1], u4[2], u4[3]);
       }
     }
   }
@@ -575,8 +597,13 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
   for (int t = 0; t < ntail; ++t) {
     RAGMI_REQUIRE(tails[t].weight && tails[t].y && tails[t].cout >= 1 && tails[t].cout <= 4, RAGMI_EINVAL,
                   "costvol_stem: tail %d needs weight, y and 1..4 output channels", t);
+    RAGMI_REQUIRE(!(tails[t].relu & 2), RAGMI_EUNSUPPORTED, "costvol_stem: down-sampling tails are not built here");
+    RAGMI_REQUIRE(!(tails[t].relu & RAGMI_TAIL_G4) || (dtype == RAGMI_F32 && tails[t].cout == 4 && tails[t].y_ch0 % 4 == 0), RAGMI_EUNSUPPORTED,
+                  "costvol_stem: a G4 tail needs fp32 storage, 4 output channels and a group-aligned y_ch0");
     ca.tail[t] = tails[t];
   }
+  RAGMI_REQUIRE(!(relu & RAGMI_CONV_Y_G4) || (dtype == RAGMI_F32 && (Cout == 4 || Cout == 8 || Cout == 12 || Cout == 16)), RAGMI_EUNSUPPORTED,
+                "costvol_stem: a G4 output needs fp32 storage and Cout in {4, 8, 12, 16}");
   int ni = CB_NI;
 #ifdef RAGMI_DIAG
   static const int diag_ni = [] { const char* v = getenv("RAGMI_CB_NI"); return v ? atoi(v) : 0; }();

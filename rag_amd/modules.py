@@ -21,6 +21,7 @@ from collections import namedtuple
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -161,18 +162,19 @@ class _ConvBR(nn.Module):
             self._cv_cache = hit
         return hit[1]
 
-    def forward_costvol(self, left_fea, right_fea, maxdisp, tails=None) -> torch.Tensor:
+    def forward_costvol(self, left_fea, right_fea, maxdisp, tails=None, out_g4: bool = False) -> torch.Tensor:
         """act(bn(conv(cost_volume(left_fea, right_fea)))) without materialising the cost volume (inference)."""
         _wk, scale, shift = self.prepared()
         return ops.costvol_stem(left_fea, right_fea, maxdisp, self.costvol_variants(), self.conv.out_channels, scale, shift,
-                                self.relu, tails=tails)
+                                self.relu, tails=tails, out_g4=out_g4)
 
-    def as_tail(self, out: torch.Tensor, out_ch0: int) -> "ops.Tail":
-        """This 1x1(x1) ConvBR (<= 4 output channels) as a tail of the kernel that produces its input."""
+    def as_tail(self, out: torch.Tensor, out_ch0: int, g4: bool = False) -> "ops.Tail":
+        """This 1x1(x1) ConvBR (<= 4 output channels) as a tail of the kernel that produces its input (g4: `out` is a
+        channel-group-interleaved buffer, ops.Tail)."""
         if self._geometry() != 1 or self.conv.out_channels > 4:
             raise ValueError("only 1x1x1 ConvBR with <= 4 output channels can be fused as a tail")
         wk, scale, shift = self.prepared()
-        return ops.Tail(wk, scale, shift, self.relu, out, out_ch0)
+        return ops.Tail(wk, scale, shift, self.relu, out, out_ch0, g4=g4)
 
     def as_down_tails(self, out: torch.Tensor, out_ch0: int) -> List["ops.Tail"]:
         """This 1x1x1 ConvBR (<= 8 output channels) applied to the x0.5 trilinear down-sampling of the producer's output, as one or
@@ -189,8 +191,9 @@ class _ConvBR(nn.Module):
 
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_ch0: int = 0,
                 resample_to: Optional[Sequence[int]] = None, tails: Optional[Sequence["ops.Tail"]] = None,
-                store_main: bool = True, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """`out`/`out_ch0` write into a channel slice of a wider buffer.  `resample_to` (1x1x1 only) first resamples x
+                store_main: bool = True, out_dtype: Optional[torch.dtype] = None, x_g4: bool = False) -> torch.Tensor:
+        """`out`/`out_ch0` write into a channel slice of a wider buffer.  `x_g4` (3x3x3 form of the fused executor only): x is a
+        channel-group-interleaved buffer (ops.conv3d_k3).  `resample_to` (1x1x1 only) first resamples x
         trilinearly (align_corners=True) to that size inside the same kernel — the reference's
         `conv(F.interpolate(x, size, mode='trilinear', align_corners=True))`.  The 2-D flavour accepts [B,C,H,W] (or an
         already depth-1 5-D view) and returns the same rank.  `out_dtype=torch.float32` (Cout <= 2 form only) keeps the result
@@ -202,6 +205,8 @@ class _ConvBR(nn.Module):
         k = self._geometry()
         wk, scale, shift = self.prepared()
         cout = self.conv.out_channels
+        if x_g4 and (k != 3 or self._small() or resample_to is not None or x.dim() != 5):
+            raise RuntimeError("rag_amd ConvBR: a G4 input is taken by the 3x3x3 form only")
         if k == -3:
             return ops.conv2d_k3_strided(x if x.dim() == 4 else x[:, :, 0], wk, scale, shift, self.relu, self.conv.stride[0])
         squeeze = x.dim() == 4
@@ -230,7 +235,7 @@ class _ConvBR(nn.Module):
             ops.conv3d_k3_small(x, wk, scale, shift, self.relu, out, out_ch0)
         elif k == 3:
             groups = [out_ch0 + 4 * g for g in range(ops.packed_groups(cout))]
-            ops.conv3d_k3(x, wk, cout, scale, shift, self.relu, out, groups, tails=tails, store_main=store_main)
+            ops.conv3d_k3(x, wk, cout, scale, shift, self.relu, out, groups, tails=tails, store_main=store_main, x_g4=x_g4)
         else:
             ops.conv3d_k1(x, wk, scale, shift, self.relu, out, out_ch0)
         return out[:, :, 0] if squeeze else out
@@ -455,8 +460,19 @@ class _Cell(nn.Module):
             return tuple(int(v) for v in prev_size)
         return tuple(self.scale_dimension(int(v), self.scale) for v in prev_size)
 
+    def dual_plan(self, s0_channels: int, s0_from_tail: bool = True) -> bool:
+        """True when ONE dual launch produces every new state of this cell (what `_run` calls single_dual): both inputs feed conv
+        branches into all of them and nothing else does — a property of the genotype (and of whether s0 goes through pre_preprocess)."""
+        C = self.C_out
+        contribs = self._contributions()
+        conv_from = {j: [(k, op) for k, lst in contribs.items() for (src, op) in lst if src == j and isinstance(op, _ConvBR)] for j in (0, 1)}
+        return (bool(conv_from[0]) and (s0_from_tail or s0_channels != C) and [k for k, _ in conv_from[0]] == [k for k, _ in conv_from[1]]
+                and all(len(contribs[k]) == 2 for k, _ in conv_from[0]) and len(conv_from[0]) == self._steps
+                and self.block_multiplier == self._steps)
+
     def _run(self, prev_prev_input, prev_input, pre: Optional[torch.Tensor] = None, pre_has=(False, False),
-             tails: Optional[Sequence["ops.Tail"]] = None, store_main: bool = True, size: Optional[Sequence[int]] = None):
+             tails: Optional[Sequence["ops.Tail"]] = None, store_main: bool = True, size: Optional[Sequence[int]] = None,
+             pre_g4: bool = False):
         """forward() plus the cross-cell fusion hooks used by MatchingNet.matching:
         `pre`/`pre_has`: the [B, 2C, ...] buffer in which the producers of the inputs have already written s0 (ch 0..C)
         and/or s1 (ch C..2C) as fused tails; `tails`/`store_main`: consumer 1x1x1 convs to compute in THIS cell's final
@@ -490,6 +506,8 @@ class _Cell(nn.Module):
                 ops.cell2d(s0, self.pre_preprocess.prepared() + (self.pre_preprocess.relu,), s1,
                            self.preprocess.prepared() + (self.preprocess.relu,), C, pa, sa, ha, pb, sb, hb, C * self._steps, True, cat, groups)
                 return cat, False
+        if pre_g4 and not (pre is not None and pre_has[0] and pre_has[1]):
+            raise RuntimeError("rag_amd.Cell_3d: a G4 input buffer must arrive complete from its producers' fused tails")
         if pre is None:
             B, dev = s1.shape[0], s1.device
             pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=s1.dtype)
@@ -573,12 +591,14 @@ class _Cell(nn.Module):
             groups = [where[k][1] + 4 * g for k, _op in conv_from[0] for g in range(C // 4)]
             ops.conv3d_k3_dual(pre, C, pa, sa, ha, pb, sb, hb, C * len(conv_from[0]), True,
                                where[conv_from[0][0][0]][0], groups,
-                               tails=tails if use_tails else None, store_main=not drop_main)
+                               tails=tails if use_tails else None, store_main=not drop_main, x_g4=pre_g4)
             tails_applied = use_tails
             for j in (0, 1):
                 for k, op in conv_from[j]:
                     written[k] = True
                     done.add((j, id(op)))
+        elif pre_g4:
+            raise RuntimeError("rag_amd.Cell_3d: a G4 input buffer was planned for a cell that does not run as one dual launch")
 
         for j in range(n_states):
             if j >= 2:
@@ -779,7 +799,7 @@ class MatchingNet(nn.Module):
             j = i + 2
             # (the cell between producer and consumer keeps the size: for j == 0 that "cell" is stem3d1 — same size by construction —
             # not cells[-1], the LAST cell)
-            mid_same = j - 1 < 0 or cells[j - 1].downup_sample == 0
+            mid_same = j - 1 < 0 or (j - 1 < n and cells[j - 1].downup_sample == 0)
             if (0 <= j < n and cells[j].downup_sample == 0 and mid_same and cells[j].C_out <= 4
                     and cells[j].C_out % 4 == 0 and cells[j].C_prev_prev != cells[j].C_out):
                 out.append((j, 0, False))
@@ -794,6 +814,55 @@ class MatchingNet(nn.Module):
         pre: Dict[int, torch.Tensor] = {}
         has: Dict[int, List[bool]] = {}
 
+        # --- G4 plan (round 5): which of the private level-3 tensors are stored channel-group-interleaved ([B][C/4][D][H][W][4],
+        # include/rag_amd.h) instead of as channel planes.  pre[j] (cell j's s0|s1 buffer) can be G4 when cell j runs as ONE dual launch
+        # on the kernel that reads G4 (ops.conv3d_k3_g4_caps bit 0) and BOTH halves arrive as full-resolution fused tails from producers
+        # that can write G4 (bit 1; stem3d0 folded with the cost volume always can).  The full-resolution tails of one producer launch
+        # share a layout, so candidates are withdrawn until every producer is consistent.  T[-2] (stem3d0 -> stem3d1) can be G4 when
+        # nothing but stem3d1 and fused tails reads it.  Everything else, and every module boundary, stays channel planes.
+        def n_tails(i):
+            """(full-resolution, down-sampling) tail counts of T[i]'s producer launch"""
+            f = fusable(i)
+            return (sum(1 for (_j, _r, d) in f if not d), sum((cells[j].C_out + 3) // 4 for (j, _r, d) in f if d))
+
+        def out_channels(i):
+            return (stem0 if i == -2 else stem1).conv.out_channels if i < 0 else cells[i].block_multiplier * cells[i].C_out
+
+        def writes_g4(i):
+            """T[i]'s producer applies its fused tails and can write them G4"""
+            nt, nd = n_tails(i)
+            if i == -2:
+                return x is None or bool(ops.conv3d_k3_g4_caps(stem0.conv.in_channels, out_channels(-2), B, *vol, nset=1, ntail=nt, dtype=adt) & 2)
+            if i == -1:
+                return bool(ops.conv3d_k3_g4_caps(out_channels(-2), out_channels(-1), B, *vol, nset=1, ntail=nt, dtype=adt) & 2)
+            c = cells[i]
+            return (c.dual_plan(out_channels(i - 2)) and c.C_out * c._steps <= 16
+                    and bool(ops.conv3d_k3_g4_caps(2 * c.C_out, c.C_out * c._steps, B, *sizes[i], nset=2, ntail=nt, ndown=nd, dtype=adt) & 2))
+
+        g4: Dict[int, bool] = {}
+        g4_ok = adt == torch.float32 and ops.get_conv_precision() == "f16x3" and ops.g4_enabled()
+        for j in range(n):
+            c = cells[j]
+            nt, nd = n_tails(j)
+            g4[j] = (g4_ok and (j, 1, False) in fusable(j - 1) and (j, 0, False) in fusable(j - 2) and c.dual_plan(out_channels(j - 2))
+                     and bool(ops.conv3d_k3_g4_caps(2 * c.C_out, c.C_out * c._steps, B, *sizes[j], nset=2, ntail=nt if c.C_out * c._steps <= 16 else 0,
+                                                    ndown=nd if c.C_out * c._steps <= 16 else 0, dtype=adt) & 1)
+                     and writes_g4(j - 1) and writes_g4(j - 2))
+        changed = True
+        while changed:          # one layout per producer launch
+            changed = False
+            for i in range(-2, n):
+                js = [j for (j, _r, d) in fusable(i) if not d]
+                if len({g4[j] for j in js}) > 1:
+                    for j in js:
+                        g4[j] = False
+                    changed = True
+        # stem3d0's own output: read by stem3d1 (3x3x3) and by cell 0's fused pre_preprocess tail only
+        t2_g4 = (g4_ok and x is None and n >= 1 and (0, 0, False) in fusable(-2)
+                 and bool(ops.conv3d_k3_g4_caps(out_channels(-2), out_channels(-1), B, *vol, nset=1, ntail=n_tails(-1)[0], dtype=adt) & 1))
+
+        self.last_g4_plan = {"pre": dict(g4), "stem0_out": bool(t2_g4)}      # (what the tests and tools read)
+
         def tails_for(i):
             """[(consumer cell j, role, [Tail, ...])]: one full-resolution tail, or the one / two down-sampling tails of a consumer
             that works one level down"""
@@ -804,7 +873,7 @@ class MatchingNet(nn.Module):
                     has[j] = [False, False]
                 mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
                 ch0 = cells[j].C_out if role == 1 else 0
-                specs.append((j, role, mod.as_down_tails(pre[j], ch0) if down else [mod.as_tail(pre[j], ch0)]))
+                specs.append((j, role, mod.as_down_tails(pre[j], ch0) if down else [mod.as_tail(pre[j], ch0, g4=g4[j])]))
             return specs
 
         def flat(specs):
@@ -814,6 +883,8 @@ class MatchingNet(nn.Module):
             """mark fused consumers as done, or run them as plain 1x1x1 launches if the producer could not fuse them"""
             for (j, role, ts) in specs:
                 if not applied:
+                    if g4[j]:
+                        raise RuntimeError("rag_amd.MatchingNet: a producer planned to write a G4 tail did not apply its tails")
                     mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
                     mod(tensor, out=pre[j], out_ch0=ts[0].out_ch0, resample_to=sizes[j] if ts[0].down else None)
                 has[j][role] = True
@@ -822,14 +893,14 @@ class MatchingNet(nn.Module):
         # stem3d0: its output also feeds stem3d1 (3x3x3), so it is always materialised
         specs = tails_for(-2)
         if x is None:
-            T[-2] = stem0.forward_costvol(features[0], features[1], self.maxdisp, tails=flat(specs))
+            T[-2] = stem0.forward_costvol(features[0], features[1], self.maxdisp, tails=flat(specs), out_g4=t2_g4)
         else:
             T[-2] = stem0(x, tails=flat(specs))
         settle(-2, specs, True, T[-2])
         # stem3d1
         specs = tails_for(-1)
         need_main = len(specs) < len(all_consumers(-1)) or n == 0
-        out1 = stem1(T[-2], tails=flat(specs), store_main=need_main or not specs)
+        out1 = stem1(T[-2], tails=flat(specs), store_main=need_main or not specs, x_g4=t2_g4)
         T[-1] = out1 if (need_main or not specs) else None
         settle(-1, specs, True, out1)
         def shared_pre(i):
@@ -860,7 +931,7 @@ class MatchingNet(nn.Module):
             specs = tails_for(i)
             need_main = i == n - 1 or len(specs) < len(all_consumers(i))   # the head reads the last cell's output
             cat, applied = c._run(T[i - 2], T[i - 1], pre=pre.get(i), pre_has=tuple(has.get(i, (False, False))),
-                                  tails=flat(specs), store_main=need_main, size=sizes[i])
+                                  tails=flat(specs), store_main=need_main, size=sizes[i], pre_g4=g4[i])
             settle(i, specs, applied, cat)
             T[i] = cat
             T.pop(i - 2, None)

@@ -112,14 +112,55 @@ def _i32_array(vals: Optional[Sequence[int]]):
     return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
 
 
+# bits of the `relu` argument / of ragmi_tail_t.relu (include/rag_amd.h): channel-group-interleaved ("G4") tensors
+CONV_X_G4, CONV_Y_G4, TAIL_G4 = 2, 4, 4
+_G4 = [os.environ.get("RAGMI_G4", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling); set_g4 chooses afterwards
+
+
+def set_g4(enabled: bool) -> None:
+    """Whether the fused executor (MatchingNet._run_chain) may keep its private level-3 tensors channel-group-interleaved."""
+    _G4[0] = bool(enabled)
+
+
+def g4_enabled() -> bool:
+    return _G4[0]
+
+
+
+def to_g4(t: torch.Tensor) -> torch.Tensor:
+    """[B, C, D, H, W] channel planes -> the same logical tensor stored group-interleaved [B][C/4][D][H][W][4], returned with the
+    plane tensor's SHAPE (a contiguous buffer the G4-aware kernels read; tests and tools only)."""
+    B, C = t.shape[:2]
+    sp = tuple(t.shape[2:])
+    perm = (0, 1) + tuple(range(3, 3 + len(sp))) + (2,)
+    return t.reshape((B, C // 4, 4) + sp).permute(perm).contiguous().view(t.shape)
+
+
+def from_g4(t: torch.Tensor) -> torch.Tensor:
+    """inverse of to_g4"""
+    B, C = t.shape[:2]
+    sp = tuple(t.shape[2:])
+    n = len(sp)
+    perm = (0, 1, 2 + n) + tuple(range(2, 2 + n))
+    return t.reshape((B, C // 4) + sp + (4,)).permute(perm).contiguous().view(t.shape)
+
+
+def conv3d_k3_g4_caps(cin: int, cout: int, B: int, D: int, H: int, W: int, nset: int = 1, ntail: int = 0, ndown: int = 0,
+                      dtype: torch.dtype = torch.float32) -> int:
+    """bit 0: this conv3d_k3 / conv3d_k3_dual call accepts a G4 input; bit 1: it can write G4 full-resolution tails (current precision)"""
+    return int(load_library().ragmi_conv3d_k3_g4_caps(cin, cout, B, D, H, W, nset, ntail, ndown, _conv_dt(_DT[dtype])))
+
+
 class Tail:
     """A consumer 1x1x1 ConvBR_3d to be computed in the producing 3x3x3 kernel's epilogue:
     out[:, ch0:ch0+cout] = act(bn(weight2d @ producer_output)) (weight2d [cout <= 4, C_producer])."""
 
     def __init__(self, weight2d: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool,
-                 out: torch.Tensor, out_ch0: int, down: bool = False):
+                 out: torch.Tensor, out_ch0: int, down: bool = False, g4: bool = False):
         """down=True: a DOWN-SAMPLING tail — `out` is at half the producer's resolution and receives
-        act(bn(F.interpolate(weight2d @ producer_output, half size, 'trilinear', align_corners=True))) (ragmi_tail_t.relu bit 1)."""
+        act(bn(F.interpolate(weight2d @ producer_output, half size, 'trilinear', align_corners=True))) (ragmi_tail_t.relu bit 1).
+        g4=True: `out` (fp32, contiguous) is read by its consumer as a channel-group-interleaved tensor [B][C/4][D][H][W][4]
+        (RAGMI_TAIL_G4, include/rag_amd.h): this tail writes group out_ch0 / 4 of it (4 output channels, out_ch0 % 4 == 0)."""
         _need_gpu(weight2d, scale, shift)
         _act(out)
         for t in (weight2d, scale, shift):
@@ -127,10 +168,13 @@ class Tail:
                 raise ValueError("Tail: weight / scale / shift must be contiguous (row slices of contiguous tensors are)")
         self.weight2d, self.scale, self.shift, self.relu, self.out, self.out_ch0 = weight2d, scale, shift, relu, out, out_ch0
         self.down = bool(down)
+        self.g4 = bool(g4)
+        if self.g4 and (self.down or weight2d.shape[0] != 4 or out_ch0 % 4 or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise ValueError("Tail: a G4 destination takes a full-resolution tail of 4 channels at a group-aligned channel of a contiguous fp32 tensor")
 
     def spec(self) -> TailSpec:
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        return TailSpec(p(self.weight2d), p(self.scale), p(self.shift), int(self.relu) | (2 if self.down else 0), self.out.data_ptr(),
+        return TailSpec(p(self.weight2d), p(self.scale), p(self.shift), int(self.relu) | (2 if self.down else 0) | (TAIL_G4 if self.g4 else 0), self.out.data_ptr(),
                         _planes(self.out), int(self.out_ch0), int(self.weight2d.shape[0]))
 
 
@@ -173,8 +217,9 @@ def costvol_stem_prepare(weight: torch.Tensor) -> torch.Tensor:
 
 def costvol_stem(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, variants: torch.Tensor, cout: int,
                  scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool, out: Optional[torch.Tensor] = None,
-                 tails: Optional[Sequence[Tail]] = None) -> torch.Tensor:
-    """act(bn(conv3x3x3(cost_volume(left_fea, right_fea)))) without building the cost volume: ragmi_costvol_stem_fwd."""
+                 tails: Optional[Sequence[Tail]] = None, out_g4: bool = False) -> torch.Tensor:
+    """act(bn(conv3x3x3(cost_volume(left_fea, right_fea)))) without building the cost volume: ragmi_costvol_stem_fwd.
+    out_g4: `out` is written channel-group-interleaved (RAGMI_CONV_Y_G4)."""
     _need_gpu(variants, scale, shift)
     dt = _act(left_fea, right_fea, out, *[t.out for t in (tails or [])])
     if left_fea.shape != right_fea.shape or left_fea.dim() != 4:
@@ -190,7 +235,9 @@ def costvol_stem(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, 
     ws = torch.empty((lib.ragmi_costvol_stem_workspace_elems(B, C, cout, d, h, w),), device=left_fea.device, dtype=torch.float32)
     ntail, tarr = _tail_array(tails)
     p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    check(lib.ragmi_costvol_stem_fwd(left_fea.data_ptr(), right_fea.data_ptr(), variants.data_ptr(), p(scale), p(shift), int(relu),
+    if out_g4 and (not out.is_contiguous() or out.shape[1] != cout):
+        raise ValueError("costvol_stem: a G4 output is a contiguous [B, Cout, ...] buffer")
+    check(lib.ragmi_costvol_stem_fwd(left_fea.data_ptr(), right_fea.data_ptr(), variants.data_ptr(), p(scale), p(shift), int(relu) | (CONV_Y_G4 if out_g4 else 0),
                                      out.data_ptr(), _planes(out), ws.data_ptr(), B, C, cout, d, h, w, ntail, tarr, _conv_dt(dt), _stream()),
           "costvol_stem")
     return out
@@ -238,10 +285,12 @@ def packed_groups(cout: int) -> int:
 def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
               relu: bool, out: torch.Tensor, out_group_ch: Optional[Sequence[int]] = None,
               res: Optional[torch.Tensor] = None, res_group_ch: Optional[Sequence[int]] = None,
-              tails: Optional[Sequence[Tail]] = None, store_main: bool = True) -> torch.Tensor:
+              tails: Optional[Sequence[Tail]] = None, store_main: bool = True, x_g4: bool = False) -> torch.Tensor:
     """Fused 3x3x3 ConvBR_3d (+ running sum / concat): see ragmi_conv3d_k3_fwd in include/rag_amd.h.
     `out` (and `res`) are [B, C*, D, H, W] buffers; group g of 4 output channels lands at channel
-    out_group_ch[g] (default 4g)."""
+    out_group_ch[g] (default 4g).  x_g4: x is stored channel-group-interleaved (RAGMI_CONV_X_G4)."""
+    if x_g4 and not x.is_contiguous():
+        raise ValueError("conv3d_k3: a G4 input is a contiguous buffer")
     _need_gpu(packed, scale, shift)
     dt = _act(x, out, res, *[t.out for t in (tails or [])])
     B, Cin, D, H, W = x.shape
@@ -261,7 +310,7 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
     ntail, tarr = _tail_array(tails)
     check(load_library().ragmi_conv3d_k3_fwd_ex(
         x.data_ptr(), xb, packed.data_ptr(),
-        scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu),
+        scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None, int(relu) | (CONV_X_G4 if x_g4 else 0),
         out.data_ptr(), yb, _i32_array(out_group_ch),
         res.data_ptr() if res is not None else None, rb, _i32_array(res_group_ch),
         B, Cin, cout, D, H, W, int(store_main), ntail, tarr, _conv_dt(dt), _stream()), "conv3d_k3")
@@ -293,9 +342,11 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
                    packed_b: torch.Tensor, scale_b, shift_b, cout: int, relu: bool, out: torch.Tensor,
                    out_group_ch: Optional[Sequence[int]] = None, res: Optional[torch.Tensor] = None,
                    res_group_ch: Optional[Sequence[int]] = None, tails: Optional[Sequence[Tail]] = None,
-                   store_main: bool = True) -> torch.Tensor:
+                   store_main: bool = True, x_g4: bool = False) -> torch.Tensor:
     """Two sibling ConvBR_3d groups in one launch: out = act(bnA(convA(x[:, :cin_a]))) + act(bnB(convB(x[:, cin_a:])))
-    (+ res): see ragmi_conv3d_k3_dual_fwd in include/rag_amd.h."""
+    (+ res): see ragmi_conv3d_k3_dual_fwd in include/rag_amd.h.  x_g4: x is stored channel-group-interleaved (RAGMI_CONV_X_G4)."""
+    if x_g4 and not x.is_contiguous():
+        raise ValueError("conv3d_k3_dual: a G4 input is a contiguous buffer")
     _need_gpu(packed_a, packed_b, scale_a, shift_a, scale_b, shift_b)
     dt = _act(x, out, res, *[t.out for t in (tails or [])])
     B, Cx, D, H, W = x.shape
@@ -310,7 +361,7 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
     ntail, tarr = _tail_array(tails)
     check(load_library().ragmi_conv3d_k3_dual_fwd_ex(
         x.data_ptr(), _planes(x), cin_a, packed_a.data_ptr(), ptr(scale_a), ptr(shift_a),
-        Cx - cin_a, packed_b.data_ptr(), ptr(scale_b), ptr(shift_b), int(relu),
+        Cx - cin_a, packed_b.data_ptr(), ptr(scale_b), ptr(shift_b), int(relu) | (CONV_X_G4 if x_g4 else 0),
         out.data_ptr(), _planes(out), _i32_array(out_group_ch),
         ptr(res), _planes(res) if res is not None else 0, _i32_array(res_group_ch),
         B, cout, D, H, W, int(store_main), ntail, tarr, _conv_dt(dt), _stream()), "conv3d_k3_dual")

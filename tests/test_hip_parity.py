@@ -1473,3 +1473,128 @@ def test_x3_bf16_storage(ra):
     got = out[:1, :, :8].float().cpu()
     # interior planes only (the reference slab has its own z border at plane 7)
     np.testing.assert_allclose(got[:, :, :7].numpy(), ref[:, :, :7].numpy(), rtol=1e-2, atol=1e-2)
+
+
+# --------------------------------------------------------------------------- G4: channel-group-interleaved level-3 tensors (round 5)
+@pytest.mark.parametrize("shape,ntail", [((1, 16, 128, 128), 2), ((2, 16, 136, 132), 1), ((1, 24, 128, 96), 0)])
+def test_x3_dual_g4_input_and_tails_bitwise(ra, x3_on, shape, ntail):
+    """The level-3 dual launch (conv3d_x3q.hip) reading a G4 input and writing G4 tails against the same launch on channel planes:
+    the arithmetic is the same instruction stream (only the loads / stores differ), so every bit must agree — and the plane run is
+    itself checked against float64 (rag_model.py:160-172 via operations_3d.py:31-47)."""
+    B, D, H, W = shape
+    C, cout = 4, 12
+    g1 = gen(501)
+    x = torch.randn((B, 2 * C, D, H, W), generator=g1)
+    wa, wb = (torch.randn((cout, C, 3, 3, 3), generator=g1) * 0.2 for _ in range(2))
+    sa, sb = (torch.rand(cout, generator=g1) + 0.5 for _ in range(2))
+    ha, hb = (torch.randn(cout, generator=g1) * 0.1 for _ in range(2))
+    tw = [torch.randn((4, cout), generator=g1) * 0.3 for _ in range(ntail)]
+    ts = [torch.rand(4, generator=g1) + 0.5 for _ in range(ntail)]
+    th = [torch.randn(4, generator=g1) * 0.1 for _ in range(ntail)]
+    with ra.ops.conv_precision("f16x3"):
+        caps = ra.ops.conv3d_k3_g4_caps(2 * C, cout, B, D, H, W, nset=2, ntail=ntail)
+        assert caps == 3, caps
+        pa, pb = ra.ops.conv3d_k3_pack(gpu(wa)), ra.ops.conv3d_k3_pack(gpu(wb))
+        outs = {}
+        for g4 in (False, True):
+            xin = ra.ops.to_g4(gpu(x)) if g4 else gpu(x)
+            pre = torch.full((B, 8, D, H, W), float("nan"), device=DEV)
+            tails = [ra.ops.Tail(gpu(tw[k]), gpu(ts[k]), gpu(th[k]), k == 0, pre, 4 * k, g4=g4) for k in range(ntail)]
+            y = torch.full((B, cout, D, H, W), float("nan"), device=DEV)
+            ra.ops.conv3d_k3_dual(xin, C, pa, gpu(sa), gpu(ha), pb, gpu(sb), gpu(hb), cout, True, y, tails=tails or None, x_g4=g4)
+            outs[g4] = (y, ra.ops.from_g4(pre) if g4 else pre)
+    assert torch.equal(outs[True][0], outs[False][0])
+    for k in range(ntail):
+        assert torch.equal(outs[True][1][:, 4 * k:4 * k + 4], outs[False][1][:, 4 * k:4 * k + 4])
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    main = sum(F.relu(F.conv3d(x[:, i * C:(i + 1) * C].double(), w.double(), padding=1) * v(s.double()) + v(h.double()))
+               for i, (w, s, h) in enumerate(((wa, sa, ha), (wb, sb, hb))))
+    np.testing.assert_allclose(outs[True][0].cpu().double().numpy(), main.numpy(), rtol=2e-4, atol=2e-4)
+    for k in range(ntail):
+        ref = torch.einsum("oc,bcdhw->bodhw", tw[k].double(), main) * v(ts[k].double()) + v(th[k].double())
+        ref = F.relu(ref) if k == 0 else ref
+        np.testing.assert_allclose(outs[True][1][:, 4 * k:4 * k + 4].cpu().double().numpy(), ref.numpy(), rtol=3e-4, atol=3e-4)
+
+
+def test_x3_stem1_g4_input_and_tails_bitwise(ra, x3_on):
+    """stem3d1's launch shape (12 -> 12, two fused tails, no main store: rag_model.py:235,341-343) on a G4 input with G4 tails against
+    the plane form: bit-identical."""
+    B, D, H, W = 1, 16, 128, 160
+    g1 = gen(511)
+    x = torch.randn((B, 12, D, H, W), generator=g1)
+    w = torch.randn((12, 12, 3, 3, 3), generator=g1) * 0.1
+    sc, sh = torch.rand(12, generator=g1) + 0.5, torch.randn(12, generator=g1) * 0.1
+    tw = [torch.randn((4, 12), generator=g1) * 0.3 for _ in range(2)]
+    with ra.ops.conv_precision("f16x3"):
+        assert ra.ops.conv3d_k3_g4_caps(12, 12, B, D, H, W, nset=1, ntail=2) == 3
+        pk = ra.ops.conv3d_k3_pack(gpu(w))
+        outs = {}
+        for g4 in (False, True):
+            xin = ra.ops.to_g4(gpu(x)) if g4 else gpu(x)
+            pre = torch.full((B, 8, D, H, W), float("nan"), device=DEV)
+            tails = [ra.ops.Tail(gpu(tw[k]), None, None, True, pre, 4 * k, g4=g4) for k in range(2)]
+            y = torch.empty((B, 12, D, H, W), device=DEV)
+            ra.ops.conv3d_k3(xin, pk, 12, gpu(sc), gpu(sh), True, y, None, tails=tails, store_main=False, x_g4=g4)
+            outs[g4] = ra.ops.from_g4(pre) if g4 else pre
+    assert torch.equal(outs[True], outs[False])
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    main = F.relu(F.conv3d(x.double(), w.double(), padding=1) * v(sc.double()) + v(sh.double()))
+    for k in range(2):
+        ref = F.relu(torch.einsum("oc,bcdhw->bodhw", tw[k].double(), main))
+        np.testing.assert_allclose(outs[True][:, 4 * k:4 * k + 4].cpu().double().numpy(), ref.numpy(), rtol=3e-4, atol=3e-4)
+
+
+def test_costvol_stem_g4_output_and_tail_bitwise(ra):
+    """stem3d0 folded with the cost volume writing a G4 output and a G4 tail against the plane form (rag_model.py:375-383, 234, 341)."""
+    B, C, h, w, maxdisp = 2, 12, 6, 40, 24
+    L, R = torch.randn((B, C, h, w), generator=gen(521)), torch.randn((B, C, h, w), generator=gen(522))
+    wt = torch.randn((12, 24, 3, 3, 3), generator=gen(523)) * 0.1
+    w1 = torch.randn((4, 12), generator=gen(524)) * 0.3
+    s1, h1 = torch.rand(4, generator=gen(525)) + 0.5, torch.randn(4, generator=gen(526)) * 0.1
+    var = ra.ops.costvol_stem_prepare(gpu(wt))
+    outs = {}
+    for g4 in (False, True):
+        pre = torch.full((B, 8, maxdisp // 3, h, w), float("nan"), device=DEV)
+        tails = [ra.ops.Tail(gpu(w1), gpu(s1), gpu(h1), True, pre, 4, g4=g4)]
+        out = ra.ops.costvol_stem(gpu(L), gpu(R), maxdisp, var, 12, None, None, True, tails=tails, out_g4=g4)
+        outs[g4] = (ra.ops.from_g4(out), ra.ops.from_g4(pre)) if g4 else (out, pre)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1][:, 4:8], outs[False][1][:, 4:8])
+    assert torch.isnan(outs[True][1][:, 0:4]).all()
+
+
+def test_g4_is_refused_where_the_kernel_does_not_take_it(ra):
+    """A call that lands on a kernel without the G4 forms fails loudly (RAGMI_EUNSUPPORTED), never reads planes as groups."""
+    x = torch.randn((1, 8, 8, 16, 32), generator=gen(531))
+    w = torch.randn((8, 8, 3, 3, 3), generator=gen(532)) * 0.1
+    with ra.ops.conv_precision("fp32"):
+        assert ra.ops.conv3d_k3_g4_caps(8, 8, 1, 8, 16, 32) == 0
+        pk = ra.ops.conv3d_k3_pack(gpu(w))
+        with pytest.raises(RuntimeError):
+            ra.ops.conv3d_k3(gpu(x), pk, 8, None, None, True, torch.empty((1, 8, 8, 16, 32), device=DEV), x_g4=True)
+
+
+@pytest.mark.parametrize("hwd", [(384, 1248, 192), (192, 384, 96)])
+def test_matchingnet_g4_plan_and_bitwise(ra, x3_on, hwd):
+    """The fused executor with its private level-3 tensors channel-group-interleaved (round 5) against the same forward on channel
+    planes: same kernels, same arithmetic, other loads and stores — the disparity maps agree bit for bit; and the plan really is G4
+    for stem3d0's output and the three level-3 cells at the headline shape (rag_model.py:341-351)."""
+    H, W, D = hwd
+    rows = O.ALL_CONV
+    sd = O.random_matching_state_dict(rows, seed=0)
+    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=D)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    lf, rf = torch.randn((2, 12, H // 3, W // 3), generator=gen(541)), torch.randn((2, 12, H // 3, W // 3), generator=gen(542))
+    outs = {}
+    try:
+        for g4 in (True, False):
+            ra.ops.set_g4(g4)
+            with torch.no_grad():
+                outs[g4] = net(gpu(lf), gpu(rf))
+            plan = net.last_g4_plan
+            assert plan["stem0_out"] == g4 and [plan["pre"][j] for j in (0, 1, 2)] == [g4] * 3, plan
+            assert not any(plan["pre"][j] for j in range(3, 8))
+    finally:
+        ra.ops.set_g4(True)
+    assert torch.equal(outs[True], outs[False])

@@ -331,3 +331,14 @@ def test_training_defaults_to_strict_fp32():
     assert train.TRAIN_PRECISION == "fp32"
     for fn in (train.forward_backward, train.train_step, train.GraphedTrainStep.__init__):
         assert inspect.signature(fn).parameters["precision"].default is None      # None -> TRAIN_PRECISION
+
+
+def test_g4_layout_helpers_round_trip():
+    import rag_amd
+    t = torch.arange(2 * 8 * 3 * 4 * 5, dtype=torch.float32).view(2, 8, 3, 4, 5)
+    g = rag_amd.ops.to_g4(t)
+    assert g.shape == t.shape and torch.equal(rag_amd.ops.from_g4(g), t)
+    # group 1, voxel (d, h, w) = (1, 2, 3): its four channels are contiguous in the buffer
+    flat = g.reshape(2, -1)
+    base = ((1 * 3 + 1) * 4 + 2) * 5 + 3
+    assert torch.equal(flat[0, 4 * base:4 * base + 4], t[0, 4:8, 1, 2, 3])
