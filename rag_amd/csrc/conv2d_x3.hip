@@ -207,16 +207,19 @@ __global__ __launch_bounds__(C2_THREADS) void cell2d_x3_kernel(K3Args a, X3Extra
   const int xb = blockIdx.x * C2_TX, yb = blockIdx.y * C2_TY;
   if (tid < 2) lmax[tid] = 0u;
   if (tid == 0) { lhi[NCG * C2_GS] = make_uint2(0u, 0u); llo[NCG * C2_GS] = make_uint2(0u, 0u); }
-  for (int i = tid; i < NSET * C2_MAX_CIN * C; i += C2_THREADS) {
-    const int st = i / (C2_MAX_CIN * C), ci = (i / C) % C2_MAX_CIN, j = i % C;
+  // (compile-time set: `st ? in1 : in0` with a lane-dependent st is an ADDRESS select — every field then comes from the argument
+  // segment by a vector load, the weights by a second, dependent one: six serial memory round trips in front of the staging)
+#pragma unroll
+  for (int st = 0; st < NSET; ++st) {
     const C2In& in = st ? in1 : in0;
-    lw[st][ci * C + j] = ci < in.Cin ? in.w[j * in.Cin + ci] : 0.f;
-  }
-  if (tid < NSET * C) {
-    const int st = tid / C, j = tid % C;
-    const C2In& in = st ? in1 : in0;
-    lsc[st][0][j] = in.scale ? in.scale[j] : 1.f;
-    lsc[st][1][j] = in.scale ? in.shift[j] : 0.f;
+    for (int i = tid; i < C2_MAX_CIN * C; i += C2_THREADS) {
+      const int ci = i / C, j = i % C;
+      lw[st][i] = ci < in.Cin ? in.w[j * in.Cin + ci] : 0.f;
+    }
+    if (tid < C) {
+      lsc[st][0][tid] = in.scale ? in.scale[tid] : 1.f;
+      lsc[st][1][tid] = in.scale ? in.shift[tid] : 0.f;
+    }
   }
   uint4 ah[NSET][C2Slices<NCGS>::NSU], al[NSET][C2Slices<NCGS>::NSU];
   c2_load_weights<NCGS, NSET>(e, cog, lane, ah, al);

@@ -155,22 +155,35 @@ __global__ __launch_bounds__(256, WPS) void conv3d_k3_kernel(K3Args a) {
   // folded-BN parameters of this workgroup's output channels, staged once into LDS: the epilogue must not
   // re-read them from global memory (its stores may alias them, which would serialise every element)
   __shared__ __attribute__((aligned(16))) float bnp[NSET][2][G * 4];
-  if (tid < NSET * G * 4) {
-    const int s = tid / (G * 4), j = tid % (G * 4), co = gbase * 4 + j;
-    const bool ok = a.scale[s] != nullptr && co < a.Cout;
-    bnp[s][0][j] = ok ? a.scale[s][co] : 1.f;   // identity affine when there is no BN: fma(x, 1, 0) == x exactly
-    bnp[s][1][j] = ok ? a.shift[s][co] : 0.f;
+  // (compile-time set / tail index in unrolled loops: a descriptor array of the kernel arguments indexed by a lane-dependent value
+  // costs a vector load of the pointer plus a dependent one of the value, serially, in front of the first tile)
+#pragma unroll
+  for (int s = 0; s < NSET; ++s) {
+    const float* const psc = a.scale[s];
+    const float* const psh = a.shift[s];
+    if (tid < G * 4) {
+      const int j = tid, co = gbase * 4 + j;
+      const bool ok = psc != nullptr && co < a.Cout;
+      bnp[s][0][j] = ok ? psc[co] : 1.f;   // identity affine when there is no BN: fma(x, 1, 0) == x exactly
+      bnp[s][1][j] = ok ? psh[co] : 0.f;
+    }
   }
   // tail weights + folded BN, staged like bnp (alias-free reads in the epilogue)
   __shared__ __attribute__((aligned(16))) float tailw[2][4][16];
   __shared__ __attribute__((aligned(16))) float tailbn[2][2][4];
-  if (a.ntail > 0 && tid < 2 * 4 * 16) {
-    const int t = tid / 64, j = (tid / 16) % 4, c = tid % 16;
-    const bool ok = t < a.ntail && j < a.tail_cout[t] && c < a.Cout;
-    tailw[t][j][c] = ok ? a.tail_w[t][j * a.Cout + c] : 0.f;
-    if (c < 2) {
-      const bool okb = t < a.ntail && j < a.tail_cout[t] && a.tail_scale[t] != nullptr;
-      tailbn[t][c][j] = okb ? (c == 0 ? a.tail_scale[t][j] : a.tail_shift[t][j]) : (c == 0 ? 1.f : 0.f);
+  if (a.ntail > 0 && tid < 4 * 16) {
+    const int j = tid / 16, c = tid % 16;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float* const pw = a.tail_w[t];
+      const float* const psc = a.tail_scale[t];
+      const float* const psh = a.tail_shift[t];
+      const bool ok = t < a.ntail && j < a.tail_cout[t] && c < a.Cout;
+      tailw[t][j][c] = ok ? pw[j * a.Cout + c] : 0.f;
+      if (c < 2) {
+        const bool okb = t < a.ntail && j < a.tail_cout[t] && psc != nullptr;
+        tailbn[t][c][j] = okb ? (c == 0 ? psc[j] : psh[j]) : (c == 0 ? 1.f : 0.f);
+      }
     }
   }
   int ych[G], rch[G];

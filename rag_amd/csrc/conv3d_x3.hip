@@ -89,11 +89,17 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 #endif
   // weight fragments, 8 bytes (one pair's four channels) at a time: lane quarter q of slice s holds the pairs x3_pair_perm(.., 2q + j)
   // of the packed slice (packed: quarter p >> 1, half p & 1)
-  for (int i = tid; i < NSL * 2 * 64 * 2; i += X3_THREADS) {
-    const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, set = sh / (NSLS * 2), s = (sh >> 1) % NSLS;
-    const int p = x3_pair_perm(NCGS, s, 2 * (ln >> 4) + j);
+  // (every descriptor array of the kernel arguments below is indexed by a COMPILE-TIME index in an unrolled loop, the lanes pick by
+  // comparison: indexed by a lane-dependent value the compiler fetches the pointer itself with a vector load from the argument
+  // segment and the value with a second, dependent one — ~25 serial memory round trips in front of the first plane of a launch)
+#pragma unroll
+  for (int set = 0; set < NSET; ++set) {
     const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set] + (int64_t)cog * NSLS * 2 * 64);
-    reinterpret_cast<uint2*>(lw)[i] = src[(((sh % (NSLS * 2)) * 64) + (p >> 1) * 16 + (ln & 15)) * 2 + (p & 1)];
+    for (int i = tid; i < NSLS * 2 * 64 * 2; i += X3_THREADS) {
+      const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, s = sh >> 1;
+      const int p = x3_pair_perm(NCGS, s, 2 * (ln >> 4) + j);
+      reinterpret_cast<uint2*>(lw)[set * (NSLS * 2 * 64 * 2) + i] = src[((sh * 64) + (p >> 1) * 16 + (ln & 15)) * 2 + (p & 1)];
+    }
   }
   for (int i = tid; i < 3 * NSL * 4; i += X3_THREADS) {
     const int ring = i / (NSL * 4), q = i % (NSL * 4), set = q / (NSLS * 4);
@@ -113,14 +119,22 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     }
     loff[i] = make_int2(o[0], o[1]);
   }
-  for (int i = tid; i < 32; i += X3_THREADS) {
-    const int set = i >> 4, co = cog * 16 + (i & 15);
-    const bool ok = set < NSET && co < a.Cout;
-    float sc = (ok && a.scale[set]) ? a.scale[set][co] : 1.f;
-    if constexpr (!BF) sc *= (ok ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
-    par[i] = sc;
-    par[96 + i] = sc;
-    par[32 + i] = (ok && a.shift[set]) ? a.shift[set][co] : 0.f;
+  if (tid < 32) {
+    const int co = cog * 16 + (tid & 15);
+    float sc = 1.f, sh = 0.f;
+#pragma unroll
+    for (int set = 0; set < NSET; ++set) {
+      const float* const psc = a.scale[set];
+      const float* const psh = a.shift[set];
+      if ((tid >> 4) == set && co < a.Cout) {
+        sc = psc ? psc[co] : 1.f;
+        if constexpr (!BF) sc *= e.wmul[set][co];          // undo the per-channel weight scale 2^k
+        sh = psh ? psh[co] : 0.f;
+      }
+    }
+    par[tid] = sc;
+    par[96 + tid] = sc;
+    par[32 + tid] = sh;
   }
   if (tid < 2) lmaxp[tid] = 0u;
   // Fused consumer 1x1x1 convs ("tails") on the matrix cores: out_t[k][voxel] = sum_c W_t[k][c] * v[c][voxel] as four 16x16x4 fp32
@@ -133,33 +147,43 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     // every lane quarter — instead of three bf16 products of three-way split operands: the splits were ~28 vector instructions per
     // tile in a kernel bound by vector issue; the fp32 MFMA holds the issue port for 8 of its 32 cycles)
     if (tid < 64) {
-      const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row
+      const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row: tail slot tl, its output channel k
+      float wv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = cog * 16 + 4 * kb + j;
-        float wv = 0.f;
-        if (tl < a.ntail && k < a.tail_cout[tl] && c < a.Cout) wv = a.tail_w[tl][k * a.Cout + c];
-        if constexpr (TAILS == 2) {
-          const int dl = tl - a.ntail;                   // down slot of this row
-          if (dl >= 0 && dl < a.ndown && k < a.down_cout[dl < 2 ? dl : 0] && c < a.Cout) wv = a.down_w[dl < 2 ? dl : 0][k * a.Cout + c];
+      for (int t = 0; t < 2; ++t) {
+        const float* const pw = a.tail_w[t];
+        if (t < a.ntail && tl == t && k < a.tail_cout[t]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int c = cog * 16 + 4 * kb + j; if (c < a.Cout) wv[j] = pw[k * a.Cout + c]; }
         }
-        reinterpret_cast<float*>(ltail)[j * 64 + lane] = wv;
+        if constexpr (TAILS == 2) {
+          const float* const pd = a.down_w[t];
+          if (t < a.ndown && tl == a.ntail + t && k < a.down_cout[t]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int c = cog * 16 + 4 * kb + j; if (c < a.Cout) wv[j] = pd[k * a.Cout + c]; }
+          }
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) reinterpret_cast<float*>(ltail)[j * 64 + lane] = wv[j];
     }
     // this lane's tail outputs after that product: rows 4 kb + r -> tail kb, output r
     if (tid < 16) {
       const int tk = tid >> 2, r = tid & 3;
-      const bool ok = tk < a.ntail && r < a.tail_cout[tk < 2 ? tk : 0];
-      par[64 + tid] = (ok && a.tail_scale[tk < 2 ? tk : 0]) ? a.tail_scale[tk < 2 ? tk : 0][r] : 1.f;
-      par[80 + tid] = (ok && a.tail_shift[tk < 2 ? tk : 0]) ? a.tail_shift[tk < 2 ? tk : 0][r] : 0.f;
-      if constexpr (TAILS == 2) {
-        const int dl = tk - a.ntail, d2 = dl >= 0 && dl < 2 ? dl : 0;
-        if (dl >= 0 && dl < a.ndown) {
-          const bool okd = r < a.down_cout[d2] && a.down_scale[d2] != nullptr;
-          par[64 + tid] = okd ? a.down_scale[d2][r] : 1.f;
-          par[80 + tid] = okd ? a.down_shift[d2][r] : 0.f;
+      float sc = 1.f, sh = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float* const psc = a.tail_scale[t];
+        const float* const psh = a.tail_shift[t];
+        if (t < a.ntail && tk == t && r < a.tail_cout[t] && psc) { sc = psc[r]; sh = psh[r]; }
+        if constexpr (TAILS == 2) {
+          const float* const dsc = a.down_scale[t];
+          const float* const dsh = a.down_shift[t];
+          if (t < a.ndown && tk == a.ntail + t && r < a.down_cout[t] && dsc) { sc = dsc[r]; sh = dsh[r]; }
         }
       }
+      par[64 + tid] = sc;
+      par[80 + tid] = sh;
     }
   }
   float pf[NPF][4];
@@ -287,9 +311,13 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const int64_t ovol = (int64_t)Do * Ho * Wo;
       // one output VALUE per thread: (slot, row pair, column) x channel — all eight waves take part (round 4, first form: one thread
       // per four channels, i.e. two waves worked while six waited at the next barrier)
+      // (the down slot is wave-uniform — waves 0..3 finish slot 0, waves 4..7 slot 1 — and SAID to be: picked by a lane-dependent index
+      // the descriptors below were three serial vector loads from the argument segment per finishing step, each behind an
+      // s_waitcnt vmcnt(0) that also drained the halo prefetch)
       const int o = tid >> 2, r = tid & 3;
-      if (o < a.ndown * 64) {
-        const int dl = o >> 6, yp = (o >> 4) & 3, xp = o & 15;
+      const int dl = __builtin_amdgcn_readfirstlane(tid >> 8);
+      if (dl < a.ndown) {
+        const int yp = (o >> 4) & 3, xp = o & 15;
         const float4 yt = ldyt[yp];
         const float* const u0 = ldu + (((0 * 2 + dl) * X3_TY + 2 * yp) * (X3_TX / 2) + xp) * 4 + r;
         const float* const u1 = u0 + 2 * X3_TY * (X3_TX / 2) * 4;
@@ -678,12 +706,19 @@ __global__ __launch_bounds__(W16 ? 1024 : XD_THREADS, W16 ? 1 : (WS ? 4 : 2)) vo
 #pragma unroll
     for (int set = 0; set < NSET; ++set) wcopy(set, set);
   }
-  for (int i = tid; i < NSET * COGS * 16; i += THREADS) {
-    const int set = i / (COGS * 16), co = cog0 * 16 + i % (COGS * 16);
-    float sc = (co < a.Cout && a.scale[set]) ? a.scale[set][co] : 1.f;
-    if constexpr (!BF) sc *= (co < a.Cout ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
-    par[i] = sc;
-    par[NSET * COGS * 16 + i] = (co < a.Cout && a.shift[set]) ? a.shift[set][co] : 0.f;
+  // (compile-time `set` in an unrolled loop: a descriptor array of the kernel arguments indexed by a lane-dependent value costs a
+  // vector load of the pointer plus a dependent one of the value — serial memory round trips in front of the first box)
+#pragma unroll
+  for (int set = 0; set < NSET; ++set) {
+    const float* const psc = a.scale[set];
+    const float* const psh = a.shift[set];
+    for (int i = tid; i < COGS * 16; i += THREADS) {
+      const int co = cog0 * 16 + i;
+      float sc = (co < a.Cout && psc) ? psc[co] : 1.f;
+      if constexpr (!BF) sc *= (co < a.Cout ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
+      par[set * COGS * 16 + i] = sc;
+      par[NSET * COGS * 16 + set * COGS * 16 + i] = (co < a.Cout && psh) ? psh[co] : 0.f;
+    }
   }
   if (tid < 3) lmaxp[tid] = 0u;
   __syncthreads();      // the slots are zero before any wave's first atomicMax (waves that skip the loops above arrive there early)
@@ -965,7 +1000,7 @@ extern "C" __attribute__((visibility("default"))) int ragmi_diag_x3_stamp_buffer
 // a: as filled for the fp32 kernel (wp[s] = packed weights: fp32-MFMA section followed by the bf16x3 fragments)
 int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
 #ifdef RAGMI_DIAG
-  static const int diag_x3 = [] { const char* v = getenv("RAGMI_X3_DIAG"); return v ? atoi(v) : 0; }();   // 1 no stores, 2 no MFMA block, 4 no commit, 8 no loads, 16 operand reads at one address, 32 in-kernel stamps
+  static const int diag_x3 = [] { const char* v = getenv("RAGMI_X3_DIAG"); return v ? atoi(v) : 0; }();   // 1 no stores, 2 no MFMA block, 4 no commit, 8 no loads, 16 operand reads at one address, 32 in-kernel stamps, 64 / 128 (quad-ring kernel) no finishing step / no parking of the down-sampling tails
   a.relu |= diag_x3 << 8;
 #endif
   X3Extra e{};
@@ -980,7 +1015,11 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   // the segments end enters the rounding, and a pair's result must not depend on how a batch is split over ranks
   const int64_t cols = (int64_t)a.tiles_x * a.tiles_y * a.B;
   const int64_t cols_seg = dtype == RAGMI_BF16 ? cols : (int64_t)a.tiles_x * a.tiles_y;
-  const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(1536, cols_seg * ncog), ceil_div(a.D, 8)));
+  int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(1536, cols_seg * ncog), ceil_div(a.D, 8)));
+#ifdef RAGMI_DIAG
+  static const int diag_nseg = [] { const char* v = getenv("RAGMI_X3_NSEG"); return v ? atoi(v) : 0; }();      // profiling builds: depth segments per column
+  if (diag_nseg > 0) nseg = std::min(diag_nseg, a.D);
+#endif
   e.seg_len = (int)ceil_div(a.D, nseg);
   if (a.ndown > 0) e.seg_len += e.seg_len & 1;         // down-sampling tails pair the planes (2Z, 2Z+1): segments start and end even
   e.nseg = (int)ceil_div(a.D, e.seg_len);

@@ -21,11 +21,14 @@
 
 namespace ragmi {
 
-// (8 records behind every channel group and behind the hi copy: with strides that are multiples of 512 bytes hipcc fuses the reads of
+// (2 records behind every channel group and behind the hi copy: with strides that are multiples of 512 bytes hipcc fuses the reads of
 // the two sets / of a hi and its lo operand into ds_read2st64_b64 — half rate, and its result registers are not an MFMA operand)
-constexpr int XQ_RS = 40, XQ_PLS = X3_HY * XQ_RS, XQ_SLOTS = 4, XQ_CGS = XQ_SLOTS * XQ_PLS + 8, XQ_LOPAD = 8;      // records of 8 bytes
+constexpr int XQ_RS = 40, XQ_PLS = X3_HY * XQ_RS, XQ_SLOTS = 4, XQ_CGS = XQ_SLOTS * XQ_PLS + 2, XQ_LOPAD = 2;      // records of 8 bytes
+constexpr int XQ_DU_SLOTS = 3, XQ_DU_PLANE = 2 * 4 * X3_TY * (X3_TX / 2);      // down-sampling tails: x-blended tail values, floats per plane copy
 static_assert(XQ_RS >= X3_HX && (2 * XQ_RS) % 32 == 16 && XQ_PLS % 32 == 16, "bank layout: partners of an LDS pass 128 bytes mod 256 apart");
 static_assert((XQ_CGS * 8) % 512 != 0 && (XQ_PLS * 8) % 512 != 0 && XQ_PLS > 255, "strides that ds_read2(st64)_b64 cannot span");
+static_assert(2 * (2 * XQ_CGS + XQ_LOPAD) * 8 + 8 * 2 * 64 * 16 + 4 * 64 * 4 + 132 * 4 + XQ_DU_SLOTS * XQ_DU_PLANE * 4 + 20 * 16 <= 80 * 1024,
+              "the dual launch with down-sampling tails must leave room for two workgroups per CU");
 // tap (dy * 3 + dx) that lane quarter q holds as operand j of a plane slice; the padding slot (q = 3, j = 1) re-reads its pass
 // partner's voxel.  Left over per plane: taps 4 = (1,1) and 5 = (1,2).
 __host__ __device__ constexpr int xq_tap7(int q, int j) {
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
   float* const par = ltail + 4 * 64;
   unsigned* const lmaxp = reinterpret_cast<unsigned*>(par + 128);
   float* const ldu = par + 132;
-  float4* const ldxt = reinterpret_cast<float4*>(ldu + 2 * 2 * 4 * X3_TY * (X3_TX / 2));
+  float4* const ldxt = reinterpret_cast<float4*>(ldu + XQ_DU_SLOTS * XQ_DU_PLANE);
   float4* const ldyt = ldxt + X3_TX / 2;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
   const int cog = blockIdx.y;
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
 #ifdef RAGMI_DIAG
   // profiling builds (RAGMI_X3_DIAG bits, as conv3d_x3_kernel): 1 no stores, 2 no MFMA block, 4 no commit, 8 no loads, 16 operand reads at one address
   const bool dg_nostore = (a.relu & 0x100) != 0, dg_nomfma = (a.relu & 0x200) != 0, dg_nocommit = (a.relu & 0x400) != 0, dg_noload = (a.relu & 0x800) != 0, dg_noread = (a.relu & 0x1000) != 0;
+  const bool dg_nofinish = (a.relu & 0x4000) != 0, dg_nopark = (a.relu & 0x8000) != 0;      // 64: no finishing step of the down-sampling tails, 128: no x blend + LDS parking
   const bool dg_stamp = (a.relu & 0x2000) != 0 && xq_stamp_buf != nullptr;
   unsigned long long dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_last = 0, dg_t0 = 0, dg_r0 = 0;
   unsigned dg_steps = 0;
@@ -84,62 +88,87 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
 #define XQ_STAMP(k) do { if (dg_stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                                          dg_sum[k] += t_ - dg_last; dg_last = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
-  constexpr bool dg_nostore = false, dg_nomfma = false, dg_nocommit = false, dg_noload = false, dg_noread = false;
+  constexpr bool dg_nostore = false, dg_nomfma = false, dg_nocommit = false, dg_noload = false, dg_noread = false, dg_nofinish = false, dg_nopark = false;
 #define XQ_STAMP(k) do { } while (0)
 #endif
   // weight fragments, 8 bytes (one pair's four channels) at a time, from the packed tap-major slices (x3_pack_one: pair P = tap, one
   // channel group per set) into this kernel's slices: [set][plane 0..2 | leftover]
-  for (int i = tid; i < NSL * 2 * 64 * 2; i += X3_THREADS) {
-    const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, hl = sh & 1, s = sh >> 1, set = s >> 2, sl = s & 3, q = ln >> 4;
-    int tap = -1;
-    if (sl < 3) { if (!xq_pad7(q, j)) tap = sl * 9 + xq_tap7(q, j); }
-    else if (q < 3) tap = q * 9 + 4 + j;
-    uint2 v = make_uint2(0u, 0u);
-    if (tap >= 0) {
-      const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set] + (int64_t)cog * 4 * 2 * 64);
-      const int ps = tap >> 3, pp = tap & 7;
-      v = src[(((ps * 2 + hl) * 64) + (pp >> 1) * 16 + (ln & 15)) * 2 + (pp & 1)];
+#pragma unroll
+  for (int set = 0; set < NSET; ++set) {          // (compile-time `set`: e.wf[set] stays a scalar — see the parameters below)
+    const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set] + (int64_t)cog * 4 * 2 * 64);
+    for (int i = tid; i < 4 * 2 * 64 * 2; i += X3_THREADS) {
+      const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, hl = sh & 1, sl = sh >> 1, q = ln >> 4;
+      int tap = -1;
+      if (sl < 3) { if (!xq_pad7(q, j)) tap = sl * 9 + xq_tap7(q, j); }
+      else if (q < 3) tap = q * 9 + 4 + j;
+      uint2 v = make_uint2(0u, 0u);
+      if (tap >= 0) {
+        const int ps = tap >> 3, pp = tap & 7;
+        v = src[(((ps * 2 + hl) * 64) + (pp >> 1) * 16 + (ln & 15)) * 2 + (pp & 1)];
+      }
+      reinterpret_cast<uint2*>(lw)[set * (4 * 2 * 64 * 2) + i] = v;
     }
-    reinterpret_cast<uint2*>(lw)[i] = v;
   }
-  for (int i = tid; i < 32; i += X3_THREADS) {
-    const int set = i >> 4, co = cog * 16 + (i & 15);
-    const bool ok = set < NSET && co < a.Cout;
-    float sc = (ok && a.scale[set]) ? a.scale[set][co] : 1.f;
-    sc *= (ok ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
-    par[i] = sc;
-    par[96 + i] = sc;
-    par[32 + i] = (ok && a.shift[set]) ? a.shift[set][co] : 0.f;
+  // Parameters -> LDS.  Every descriptor array of the kernel arguments is indexed by a COMPILE-TIME index inside an unrolled loop and
+  // the lanes pick by comparison: indexed by a lane-dependent value (set = i >> 4, tail = row >> 2) the compiler fetches the pointer
+  // itself with a vector load from the argument segment and the value with a second, dependent one — ~25 serial memory round trips
+  // in front of the first plane of every level-3 launch (round 5: found in the listing of the finishing step, below).
+  if (tid < 32) {
+    const int co = cog * 16 + (tid & 15);
+    float sc = 1.f, sh = 0.f;
+#pragma unroll
+    for (int set = 0; set < NSET; ++set) {
+      const float* const psc = a.scale[set];
+      const float* const psh = a.shift[set];
+      const float* const pwm = e.wmul[set];
+      if ((tid >> 4) == set && co < a.Cout) {
+        sc = (psc ? psc[co] : 1.f) * pwm[co];          // BatchNorm scale x 2^-k (undoes the per-channel weight scale)
+        sh = psh ? psh[co] : 0.f;
+      }
+    }
+    par[tid] = sc;
+    par[96 + tid] = sc;
+    par[32 + tid] = sh;
   }
   if (tid < 3) lmaxp[tid] = 0u;
   if constexpr (TAILS) {
     if (tid < 64) {
-      const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row
+      const int row = n, tl = row >> 2, k = row & 3;     // n = lane & 15 is the A row: tail slot tl, its output channel k
+      float wv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = cog * 16 + 4 * kb + j;
-        float wv = 0.f;
-        if (tl < a.ntail && k < a.tail_cout[tl] && c < a.Cout) wv = a.tail_w[tl][k * a.Cout + c];
-        if constexpr (TAILS == 2) {
-          const int dl = tl - a.ntail;                   // down slot of this row
-          if (dl >= 0 && dl < a.ndown && k < a.down_cout[dl < 2 ? dl : 0] && c < a.Cout) wv = a.down_w[dl < 2 ? dl : 0][k * a.Cout + c];
+      for (int t = 0; t < 2; ++t) {
+        const float* const pw = a.tail_w[t];
+        if (t < a.ntail && tl == t && k < a.tail_cout[t]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int c = cog * 16 + 4 * kb + j; if (c < a.Cout) wv[j] = pw[k * a.Cout + c]; }
         }
-        ltail[j * 64 + lane] = wv;
+        if constexpr (TAILS == 2) {
+          const float* const pd = a.down_w[t];
+          if (t < a.ndown && tl == a.ntail + t && k < a.down_cout[t]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int c = cog * 16 + 4 * kb + j; if (c < a.Cout) wv[j] = pd[k * a.Cout + c]; }
+          }
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ltail[j * 64 + lane] = wv[j];
     }
     if (tid < 16) {
-      const int tk = tid >> 2, r = tid & 3;
-      const bool ok = tk < a.ntail && r < a.tail_cout[tk < 2 ? tk : 0];
-      par[64 + tid] = (ok && a.tail_scale[tk < 2 ? tk : 0]) ? a.tail_scale[tk < 2 ? tk : 0][r] : 1.f;
-      par[80 + tid] = (ok && a.tail_shift[tk < 2 ? tk : 0]) ? a.tail_shift[tk < 2 ? tk : 0][r] : 0.f;
-      if constexpr (TAILS == 2) {
-        const int dl = tk - a.ntail, d2 = dl >= 0 && dl < 2 ? dl : 0;
-        if (dl >= 0 && dl < a.ndown) {
-          const bool okd = r < a.down_cout[d2] && a.down_scale[d2] != nullptr;
-          par[64 + tid] = okd ? a.down_scale[d2][r] : 1.f;
-          par[80 + tid] = okd ? a.down_shift[d2][r] : 0.f;
+      const int tk = tid >> 2, r = tid & 3;      // tail slot tk (full-resolution tails first, then the down-sampling ones), output r
+      float sc = 1.f, sh = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float* const psc = a.tail_scale[t];
+        const float* const psh = a.tail_shift[t];
+        if (t < a.ntail && tk == t && r < a.tail_cout[t] && psc) { sc = psc[r]; sh = psh[r]; }
+        if constexpr (TAILS == 2) {
+          const float* const dsc = a.down_scale[t];
+          const float* const dsh = a.down_shift[t];
+          if (t < a.ndown && tk == a.ntail + t && r < a.down_cout[t] && dsc) { sc = dsc[r]; sh = dsh[r]; }
         }
       }
+      par[64 + tid] = sc;
+      par[80 + tid] = sh;
     }
   }
   // Halo staging: thread t < 340 owns voxel t of the 10 x 34 halo plane for EVERY channel group (the groups are a wave-uniform
@@ -245,16 +274,23 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
   int b = 0, y0 = 0, x0 = 0;
   auto down_finish = [&](int zodd) {
     if constexpr (TAILS == 2) {
+      if (dg_nofinish) return;
       const int Z = zodd >> 1, Do = a.D >> 1, Ho = a.H >> 1, Wo = a.W >> 1;
       const LinIdx lz = lin_index(min(Z, Do - 1), a.D, Do, e.dsd, 1);            // wave-uniform
       const float wz0 = lz.i0 == 2 * Z ? lz.w0 : 0.f, wz1 = lz.i0 == 2 * Z ? lz.w1 : 1.f;
       const int64_t ovol = (int64_t)Do * Ho * Wo;
+      // (the down slot is wave-uniform — waves 0..3 finish slot 0, waves 4..7 slot 1 — and SAID to be: picked by a lane-dependent
+      // index the descriptors below were three serial vector loads from the argument segment per finishing step, each behind an
+      // s_waitcnt vmcnt(0) that also drained the halo prefetch: 196 -> 150 us for cell 1's launch with this step switched off)
       const int o = tid >> 2, r = tid & 3;
-      if (o < a.ndown * 64) {
-        const int dl = o >> 6, yp = (o >> 4) & 3, xp = o & 15;
+      const int dl = __builtin_amdgcn_readfirstlane(tid >> 8);
+      if (dl < a.ndown) {
+        const int yp = (o >> 4) & 3, xp = o & 15;
         const float4 yt = ldyt[yp];
-        const float* const u0 = ldu + (((0 * 2 + dl) * X3_TY + 2 * yp) * (X3_TX / 2) + xp) * 4 + r;
-        const float* const u1 = u0 + 2 * X3_TY * (X3_TX / 2) * 4;
+        // (THREE plane copies, plane z in copy z % 3: this step — after ONE barrier — reads the copies of planes zodd-1 and zodd while
+        // the epilogues of this step already write plane zodd+1 into the third; with two copies a second barrier stood here)
+        const float* const u0 = ldu + ((zodd - 1) % 3) * XQ_DU_PLANE + ((dl * X3_TY + 2 * yp) * (X3_TX / 2) + xp) * 4 + r;
+        const float* const u1 = ldu + (zodd % 3) * XQ_DU_PLANE + ((dl * X3_TY + 2 * yp) * (X3_TX / 2) + xp) * 4 + r;
         const float e0 = u0[0], e1 = u0[(X3_TX / 2) * 4], o0 = u1[0], o1 = u1[(X3_TX / 2) * 4];
         const int slot = a.ntail + dl;
         const float sc = par[64 + 4 * slot + r], sh = par[80 + 4 * slot + r];
@@ -327,7 +363,7 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
         }
         if constexpr (TAILS == 2) {
           const int dl = kb - a.ntail;
-          if (dl >= 0 && dl < a.ndown) {
+          if (dl >= 0 && dl < a.ndown && !dg_nopark) {
             const float4 xt = ldxt[8 * (nt & 1) + (n >> 1)];
             float ux[4];
 #pragma unroll
@@ -336,7 +372,7 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
               ux[r] = lerp2(xt.x, tacc[r], xt.y, p1);
             }
             if (!(n & 1))
-              reinterpret_cast<float4*>(ldu)[(((z & 1) * 2 + dl) * X3_TY + (nt >> 1)) * (X3_TX / 2) + 8 * (nt & 1) + (n >> 1)] =
+              reinterpret_cast<float4*>(ldu + (z % 3) * XQ_DU_PLANE)[(dl * X3_TY + (nt >> 1)) * (X3_TX / 2) + 8 * (nt & 1) + (n >> 1)] =
                   make_float4(ux[0], ux[1], ux[2], ux[3]);
           }
         }
@@ -352,10 +388,7 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
     __syncthreads();                     // step z-1's operand reads are done (slot of plane z-2 is free); plane z+1 is in the LDS
     XQ_STAMP(0);
     if constexpr (TAILS == 2) {
-      if (z > zs && !(z & 1)) {
-        down_finish(z - 1);              // planes z-2, z-1 of the x-blended tail values are complete (segments start even)
-        __syncthreads();                 // ...and read, before this step's epilogue overwrites the even-plane copy
-      }
+      if (z > zs && !(z & 1)) down_finish(z - 1);      // planes z-2, z-1 of the x-blended tail values are complete (segments start even)
     }
     note_overflow(PH & 1);
     commit((PH + 2) & 3);                // plane z+2, first read at step z+1
@@ -505,7 +538,7 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
 
 size_t xq_lds_bytes(int nset, bool down) {
   return (size_t)2 * (nset * XQ_CGS + XQ_LOPAD) * sizeof(uint2) + (size_t)4 * nset * 2 * 64 * sizeof(uint4) + 4 * 64 * sizeof(float) + 132 * sizeof(float) +
-         (down ? (size_t)(2 * 2 * 4 * X3_TY * (X3_TX / 2)) * sizeof(float) + (size_t)(X3_TX / 2 + X3_TY / 2) * sizeof(float4) : 0);
+         (down ? (size_t)(XQ_DU_SLOTS * XQ_DU_PLANE) * sizeof(float) + (size_t)(X3_TX / 2 + X3_TY / 2) * sizeof(float4) : 0);
 }
 
 // the shapes conv3d_x3_kernel<float, NSET, NSET, *> serves (x3_launch decides eligibility and the work list)

@@ -20,6 +20,9 @@ with ops.conv_precision("f16x3"):
     pa, pb = ops.conv3d_k3_pack(r(12, 4, 3, 3, 3)), ops.conv3d_k3_pack(r(12, 4, 3, 3, 3))
     y = torch.empty((1, 12) + shape[1:], device=dev)
     tl = [ops.Tail(r(4, 12), r(4).abs() + 0.5, r(4), True, tails_out, 4 * k, g4=g4) for k in range(2)]
+    if len(sys.argv) > 3 and sys.argv[3] == "down":      # cell 1's launch: one full-resolution tail + the two down-sampling tails of cell 3
+        half = torch.empty((1, 8, 32, 64, 208), device=dev)
+        tl = tl[:1] + [ops.Tail(r(4, 12), r(4).abs() + 0.5, r(4), True, half, 4 * k, down=True) for k in range(2)]
     sa, ha, sb, hb = r(12).abs() + 0.5, r(12), r(12).abs() + 0.5, r(12)
     for _ in range(300):
         ops.conv3d_k3_dual(x8, 4, pa, sa, ha, pb, sb, hb, 12, True, y, tails=tl, store_main=not nomain, x_g4=g4)
