@@ -130,6 +130,60 @@ class K3Profiler:
         return by
 
 
+def roofline_of(by, args, dt, graphed, steps=None, f32_dtype_is_split=True):
+    """`roofline` object of the dominant 3x3x3 convolution kernel of a profiled pass (K3Profiler.summary()): the kernel with the largest
+    share of the per-kernel HIP-event time, priced against the LARGER of its two floors (HBM: algorithmic bytes / 8 TB/s; matrix
+    cores: the MFMA flops it must issue / dense peak of the form it issues).  dt = seconds of the `steps` timed steps."""
+    steps = steps or args.steps
+    dom_key = max(by, key=lambda k: by[k][0]) if by else None
+    if dom_key is None:
+        return None
+    secs, flops, nbytes, nlaunch = by[dom_key]
+    groups, log_tx, rows, nset = dom_key
+    ach = flops / secs * 1e-12
+    x3 = log_tx == "x3"
+    if x3 and groups[0] == 2 and nset == 2 and args.dtype != "bf16":
+        kname = "conv3d_x3q_kernel<2,"       # the level-3 dual cells (conv3d_x3q.hip): every tail / layout instantiation
+    else:
+        kname = (f"conv3d_x3_kernel<{groups[0]}, {nset}>" if x3 else f"conv3d_k3_kernel<{groups[0]}, {log_tx}, {rows}, {nset}, 2, 0>")
+    peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
+    # which roof bounds this kernel: the larger of its two floors per launch — HBM: algorithmic bytes / 8 TB/s;
+    # matrix cores: the MFMA flops it must ISSUE / dense peak (the split form issues 3 16-bit MFMAs per fp32
+    # product, 2 with bf16 activation storage; row / K padding not counted)
+    issue = (2.0 if args.dtype == "bf16" else 3.0) if x3 else 1.0
+    t_hbm = (nbytes / nlaunch) / (PEAK_HBM_GBS * 1e9)
+    t_mfma = issue * (flops / nlaunch) / (peak * 1e12)
+    traffic, traffic_src = pmc_traffic_bytes(kname)
+    common = {"traffic": traffic,
+              "traffic_source": (f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
+                                 "not measured in this run)") if traffic_src else None,
+              "algorithmic_bytes_per_launch": nbytes / nlaunch,
+              "launches_per_step": nlaunch // steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
+              "avg_launch_us_source": ("HIP events around each launch in an eager pass of the same kernels on the same stream right "
+                                       "after the timed hipGraph replays (a launch inside the replayed graph is 10-20 % shorter: "
+                                       "profiles/r05*_warm_timeline.txt)" if graphed else
+                                       "HIP events around each launch inside the timed region (eager launches)"),
+              "flops_per_launch": flops / nlaunch, "share_of_step": round(secs / steps / (dt / steps), 3),
+              "floor_us": {"hbm": round(t_hbm * 1e6, 1), "mfma": round(t_mfma * 1e6, 1)}}
+    if t_hbm >= t_mfma:
+        gbs = nbytes / secs * 1e-9
+        roofline = {"kernel": kname + " *>" if kname.endswith(",") else kname, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), **common,
+                    "mfma": {"achieved_tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4)}}
+    else:
+        roofline = {"kernel": kname + " *>" if kname.endswith(",") else kname, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), **common}
+    if x3:
+        roofline["note"] = ("fp32 convolution on the 16-bit matrix cores (scaled fp16 halves: hi*hi + hi*lo + lo*hi, fp32 accumulate). Its HBM "
+                            "floor (input once + output once at 8 TB/s) is above its MFMA floor (3 16x16x32 MFMAs per product at "
+                            "the 2.5 PFLOP/s dense peak), so HBM is the roof it is priced against; `mfma` = ALGORITHMIC fp32 "
+                            f"flops / time against the bf16 dense peak ({ach / PEAK_FP32_MFMA_TFLOPS:.2f} of the fp32 matrix peak 157.3). "
+                            "Neither roof binds it, nor does instruction issue: in-kernel stamps, the clock it holds (2.1 GHz) and "
+                            "switch-off builds are in profiles/r05_x3_stamps.md (matrix pipe ~40 % busy; chains of short dependent phases "
+                            "per workgroup, two workgroups per CU overlapping 1.39x).")
+    return roofline
+
+
 def pmc_traffic_bytes(kernel_name: str):
     """(HBM bytes per launch of `kernel_name`, source file) from the newest committed rocprofv3 PMC summary
     (profiles/r*_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same bench command).
@@ -684,6 +738,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (configs object)")
     ap.add_argument("--hw", default=None, help="HxW of the stereo pairs, multiples of 12 (default 384x1248 = configs[1]; configs[3]: "
                                                "480x960 with --batch 8)")
+    ap.add_argument("--precision", choices=["f16x3", "fp32"], default=None,
+                    help="arithmetic contract of the 3x3x3 convolutions of the TIMED path (default: the library's default, f16x3); fp32 = "
+                         "the strict leg as the headline (profiling passes of the strict path: tools/collect_profiles.sh)")
     ap.add_argument("--dry-ranks", action="store_true", help="rank plumbing only (no GPU): every rank reports rank / world / device / seed")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -714,6 +771,8 @@ def main():
 
     import rag_amd
     rag_amd.load_library()          # fail loudly if the HIP extension is missing
+    if args.precision:
+        rag_amd.ops.set_conv_precision(args.precision)
     if args.train:
         line = train_leg(device, dist, rank, n_gpus, args.batch if args.batch > 1 else TRAIN_B, args.steps, args.warmup, bool(args.graph),
                          args.train_precision, with_cpu=not args.no_cpu_baseline)
@@ -772,59 +831,8 @@ def main():
     if rank == 0:
         torch.cuda.synchronize()
         by = prof.summary()
-        dom_key = max(by, key=lambda k: by[k][0]) if by else None
-        roofline = None
-        if dom_key is not None:
-            secs, flops, nbytes, nlaunch = by[dom_key]
-            groups, log_tx, rows, nset = dom_key
-            ach = flops / secs * 1e-12
-            x3 = log_tx == "x3"
-            kname = (f"conv3d_x3_kernel<{groups[0]}, {nset}>" if x3 else f"conv3d_k3_kernel<{groups[0]}, {log_tx}, {rows}, {nset}, 2, 0>")
-            peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
-            # which roof bounds this kernel: the larger of its two floors per launch — HBM: algorithmic bytes / 8 TB/s;
-            # matrix cores: the MFMA flops it must ISSUE / dense peak (the split form issues 3 16-bit MFMAs per fp32
-            # product, 2 with bf16 activation storage; row / K padding not counted)
-            issue = (2.0 if args.dtype == "bf16" else 3.0) if x3 else 1.0
-            t_hbm = (nbytes / nlaunch) / (PEAK_HBM_GBS * 1e9)
-            t_mfma = issue * (flops / nlaunch) / (peak * 1e12)
-            traffic, traffic_src = pmc_traffic_bytes(kname)
-            common = {"traffic": traffic,
-                      "traffic_source": (f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
-                                         "not measured in this run)") if traffic_src else None,
-                      "algorithmic_bytes_per_launch": nbytes / nlaunch,
-                      "launches_per_step": nlaunch // args.steps, "avg_launch_us": round(secs / nlaunch * 1e6, 2),
-                      "avg_launch_us_source": ("HIP events around each launch in an eager pass of the same kernels on the same stream right "
-                                               "after the timed hipGraph replays" if graph is not None else
-                                               "HIP events around each launch inside the timed region (eager launches)"),
-                      "flops_per_launch": flops / nlaunch, "share_of_step": round(secs / args.steps / (dt / args.steps), 3),
-                      "floor_us": {"hbm": round(t_hbm * 1e6, 1), "mfma": round(t_mfma * 1e6, 1)}}
-            if t_hbm >= t_mfma:
-                gbs = nbytes / secs * 1e-9
-                roofline = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": round(gbs / PEAK_HBM_GBS, 4), **common,
-                            "mfma": {"achieved_tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4)}}
-            else:
-                roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                            "frac": round(ach / peak, 4), **common}
-            if x3:
-                roofline["note"] = ("fp32 convolution on the 16-bit matrix cores (scaled fp16 halves: hi*hi + hi*lo + lo*hi, fp32 accumulate). Its HBM "
-                                    "floor (input once + output once at 8 TB/s) is above its MFMA floor (3 16x16x32 MFMAs per product at "
-                                    "the 2.5 PFLOP/s dense peak), so HBM is the roof it is priced against; `mfma` = ALGORITHMIC fp32 "
-                                    f"flops / time against the bf16 dense peak ({ach / PEAK_FP32_MFMA_TFLOPS:.2f} of the fp32 matrix peak 157.3). "
-                                    "What actually bounds it is neither roof but the SIMDs' issue port (DESIGN.md 4.3): vector and matrix instructions of "
-                                    "the four waves of a SIMD issue one after the other; see `issue_model`.")
-                if groups[0] == 2 and nset == 2 and args.dtype != "bf16" and args.batch == 1 and args.hw is None:
-                    # per wave and plane step of the shipped dual-cell loop (tools/isa_mix.py "conv3d_x3_kernel<float, 2, 2, 1>" --loop):
-                    # vector instructions, split-product MFMAs (16x16x32, ~20 cycles of a 2.4 GHz clock sustained: tools/probe_mfma_bf16.hip),
-                    # fp32 tail MFMAs (16x16x4, ~40 cycles); 4 waves per SIMD; plane steps per workgroup = depth segment + 3 ring planes
-                    vec, mf16, mf32 = 183, 48, 8
-                    cyc = 4 * (vec * 4 + mf16 * 20 + mf32 * 40)
-                    steps_per_wg = 32 + 3
-                    t_issue = cyc * steps_per_wg / 2.4e9
-                    roofline["issue_model"] = {"vector_per_wave_step": vec, "mfma_16x16x32_per_wave_step": mf16, "mfma_16x16x4_f32_per_wave_step": mf32,
-                                               "cycles_per_plane_step_per_simd": cyc, "plane_steps_per_workgroup": steps_per_wg,
-                                               "floor_us": round(t_issue * 1e6, 1), "frac": round(t_issue / (secs / nlaunch), 3),
-                                               "what": "issue cycles of one SIMD for one launch at the headline shape (one work item per resident workgroup) / measured launch time"}
+        roofline = roofline_of(by, args, dt, graph is not None)
+        if by:
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
                 log(f"  conv3d {'x3 (split operands) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
                     f"{f_ / s_ * 1e-12:.1f} TFLOP/s, {b_ / s_ * 1e-9:.0f} GB/s (in+out)")
@@ -855,8 +863,17 @@ def main():
                 torch.cuda.synchronize()
                 dt32 = (time.perf_counter() - t0) / n32
                 out32 = cap32 if g32 is not None else out32
+                # its own roofline: per-kernel HIP events of an eager pass of the same kernels under the strict contract
+                prof.records.clear()
+                prof.enabled = True
+                for _ in range(n32):
+                    step()
+                torch.cuda.synchronize()
+                prof.enabled = False
+                strict_roofline = roofline_of(prof.summary(), args, dt32 * n32, g32 is not None, steps=n32)
             strict = {"value_fp32_mfma": round(B / dt32, 3), "ms_per_step": round(dt32 * 1e3, 4), "steps": n32,
-                      "what": "same workload, ops.set_conv_precision('fp32'): every 3x3x3 contraction on v_mfma_f32_4x4x1 (exact fmaf chains)"}
+                      "what": "same workload, ops.set_conv_precision('fp32'): every 3x3x3 contraction on v_mfma_f32_4x4x1 (exact fmaf chains)",
+                      "roofline": strict_roofline}
             if cpu is not None:
                 strict["epe_gpu_vs_cpu_px"] = O.epe(out32[:1].float().cpu(), ref)
             log(f"  strict fp32 MFMA: {strict['value_fp32_mfma']} maps/s, EPE {strict.get('epe_gpu_vs_cpu_px')}")
