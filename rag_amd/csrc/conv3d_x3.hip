@@ -92,13 +92,24 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // (every descriptor array of the kernel arguments below is indexed by a COMPILE-TIME index in an unrolled loop, the lanes pick by
   // comparison: indexed by a lane-dependent value the compiler fetches the pointer itself with a vector load from the argument
   // segment and the value with a second, dependent one — ~25 serial memory round trips in front of the first plane of a launch)
+  // (and all loads of a set first, then its LDS stores: as load -> store per element the loop waits out a memory round trip per
+  // iteration, up to eleven of them for the 22 KB of a 12-channel set)
 #pragma unroll
   for (int set = 0; set < NSET; ++set) {
     const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set] + (int64_t)cog * NSLS * 2 * 64);
-    for (int i = tid; i < NSLS * 2 * 64 * 2; i += X3_THREADS) {
-      const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, s = sh >> 1;
-      const int p = x3_pair_perm(NCGS, s, 2 * (ln >> 4) + j);
-      reinterpret_cast<uint2*>(lw)[set * (NSLS * 2 * 64 * 2) + i] = src[((sh * 64) + (p >> 1) * 16 + (ln & 15)) * 2 + (p & 1)];
+    constexpr int PER_SET = NSLS * 2 * 64 * 2, ITER = (PER_SET + X3_THREADS - 1) / X3_THREADS;
+    uint2 wv[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = min(it * X3_THREADS + tid, PER_SET - 1);
+      const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, sl = sh >> 1;
+      const int p = x3_pair_perm(NCGS, sl, 2 * (ln >> 4) + j);
+      wv[it] = src[((sh * 64) + (p >> 1) * 16 + (ln & 15)) * 2 + (p & 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = it * X3_THREADS + tid;
+      if (i < PER_SET) reinterpret_cast<uint2*>(lw)[set * PER_SET + i] = wv[it];
     }
   }
   for (int i = tid; i < 3 * NSL * 4; i += X3_THREADS) {
@@ -608,10 +619,22 @@ __global__ __launch_bounds__(W16 ? 1024 : XD_THREADS, W16 ? 1 : (WS ? 4 : 2)) vo
   // weight fragments of this workgroup's output blocks, as packed (tap-major pairs: lane quarter kb of slice s holds the 8 channels
   // 8 (kb & 1) .. +7 of tap 2 s + (kb >> 1) for 16 channels per set, all 8 channels of tap 4 s + kb for 8)
   constexpr int NWS = COGS * NSLS * 2 * 64;              // uint4 words of one set's fragments
+  // (all loads of a set first, then the LDS stores: written as load -> store per element the loop waits out one L2 round trip per
+  // iteration — four to seven of them in front of the first box of every deep-level launch)
   auto wcopy = [&](int set, int region) {
-    for (int i = tid; i < NWS; i += THREADS) {
+    constexpr int ITER = (NWS + THREADS - 1) / THREADS;
+    uint4 wv[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = min(it * THREADS + tid, NWS - 1);
       const int cl = i / (NSLS * 2 * 64), r = i % (NSLS * 2 * 64);
-      lw[region * NWS + i] = cog0 + cl < ncog ? e.wf[set][(int64_t)(cog0 + cl) * NSLS * 2 * 64 + r] : make_uint4(0u, 0u, 0u, 0u);
+      const uint4 v = e.wf[set][(int64_t)min(cog0 + cl, ncog - 1) * NSLS * 2 * 64 + r];      // (unconditional, clamped: no branch between the loads)
+      wv[it] = cog0 + cl < ncog ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = it * THREADS + tid;
+      if (i < NWS) lw[region * NWS + i] = wv[it];
     }
   };
 #ifdef RAGMI_DIAG
@@ -712,12 +735,13 @@ __global__ __launch_bounds__(W16 ? 1024 : XD_THREADS, W16 ? 1 : (WS ? 4 : 2)) vo
   for (int set = 0; set < NSET; ++set) {
     const float* const psc = a.scale[set];
     const float* const psh = a.shift[set];
-    for (int i = tid; i < COGS * 16; i += THREADS) {
-      const int co = cog0 * 16 + i;
-      float sc = (co < a.Cout && psc) ? psc[co] : 1.f;
-      if constexpr (!BF) sc *= (co < a.Cout ? e.wmul[set][co] : 1.f);          // undo the per-channel weight scale 2^k
-      par[set * COGS * 16 + i] = sc;
-      par[NSET * COGS * 16 + set * COGS * 16 + i] = (co < a.Cout && psh) ? psh[co] : 0.f;
+    if (tid < COGS * 16) {      // (THREADS >= 512 > COGS * 16; loads unconditional and clamped: no branch, one wait for all of them)
+      const int co = cog0 * 16 + tid, cc = min(co, a.Cout - 1);
+      const float vsc = psc ? psc[cc] : 1.f, vsh = psh ? psh[cc] : 0.f;
+      float sc = co < a.Cout ? vsc : 1.f;
+      if constexpr (!BF) { const float wm = e.wmul[set][cc]; sc *= (co < a.Cout ? wm : 1.f); }          // undo the per-channel weight scale 2^k
+      par[set * COGS * 16 + tid] = sc;
+      par[NSET * COGS * 16 + set * COGS * 16 + tid] = co < a.Cout ? vsh : 0.f;
     }
   }
   if (tid < 3) lmaxp[tid] = 0u;

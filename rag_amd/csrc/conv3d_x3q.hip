@@ -93,21 +93,31 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
 #endif
   // weight fragments, 8 bytes (one pair's four channels) at a time, from the packed tap-major slices (x3_pack_one: pair P = tap, one
   // channel group per set) into this kernel's slices: [set][plane 0..2 | leftover]
+  {
+    // (all loads of the staging first, then the LDS stores: written as load -> store per element the loop waits out one memory round
+    // trip per iteration; compile-time `set`: e.wf[set] stays a scalar — see the parameters below)
+    constexpr int PER_SET = 4 * 2 * 64 * 2, ITER = PER_SET / X3_THREADS;
+    static_assert(PER_SET % X3_THREADS == 0, "weight staging: whole rounds");
+    uint2 wv[NSET][ITER];
 #pragma unroll
-  for (int set = 0; set < NSET; ++set) {          // (compile-time `set`: e.wf[set] stays a scalar — see the parameters below)
-    const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set] + (int64_t)cog * 4 * 2 * 64);
-    for (int i = tid; i < 4 * 2 * 64 * 2; i += X3_THREADS) {
-      const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, hl = sh & 1, sl = sh >> 1, q = ln >> 4;
-      int tap = -1;
-      if (sl < 3) { if (!xq_pad7(q, j)) tap = sl * 9 + xq_tap7(q, j); }
-      else if (q < 3) tap = q * 9 + 4 + j;
-      uint2 v = make_uint2(0u, 0u);
-      if (tap >= 0) {
-        const int ps = tap >> 3, pp = tap & 7;
-        v = src[(((ps * 2 + hl) * 64) + (pp >> 1) * 16 + (ln & 15)) * 2 + (pp & 1)];
+    for (int set = 0; set < NSET; ++set) {
+      const uint2* const src = reinterpret_cast<const uint2*>(e.wf[set] + (int64_t)cog * 4 * 2 * 64);
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int i = it * X3_THREADS + tid;
+        const int j = i & 1, ln = (i >> 1) & 63, sh = i >> 7, hl = sh & 1, sl = sh >> 1, q = ln >> 4;
+        int tap = -1;
+        if (sl < 3) { if (!xq_pad7(q, j)) tap = sl * 9 + xq_tap7(q, j); }
+        else if (q < 3) tap = q * 9 + 4 + j;
+        const int ps = max(tap, 0) >> 3, pp = max(tap, 0) & 7;
+        const uint2 v = src[(((ps * 2 + hl) * 64) + (pp >> 1) * 16 + (ln & 15)) * 2 + (pp & 1)];      // (unconditional: a padding slot reads tap 0 and drops it)
+        wv[set][it] = tap >= 0 ? v : make_uint2(0u, 0u);
       }
-      reinterpret_cast<uint2*>(lw)[set * (4 * 2 * 64 * 2) + i] = v;
     }
+#pragma unroll
+    for (int set = 0; set < NSET; ++set)
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) reinterpret_cast<uint2*>(lw)[set * PER_SET + it * X3_THREADS + tid] = wv[set][it];
   }
   // Parameters -> LDS.  Every descriptor array of the kernel arguments is indexed by a COMPILE-TIME index inside an unrolled loop and
   // the lanes pick by comparison: indexed by a lane-dependent value (set = i >> 4, tail = row >> 2) the compiler fetches the pointer
@@ -390,15 +400,17 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
     if constexpr (TAILS == 2) {
       if (z > zs && !(z & 1)) down_finish(z - 1);      // planes z-2, z-1 of the x-blended tail values are complete (segments start even)
     }
-    note_overflow(PH & 1);
-    commit((PH + 2) & 3);                // plane z+2, first read at step z+1
     // (workgroup-uniform: the word of step z-1 holds the notes of the commits BEFORE the barrier above and is not written during this
     // step.  No restart once the scale sits at its floor: an Inf — or an operand above ~2^110 — can never be made to fit; such inputs
     // give non-finite outputs, include/rag_amd.h)
     if (lmaxp[1 + ((PH + 1) & 1)] != 0u && __float_as_uint(mul) > X3_SCALE_FLOOR_BITS) return true;
+#ifdef XQ_COMMIT_FIRST
+    note_overflow(PH & 1);
+    commit((PH + 2) & 3);                // plane z+2, first read at step z+1
     XQ_STAMP(1);
     prefetch(z + 3);                 // unconditional (addresses clamped): straight-line code ahead of the MFMA block
     __builtin_amdgcn_sched_barrier(0);
+#endif
     XQ_STAMP(3);
 #pragma unroll
     for (int st = 0; st < NSET; ++st)
@@ -431,6 +443,18 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
       for (int i = 0; i < X3_NT; ++i) acc[st][i] = x3_mma<false>(al, bh[i], acc[st][i]);
     }
     XQ_STAMP(4);
+#ifndef XQ_COMMIT_FIRST
+    // Plane z+2 (in the registers since step z-1) goes to the ring AFTER the matrix block, not in front of it: vmcnt counts loads and
+    // stores together and in order, and across the loop's back edge the compiler can only wait for vmcnt(0) — in front of the matrix
+    // block that wait also sat out the acknowledgement of the stores the previous epilogue had issued a few hundred cycles earlier,
+    // on the critical path of the slowest wave behind every barrier.  Here loads and stores are a matrix block old.
+    __builtin_amdgcn_sched_barrier(0);
+    note_overflow(PH & 1);
+    commit((PH + 2) & 3);                // plane z+2, first read at step z+1 (its slot was plane z-2's: free since the barrier above)
+    XQ_STAMP(1);
+    prefetch(z + 3);                     // unconditional (addresses clamped); consumed a whole step later
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     epilogue(z);
     XQ_STAMP(5);
 #ifdef RAGMI_DIAG
