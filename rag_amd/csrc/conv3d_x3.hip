@@ -769,6 +769,9 @@ __global__ __launch_bounds__(W16 ? 1024 : XD_THREADS, W16 ? 1 : (WS ? 4 : 2)) vo
     static_for<NSET>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
       float mul = 1.f;
+      // (nothing of this stage may move up into the previous stage's MFMA block: hipcc hoisted the maximum of the values that block's
+      // prefetch had just requested into it — an s_waitcnt vmcnt on loads a few instructions old, a memory round trip per stage)
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (!BF) {
         // the box's operand scale: its largest |x| lands at 2^13..2^14 (exact maximum: no headroom needed).  Slot k % 3 of three:
         // the slot of stage k + 2 is cleared behind this stage's second barrier, two barriers ahead of its next use
