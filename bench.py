@@ -193,9 +193,12 @@ def pmc_traffic_bytes(kernel_name: str):
     import re
     base = re.sub(r"[<(].*", "", kernel_name)
     targs = kernel_name[len(base):].strip("<>").replace(" ", "")
-    # newest first: tags run r04a .. r04z, r04aa .. (a longer tag is a later one)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")),
-                       key=lambda q: (len(os.path.basename(q).split("_")[0]), os.path.basename(q)), reverse=True):
+    # newest first: the round number, then the letter suffix of the tag (r04a .. r04z, r04aa ..: a longer suffix is a later one)
+    def age(q):
+        tag = os.path.basename(q).split("_")[0]
+        m = re.match(r"r(\d+)(.*)", tag)
+        return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (-1, 0, tag)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=age, reverse=True):
         try:
             with open(path) as f:
                 table = json.load(f)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counter passes of the dominant kernel (conv3d_x3_kernel<2,2>, tools/x3_dual_one.py): where the waves' cycles go.
+# SQ counter passes of the dominant kernel (the level-3 dual launch: conv3d_x3q_kernel<2, *>, tools/x3_dual_one.py): where the waves' cycles go.
 #   bash tools/sq_counters.sh r03b      (through gpurun, from the repo root; writes gpurun_out/<tag>_sq_counters.txt)
 # Counters (MI355X_MICROARCH.md, rocprofv3 PMC slots): SQ_WAVE_CYCLES ~ SQ_WAIT_ANY (parked: s_waitcnt / barrier) + SQ_WAIT_INST_ANY
 # (issue stall) + SQ_ACTIVE_INST_ANY; SQ_WAIT_INST_LDS is a sub-bucket of the issue stalls; LDS array cycles and conflicts.
@@ -17,7 +17,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv3d_x3_kernel" not in r["Kernel_Name"]:
+        if "conv3d_x3" not in r["Kernel_Name"]:
             continue
         a = acc[r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
