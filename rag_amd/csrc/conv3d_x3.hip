@@ -340,8 +340,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         if (Y < Ho && X < Wo && Z < Do && r < dcout) {
           T* const dy = static_cast<T*>(dl ? a.down_y[1] : a.down_y[0]) + b * (dl ? a.down_bstride[1] : a.down_bstride[0]) +
                         (int64_t)((dl ? a.down_ch0[1] : a.down_ch0[0]) + r) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
-          const float ye = lerp2(yt.x, e0, yt.y, e1), yo = lerp2(yt.x, o0, yt.y, o1);
-          const float uu = fmaf(lerp2(wz0, ye, wz1, yo), sc, sh);
+          const bool yclamp = yt.z != 0.f, zclamp = lz.i0 != 2 * Z;      // clamped pairs read the odd source twice
+          const float ye = lerp2(yt.x, yclamp ? e1 : e0, yt.y, e1), yo = lerp2(yt.x, yclamp ? o1 : o0, yt.y, o1);
+          const float uu = fmaf(lerp2(wz0, zclamp ? yo : ye, wz1, yo), sc, sh);
           st(dy, drelu ? fmaxf(uu, 0.f) : uu);
         }
       }
@@ -377,7 +378,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         const LinIdx l = lin_index(min(o, (in >> 1) - 1), in, in >> 1, isx ? e.dsw : e.dsh, 1);
         // the pair (source 2o, source 2o+1) with weights (w0, w1); where the last output of an axis clamps (i0 = i1 = 2o+1, fp32
         // source index a hair above in-1) the reference blends the odd source with itself: weights (0, 1)
-        const float4 ent = l.i0 == 2 * o ? make_float4(l.w0, l.w1, 0.f, 0.f) : make_float4(0.f, 1.f, 0.f, 0.f);
+        // (.z != 0: the clamped pair — BOTH taps are the odd source, as in the reference; blending the even one with weight 0 would turn
+        // a non-finite even source into NaN where the reference stays finite: ADVICE r04)
+        const float4 ent = l.i0 == 2 * o ? make_float4(l.w0, l.w1, 0.f, 0.f) : make_float4(0.f, 1.f, 1.f, 0.f);
         if (isx) ldxt[tid] = ent; else ldyt[tid - X3_TX / 2] = ent;
       }
     }
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
               for (int r = 0; r < 4; ++r) {
                 // w0 * (this lane's value) + w1 * (the next lane's): the row shift rides on the multiply's operand (v_mul_f32_dpp)
                 const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tacc[r]), 0x101, 0xF, 0xF, false));   // row_shl:1
-                ux[r] = lerp2(xt.x, tacc[r], xt.y, p1);
+                ux[r] = lerp2(xt.x, xt.z != 0.f ? p1 : tacc[r], xt.y, p1);
               }
               if (!(n & 1))
                 reinterpret_cast<float4*>(ldu)[(((z & 1) * 2 + dl) * X3_TY + (nt >> 1)) * (X3_TX / 2) + 8 * (nt & 1) + (n >> 1)] =

@@ -309,8 +309,9 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
         if (Y < Ho && X < Wo && Z < Do && r < dcout) {
           T* const dy = static_cast<T*>(dl ? a.down_y[1] : a.down_y[0]) + b * (dl ? a.down_bstride[1] : a.down_bstride[0]) +
                         (int64_t)((dl ? a.down_ch0[1] : a.down_ch0[0]) + r) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
-          const float ye = lerp2(yt.x, e0, yt.y, e1), yo = lerp2(yt.x, o0, yt.y, o1);
-          const float uu = fmaf(lerp2(wz0, ye, wz1, yo), sc, sh);
+          const bool yclamp = yt.z != 0.f, zclamp = lz.i0 != 2 * Z;      // clamped pairs read the odd source twice
+          const float ye = lerp2(yt.x, yclamp ? e1 : e0, yt.y, e1), yo = lerp2(yt.x, yclamp ? o1 : o0, yt.y, o1);
+          const float uu = fmaf(lerp2(wz0, zclamp ? yo : ye, wz1, yo), sc, sh);
           st(dy, drelu ? fmaxf(uu, 0.f) : uu);
         }
       }
@@ -331,10 +332,12 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
   // epilogue of plane z: lane holds channels 4 g + reg (g = cog*4 + kb) of voxel n of each column tile
   auto epilogue = [&](int z) {
     const int ybase = z * HW * (int)sizeof(T);      // wave-uniform
+    // BatchNorm + ReLU + sum of the sets for BOTH column tiles first, then the two tiles' tail products INTERLEAVED (product r of tile
+    // 0, of tile 1, r + 1 ...: a dependent chain of four fp32 MFMAs per tile, 40 cycles of latency a link — issued tile after tile
+    // the second chain waited out the first), the stores last.
+    float v[X3_NT][4];
 #pragma unroll
-    for (int i = 0; i < X3_NT; ++i) {
-      const int nt = wave * X3_NT + i;
-      float v[4];
+    for (int i = 0; i < X3_NT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float sum = 0.f;
@@ -343,24 +346,38 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
           const float u = fmaxf(fmaf(acc[st][i][r], par[st * 16 + 4 * kb + r], par[32 + st * 16 + 4 * kb + r]), act_floor);
           sum = st == 0 ? u : sum + u;
         }
-        v[r] = sum;
+        v[i][r] = sum;
       }
-      if (a.store_main && inside[i] && g < ngroups && !(dg_nostore && v[0] != 12345.f)) {
+    f32x4 tacc[X3_NT];
+    if constexpr (TAILS) {
+#pragma unroll
+      for (int i = 0; i < X3_NT; ++i) tacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float wt = ltail[r * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < X3_NT; ++i) tacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt, v[i][r], tacc[i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < X3_NT; ++i) {
+      if (a.store_main && inside[i] && g < ngroups && !(dg_nostore && v[i][0] != 12345.f)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, (int)yoff[i], ybase + r * (int)DHW * (int)sizeof(T), 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i][r]), yrs, (int)yoff[i], ybase + r * (int)DHW * (int)sizeof(T), 0);
       }
-      if constexpr (TAILS) {
-        f32x4 tacc = {0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (TAILS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ltail[r * 64 + lane], v[r], tacc, 0, 0, 0);
-        if (my_tail_cout > 0 && inside[i] && !(dg_nostore && tacc[0] != 12345.f)) {
+      for (int i = 0; i < X3_NT; ++i) {
+        const int nt = wave * X3_NT + i;
+        if (my_tail_cout > 0 && inside[i] && !(dg_nostore && tacc[i][0] != 12345.f)) {
           const float4 tsc = *reinterpret_cast<const float4*>(par + 64 + 4 * kb), tsh = *reinterpret_cast<const float4*>(par + 80 + 4 * kb);
           const float sc4[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, sh4[4] = {tsh.x, tsh.y, tsh.z, tsh.w};
           float u4[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {      // (xq_takes: every fused tail has exactly four output channels)
-            const float u = fmaf(tacc[r], sc4[r], sh4[r]);
+            const float u = fmaf(tacc[i][r], sc4[r], sh4[r]);
             u4[r] = my_trelu ? fmaxf(u, 0.f) : u;
           }
           if constexpr (G4T) {
@@ -378,8 +395,8 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
             float ux[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tacc[r]), 0x101, 0xF, 0xF, false));   // row_shl:1
-              ux[r] = lerp2(xt.x, tacc[r], xt.y, p1);
+              const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tacc[i][r]), 0x101, 0xF, 0xF, false));   // row_shl:1
+              ux[r] = lerp2(xt.x, xt.z != 0.f ? p1 : tacc[i][r], xt.y, p1);
             }
             if (!(n & 1))
               reinterpret_cast<float4*>(ldu + (z % 3) * XQ_DU_PLANE)[(dl * X3_TY + (nt >> 1)) * (X3_TX / 2) + 8 * (nt & 1) + (n >> 1)] =
@@ -462,6 +479,10 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
 #endif
     return false;
   };
+#ifdef XQ_PHASE_OFFSET
+  // experiment: the two workgroups of a CU (dispatched a grid-half apart) start half a plane step apart
+  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(XQ_PHASE_OFFSET);
+#endif
   const int chunk = (e.nwork + 7) / 8;
   for (int j = blockIdx.x; j < chunk * 8; j += gridDim.x) {
     const int work = (j & 7) * chunk + (j >> 3);
@@ -503,7 +524,9 @@ __global__ __launch_bounds__(X3_THREADS, 4) void conv3d_x3q_kernel(K3Args a, X3E
         const bool isx = tid < X3_TX / 2;
         const int o = isx ? (x0 >> 1) + tid : (y0 >> 1) + (tid - X3_TX / 2), in = isx ? a.W : a.H;
         const LinIdx l = lin_index(min(o, (in >> 1) - 1), in, in >> 1, isx ? e.dsw : e.dsh, 1);
-        const float4 ent = l.i0 == 2 * o ? make_float4(l.w0, l.w1, 0.f, 0.f) : make_float4(0.f, 1.f, 0.f, 0.f);
+        // (.z != 0: the clamped pair — BOTH taps are the odd source, as in the reference; blending the even one with weight 0 would turn
+        // a non-finite even source into NaN where the reference stays finite: ADVICE r04)
+        const float4 ent = l.i0 == 2 * o ? make_float4(l.w0, l.w1, 0.f, 0.f) : make_float4(0.f, 1.f, 1.f, 0.f);
         if (isx) ldxt[tid] = ent; else ldyt[tid - X3_TX / 2] = ent;
       }
     }

@@ -1598,3 +1598,32 @@ def test_matchingnet_g4_plan_and_bitwise(ra, x3_on, hwd):
     finally:
         ra.ops.set_g4(True)
     assert torch.equal(outs[True], outs[False])
+
+
+def test_x3_down_tail_clamped_pair_ignores_a_non_finite_even_source(ra, x3_on):
+    """Where the last output of an axis clamps, the x0.5 trilinear resample (align_corners=True, rag_model.py:146-150) reads the ODD source
+    for both taps: a non-finite value in the even source next to it must not reach that output (0 * Inf = NaN).  D = 16:
+    output plane 7 reads source plane 15 twice; an Inf in input plane 13 makes the producer's planes 12..14 non-finite and leaves 15 alone."""
+    B, D, H, W = 1, 16, 128, 128
+    C, cout = 4, 12
+    g1 = gen(551)
+    x = torch.randn((B, 2 * C, D, H, W), generator=g1)
+    x[0, 1, 13, 40, 50] = float("inf")
+    wa, wb = (torch.randn((cout, C, 3, 3, 3), generator=g1) * 0.2 for _ in range(2))
+    tw = torch.randn((8, cout), generator=g1) * 0.3
+    out = torch.full((B, 8, D // 2, H // 2, W // 2), float("nan"), device=DEV)
+    gw = gpu(tw)
+    tails = [ra.ops.Tail(gw[c0:c0 + 4], None, None, False, out, c0, down=True) for c0 in (0, 4)]
+    y = torch.empty((B, cout, D, H, W), device=DEV)
+    with ra.ops.conv_precision("f16x3"):
+        # (no ReLU: max(NaN, 0) = 0 would hide the non-finite planes the test needs)
+        ra.ops.conv3d_k3_dual(gpu(x), C, ra.ops.conv3d_k3_pack(gpu(wa)), None, None, ra.ops.conv3d_k3_pack(gpu(wb)), None, None, cout, False, y, tails=tails)
+    yc = y.cpu()
+    assert not torch.isfinite(yc[0, :, 14, 40, 50]).all() and torch.isfinite(yc[0, :, 15]).all()
+    got = out.cpu()
+    assert torch.isfinite(got[:, :, 7]).all()                      # the clamped plane: odd source only
+    assert not torch.isfinite(got[:, :, 6, 20, 25]).all()          # the plane below reads (12, 13): non-finite, as in the reference
+    main = F.conv3d(x[:, :C], wa, padding=1) + F.conv3d(x[:, C:], wb, padding=1)
+    ref = torch.einsum("oc,bcdhw->bodhw", tw, F.interpolate(main[:, :, 15:16], (1, H // 2, W // 2), mode="trilinear", align_corners=True))
+    ref = torch.cat([torch.zeros_like(ref)] * 7 + [ref], dim=2)      # (plane 7 = source plane 15 alone; planes 0..6 are not compared)
+    np.testing.assert_allclose(got[:, :, 7].numpy(), ref[:, :, 7].numpy(), rtol=3e-4, atol=3e-4)
