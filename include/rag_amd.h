@@ -389,6 +389,23 @@ int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* vari
                            void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
                            int ntail, const ragmi_tail_t* tails, int dtype, void* stream);
 
+/* stem3d0 AND stem3d1 (rag_model.py:234-235, 341-343: ConvBR_3d(2C, 12, 3, 1, 1) on the cost volume of rag_model.py:375-383, then
+ * ConvBR_3d(12, Cout, 3, 1, 1)) with stem3d0's OUTPUT never written either: ragmi_costvol_stem_fwd's variant planes; its fused tails
+ * (ntail0 consumer 1x1x1 convs of stem3d0's output — cell 0's pre_preprocess, rag_model.py:125,154 — by the combine kernel without its
+ * main store; ragmi_costvol_stem_fwd itself takes y = NULL for that); then stem3d1's 3x3x3 convolution on the z-marching
+ * split-operand kernel, whose halo staging evaluates act(scale0 * (A + B) + shift0) from the planes — the combine kernel's
+ * arithmetic, bit for bit — instead of loading a tensor.  What it saves at the headline shape: a 164 MB write and its read-back
+ * (stem3d0's combine kernel was bound by exactly that write).  RAGMI_F32X3 only, Cmid = 12 (stem3d0's output channels), C <= 12 a
+ * multiple of 4; y / store_main / tails / y_group_ch as ragmi_conv3d_k3_fwd_ex (tails may be RAGMI_TAIL_G4); workspace as
+ * ragmi_costvol_stem_workspace_elems(B, C, Cmid, D, H, W).  ragmi_costvol_stem_conv3d_supported: 1 when the stem3d1 launch of this shape
+ * runs on that kernel. */
+int ragmi_costvol_stem_conv3d_supported(int C, int Cmid, int Cout, int B, int D, int H, int W, int ntail, int dtype);
+int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right, const void* variants, const void* scale0, const void* shift0, int relu0,
+                                  void* workspace, int ntail0, const ragmi_tail_t* tails0,
+                                  const void* packed_weight, const void* scale, const void* shift, int relu,
+                                  void* y, int64_t y_bstride, const int32_t* y_group_ch, int store_main, int ntail, const ragmi_tail_t* tails,
+                                  int B, int C, int Cmid, int Cout, int D, int H, int W, int dtype, void* stream);
+
 /* 1 when ragmi_conv3d_k3_fwd(_ex) (nset = 1) / ragmi_conv3d_k3_dual_fwd(_ex) (nset = 2, Cin = both inputs) called with this
  * dtype (RAGMI_F32X3 or RAGMI_BF16) runs this shape on the 16-bit matrix cores (fp16 / bf16 operands), 0 when it runs on the fp32-MFMA kernel.  Three forms
  * (conv3d_x3.hip, conv2d_x3.hip), all without a residual input and with whole 4-channel groups in and out (Cin % 4 == 0, Cout % 4 == 0): the z-marching form for

@@ -48,6 +48,10 @@ SIGNATURES = {
     "ragmi_costvol_stem_workspace_elems": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ragmi_costvol_stem_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p,
                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_tail_p, c_int, c_void_p]),
+    "ragmi_costvol_stem_conv3d_supported": (c_int, [c_int] * 9),
+    "ragmi_costvol_stem_conv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_tail_p,
+                                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int32_p, c_int, c_int, c_tail_p,
+                                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ragmi_conv3d_k3_uses_x3": (c_int, [c_int] * 10),
     "ragmi_conv3d_k3_g4_caps": (c_int, [c_int] * 10),
     "ragmi_conv3d_k3_packed_elems": (c_int64, [c_int, c_int]),

@@ -41,7 +41,7 @@ static int choose_cfg(int B, int D, int H, int W, int Cout = 0) {
   if (W > 8 && waste(16) <= waste(8) + 1e-9 && vol >= (1 << 17) && !(Cout >= 20 && vol < (1 << 19))) return 1;
   return 2;
 }
-static int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int64_t y_bstride,
+int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int64_t y_bstride,
                        const int32_t* y_group_ch, const void* res, int64_t res_bstride, const int32_t* res_group_ch,
                        int B, int Cin, int Cout, int D, int H, int W, int relu) {
   RAGMI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, RAGMI_EINVAL, "conv3d_k3: non-positive size");
@@ -74,7 +74,7 @@ static bool down2_pairs_aligned(int in_size) {
   return i0 == in_size - 2 || i0 == in_size - 1;
 }
 
-static int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* tails, int Cout) {
+int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* tails, int Cout) {
   a.store_main = 1;
   a.ntail = 0;
   a.ndown = 0;

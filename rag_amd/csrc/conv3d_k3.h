@@ -625,7 +625,12 @@ int c1_launch(const K3Args& k, int dtype, int y_dtype, hipStream_t st);
 int pack_both(const float* w, float* packed, int64_t total_k3, int Cout, int Cin, int transpose, int planar, bool all, hipStream_t s);
 bool x3_eligible(const K3Args& a, int nset, int dtype);
 int x3_g4_caps(const K3Args& a, int nset, int dtype);      // G4 forms (include/rag_amd.h) the kernel this call lands on takes
-int x3_launch(K3Args a, int nset, int dtype, hipStream_t st);
+struct X3StemSrc;
+int x3_launch(K3Args a, int nset, int dtype, hipStream_t st, const X3StemSrc* src = nullptr);
+// argument marshalling of the 3x3x3 entry points (conv3d.hip), shared with ragmi_costvol_stem_conv3d_fwd (costvol_stem.hip)
+int fill_common(K3Args& a, const void* x, int64_t x_bstride, void* y, int64_t y_bstride, const int32_t* y_group_ch, const void* res,
+                int64_t res_bstride, const int32_t* res_group_ch, int B, int Cin, int Cout, int D, int H, int W, int relu);
+int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* tails, int Cout);
 // deep-level bf16x3 form (8 / 16 input channels per set, box tiles): levels 6 and 12
 // depth-1 volumes (the Feature Net's 2-D convolutions) on the split-operand form: conv2d_x3.hip
 bool x2d_eligible(const K3Args& a, int nset, int dtype);

@@ -43,12 +43,16 @@ constexpr int X3_STAMP_WORDS = 16;
 // T = activation storage: float (three MFMAs per product) or bf16_t (the activations ARE bf16: no lo copy, two MFMAs per
 // product — weight hi and lo — and half the LDS operand traffic)
 // TAILS: 0 none, 1 fused consumer 1x1x1 convs at full resolution, 2 also DOWN-SAMPLING ones (see K3Args::ndown and the finishing step)
-// G4X: x is a channel-group-interleaved tensor [B][C/4][D][H][W][4] (include/rag_amd.h, "G4"; fp32 storage): the four channels of
+// XSRC == 1 (G4X): x is a channel-group-interleaved tensor [B][C/4][D][H][W][4] (include/rag_amd.h, "G4"; fp32 storage): the four channels of
 // a halo voxel are ONE 16-byte load.  The tails write G4 destinations when a.tail_g4 says so (one 16-byte store per voxel).
-template <class T, int NCG, int NSET, int TAILS, bool G4X = false>
+// XSRC == 2 (round 5, stem3d1 behind the cost-volume-folded stem3d0): there is NO input tensor — a halo voxel's channels are
+// act(scale0 * (A + B) + shift0) of stem3d0's variant planes (costvol_stem.hip: the arithmetic of its combine kernel, bit for bit),
+// evaluated in the staging; the 164 MB tensor between the two stems is never written or read.
+template <class T, int NCG, int NSET, int TAILS, int XSRC = 0>
 __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
-  static_assert(!G4X || !BF, "G4 tensors are fp32");
+  constexpr bool G4X = XSRC == 1, ABX = XSRC == 2;
+  static_assert(XSRC == 0 || !BF, "G4 tensors and the plane source are fp32");
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
   // LDS row / plane / channel-group strides in records (padded against bank conflicts: conv3d_x3_common.h; staging still enumerates X3_PL voxels)
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // down-sampling tails (TAILS == 2): x-blended tail values of two consecutive planes U[plane parity][down slot 2][8 rows][16][4 ch] |
   // x table [16]{w0, w1: weights of the source pair (2X, 2X+1)} | y table [4]{...}
   float* const ldu = par + 132;
+  float4* const lsrc = reinterpret_cast<float4*>(par + 132);      // XSRC == 2 (no down-sampling tails there): stem3d0's scale[NCG] | shift[NCG] per channel group
   float4* const ldxt = reinterpret_cast<float4*>(ldu + 2 * 2 * 4 * X3_TY * (X3_TX / 2));
   float4* const ldyt = ldxt + X3_TX / 2;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kb = lane >> 4;
@@ -148,6 +153,26 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     par[32 + tid] = sh;
   }
   if (tid < 2) lmaxp[tid] = 0u;
+  if constexpr (ABX) {      // stem3d0's folded BatchNorm per channel group (identity when absent)
+    if (tid < 2 * NCG) {
+      const bool isshift = tid >= NCG;
+      const int cg = isshift ? tid - NCG : tid;
+      const float* const pp = isshift ? e.src.shift : e.src.scale;
+      const float idv = isshift ? 0.f : 1.f;
+      lsrc[tid] = pp ? make_float4(pp[4 * cg], pp[4 * cg + 1], pp[4 * cg + 2], pp[4 * cg + 3]) : make_float4(idv, idv, idv, idv);
+    }
+    if (e.src.ntail > 0 && tid >= 64 && tid < 64 + 4 * NCG + 2) {      // the fused tail: w[0..3][c] per input channel c, then its scale and shift
+      const int c = tid - 64;
+      const float* const tw = e.src.tail_w;
+      const float* const tsc = e.src.tail_scale;
+      const float* const tsh = e.src.tail_shift;
+      float4 q4;
+      if (c < 4 * NCG) q4 = make_float4(tw[c], tw[4 * NCG + c], tw[8 * NCG + c], tw[12 * NCG + c]);
+      else if (c == 4 * NCG) q4 = tsc ? make_float4(tsc[0], tsc[1], tsc[2], tsc[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+      else q4 = tsh ? make_float4(tsh[0], tsh[1], tsh[2], tsh[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      lsrc[2 * NCG + c] = q4;
+    }
+  }
   // Fused consumer 1x1x1 convs ("tails") on the matrix cores: out_t[k][voxel] = sum_c W_t[k][c] * v[c][voxel] as four 16x16x4 fp32
   // products laid out so that every lane quarter feeds ITS OWN four channels (product r: channel 4 kb + r of each quarter), so no
   // value crosses lanes.  Rows: tail 0 -> 0..3, tail 1 -> 4..7, down-sampling tails after them.
@@ -197,7 +222,14 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       par[80 + tid] = sh;
     }
   }
-  float pf[NPF][4];
+  // staging elements of a thread: (channel group, halo voxel) pairs numbered p * X3_THREADS + tid through the groups — or, with the
+  // plane source (XSRC == 2), ALL groups of the ONE voxel tid (threads past the 340 halo voxels stage nothing): the plane addressing
+  // is per voxel, and the voxel's owner has every channel for the fused tail of stem3d0
+  constexpr int NPE = ABX ? NCG : NPF;
+  auto el_cg = [&](int p) { return ABX ? p : (p * X3_THREADS + tid) / X3_PL; };
+  auto el_r = [&](int p) { return ABX ? min(tid, X3_PL - 1) : (p * X3_THREADS + tid) % X3_PL; };
+  auto el_on = [&](int p) { return ABX ? tid < X3_PL : p * X3_THREADS + tid < NCG * X3_PL; };
+  float pf[NPE][4];
   unsigned valid = 0;
   const T* const x = static_cast<const T*>(a.x);
   // this thread's halo elements of a column, located ONCE per column: element offset of each of the four channels inside the
@@ -205,9 +237,22 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // plane base changes, so the loads are `uniform base + lane offset` with no address arithmetic left in the z loop (per plane it
   // was ~100 VALU instructions per wave next to 48 MFMAs, and VALU issue is additive to MFMA issue on this chip)
   int voff[NPF];
+  int vgy = 0, vgx = 0;                // XSRC == 2: the thread's voxel (clamped row, column) and whether this workgroup OWNS it
+  bool vinterior = false;              // (inside the 8 x 32 tile, not its halo: the fused tail of stem3d0 is stored by the owner)
+  float4 pa[ABX ? NCG : 1], pbv[ABX ? NCG : 1];      // XSRC == 2: the A and B plane values of the plane in flight, per channel group
+  unsigned hflags = 0;                 // XSRC == 2: bit 0: the voxel has an A term in that plane, bit 1: a B term
   unsigned vmask = 0;
   auto locate = [&](int y0, int x0) {
     vmask = 0;
+    if constexpr (ABX) {
+      const int r = min(tid, X3_PL - 1), xx = r % X3_HX, yy = r / X3_HX;
+      const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+      const bool ok = tid < X3_PL && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      vmask = ok ? (1u << NPE) - 1u : 0u;
+      vgy = min(max(gy, 0), a.H - 1); vgx = min(max(gx, 0), a.W - 1);
+      vinterior = ok && yy >= 1 && yy <= X3_TY && xx >= 1 && xx <= X3_TX;
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NPF; ++p) {
       const int el = p * X3_THREADS + tid, cg = el / X3_PL, r = el % X3_PL;
@@ -220,9 +265,35 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     }
   };
   // issue the loads of input plane gz of the located column: unconditional, the plane index clamped into the volume
+  const float* wsb = nullptr;          // XSRC == 2: this sample's planes
+  float* tdst = nullptr;               // ... and the sample of the fused tail's destination
   auto prefetch = [&](const T* xb, int gz) {
     if (dg_noload) return;
     valid = (unsigned)gz < (unsigned)a.D ? vmask : 0u;
+    if constexpr (ABX) {
+      // the combine kernel's addressing (costvol_stem.hip), once per voxel: cls = z border, tc = clamp(x - i, -3, 2) picks the A plane
+      // (full / band / none), B is indexed by x - i (right-border variant at x = W - 1); unconditional loads — an absent term reads
+      // the set's base and is discarded by a select in mat()
+      const int gzc = min(max(gz, 0), a.D - 1), cls = (gzc == 0 ? 1 : 0) + (gzc == a.D - 1 ? 2 : 0);
+      auto pick = [&](const int (&o)[4]) { return cls == 0 ? o[0] : cls == 1 ? o[1] : cls == 2 ? o[2] : o[3]; };      // (scalar selects: no argument-segment loads)
+      const int ofull = pick(e.src.off_afull), oband = pick(e.src.off_aband), ob0 = pick(e.src.off_b0), ob1 = pick(e.src.off_b1);
+      constexpr int CM = 4 * NCG;
+      const int t = vgx - gzc, tc = min(max(t, -3), 2);
+      int oa = ofull;
+      if (tc == 2) oa = ofull + (vgy * a.W + vgx) * CM;
+      else if (tc > -3) oa = oband + (tc + 2) * CM * a.H * e.src.wband + (vgy * e.src.wband + vgx - (tc == 1 ? 1 : 0)) * CM;
+      int ob = ob0;
+      if (t >= -2) ob = vgx == a.W - 1 ? ob1 + (vgy * e.src.wb1 + (t - e.src.u1_0)) * CM : ob0 + (vgy * (a.W + 2) + (t + 2)) * CM;
+      hflags = (tc > -3 ? 1u : 0u) | (t >= -2 ? 2u : 0u);
+      if (tid < X3_PL) {
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) {
+          pa[cg] = *reinterpret_cast<const float4*>(wsb + oa + 4 * cg);
+          pbv[cg] = *reinterpret_cast<const float4*>(wsb + ob + 4 * cg);
+        }
+      }
+      return;
+    }
     const T* const pb = xb + (int64_t)min(max(gz, 0), a.D - 1) * HW * (G4X ? 4 : 1);
     if constexpr (G4X) {
 #pragma unroll
@@ -239,15 +310,64 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       }
     }
   };
+  // XSRC == 2: the plane values in flight -> the voxel's channels, exactly as costvol_stem_combine_kernel computes them:
+  // s = (B term or 0) + (A term or 0); s = fma(s, scale, shift); ReLU.  Called where the loads are first needed.
+  // (and the fused tail of stem3d0 — cell 0's pre_preprocess, rag_model.py:125,154 — for the voxels this workgroup owns, in the
+  // planes of its own depth segment: the combine kernel's fmaf chain over the channels in order, BatchNorm, ReLU, one store)
+  int zlo = 0, zhi = 0;                  // XSRC == 2: the item's own planes [zlo, zhi)
+  auto mat = [&](int gz) {
+    if constexpr (ABX) {
+      if (tid >= X3_PL) return;
+      const bool ha = hflags & 1u, hb = (hflags >> 1) & 1u;
+      float v[NCG][4];
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        const float4 sc = lsrc[cg], sh = lsrc[NCG + cg];
+        const float av[4] = {pa[cg].x, pa[cg].y, pa[cg].z, pa[cg].w}, bv[4] = {pbv[cg].x, pbv[cg].y, pbv[cg].z, pbv[cg].w};
+        const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float sv = (hb ? bv[c] : 0.f) + (ha ? av[c] : 0.f);
+          sv = fmaf(sv, s4[c], h4[c]);
+          v[cg][c] = e.src.relu ? fmaxf(sv, 0.f) : sv;
+          pf[cg][c] = v[cg][c];
+        }
+      }
+      if (e.src.ntail > 0 && vinterior && gz >= zlo && gz < zhi) {
+        float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4 * NCG; ++c) {
+          const float4 wk = lsrc[2 * NCG + c];                      // w[0..3][c]
+          // (one scalar v_fma per term, kept apart by opaque statements: paired into v_pk_fma_f32 by the SLP vectoriser this chain
+          // gave WRONG low halves in lanes 48..63 of a wave now and then — run to run different voxels, ~0.1 % of them — on gfx950 with
+          // ROCm 7.2's hipcc; the same source built with -fno-slp-vectorize is exact.  tools/_dbg history: NOTES.md round 5)
+          u[0] = fmaf(wk.x, v[c >> 2][c & 3], u[0]); asm volatile("" : "+v"(u[0]));
+          u[1] = fmaf(wk.y, v[c >> 2][c & 3], u[1]); asm volatile("" : "+v"(u[1]));
+          u[2] = fmaf(wk.z, v[c >> 2][c & 3], u[2]); asm volatile("" : "+v"(u[2]));
+          u[3] = fmaf(wk.w, v[c >> 2][c & 3], u[3]); asm volatile("" : "+v"(u[3]));
+        }
+        const float4 tsc = lsrc[2 * NCG + 4 * NCG], tsh = lsrc[2 * NCG + 4 * NCG + 1];
+        const float ts[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, th[4] = {tsh.x, tsh.y, tsh.z, tsh.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u[k] = fmaf(u[k], ts[k], th[k]); asm volatile("" : "+v"(u[k])); u[k] = e.src.tail_relu ? fmaxf(u[k], 0.f) : u[k]; }
+        const int64_t vox = (int64_t)gz * HW + vgy * a.W + vgx;
+        if (e.src.tail_g4) {
+          *reinterpret_cast<float4*>(tdst + ((int64_t)(e.src.tail_ch0 >> 2) * DHW + vox) * 4) = make_float4(u[0], u[1], u[2], u[3]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tdst[(int64_t)(e.src.tail_ch0 + k) * DHW + vox] = u[k];
+        }
+      }
+    }
+  };
   float mul = 1.f;                       // fp32 storage: the column's operand scale 2^-e (wave-uniform)
   unsigned cap_bits = 0x7f7fffffu;       // bit pattern of X3_F16_CAP / mul: an element above it does not fit the column's scale
   auto commit = [&](int slot) {          // registers -> ring plane `slot` (16-bit hi / lo halves), zeros outside the volume / past Cin
     if (dg_nocommit) return;
 #pragma unroll
-    for (int p = 0; p < NPF; ++p) {
-      const int el = p * X3_THREADS + tid;
-      if (el >= NCG * X3_PL) continue;
-      const int cg = el / X3_PL, r = el % X3_PL;
+    for (int p = 0; p < NPE; ++p) {
+      if (!el_on(p)) continue;
+      const int cg = el_cg(p), r = el_r(p);
       float v[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = ((valid >> p) & 1u) ? pf[p][c] : 0.f;
@@ -266,7 +386,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   auto local_max = [&]() {
     float m = 0.f;
 #pragma unroll
-    for (int p = 0; p < NPF; ++p) {
+    for (int p = 0; p < NPE; ++p) {
       const float mp = x3_scalable_max4(pf[p][0], pf[p][1], pf[p][2], pf[p][3]);
       m = fmaxf(m, ((valid >> p) & 1u) ? mp : 0.f);
     }
@@ -282,7 +402,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   auto note_overflow = [&]() {
     unsigned mb = 0u;
 #pragma unroll
-    for (int p = 0; p < NPF; ++p) {
+    for (int p = 0; p < NPE; ++p) {
       const unsigned mp = max(max(__float_as_uint(pf[p][0]) & 0x7fffffffu, __float_as_uint(pf[p][1]) & 0x7fffffffu),
                               max(__float_as_uint(pf[p][2]) & 0x7fffffffu, __float_as_uint(pf[p][3]) & 0x7fffffffu));
       mb = max(mb, ((valid >> p) & 1u) ? mp : 0u);
@@ -309,6 +429,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // vector memory load per use, and its s_waitcnt vmcnt drains the prefetch that is supposed to fly under the MFMAs
   const int my_ych = g < ngroups ? a.y_ch[g < RAGMI_MAX_GROUPS ? g : 0] : 0;
   const int tsel = kb & 1;
+  const int my_tail_cout = TAILS ? (kb < a.ntail ? (tsel ? a.tail_cout[1] : a.tail_cout[0]) : 0) : 0;
+  const int my_trelu = tsel ? a.tail_relu[1] : a.tail_relu[0];
+  T* tbase = nullptr;
   // XCD-aware schedule: workgroup j runs on XCD j % 8 (round-robin dispatch); give every XCD one contiguous chunk of the
   // (x-fastest) work list so that neighbouring columns — which share halo rows and cache lines — meet in the same L2
   // Down-sampling tails, second half: the planes 2Z (LDS parity 0) and 2Z+1 (parity 1) of the x-blended tail values are complete ->
@@ -366,6 +489,23 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     int zs = seg * e.seg_len, ze = min(a.D, zs + e.seg_len);
     if (half >= 0) { const int mid = zs + ((ze - zs + 1) >> 1); if (half) zs = mid; else ze = mid; }
     const T* xb = x + b * a.x_bstride;
+    if constexpr (TAILS) {
+      T* const my_tail = static_cast<T*>(tsel ? a.tail_y[1] : a.tail_y[0]);
+      const int64_t tb = tsel ? a.tail_bstride[1] : a.tail_bstride[0];
+      const int tch0 = tsel ? a.tail_ch0[1] : a.tail_ch0[0];
+      const int64_t v0 = (int64_t)(y0 + wave) * a.W + x0 + n;      // this wave's row of the tile (X3_NT == 2: tile i = x half i)
+      if constexpr (!BF) {
+        tbase = a.tail_g4 ? reinterpret_cast<T*>(reinterpret_cast<float*>(my_tail) + b * tb + ((int64_t)(tch0 >> 2) * DHW + v0) * 4)
+                          : my_tail + b * tb + (int64_t)tch0 * DHW + v0;
+      } else {
+        tbase = my_tail + b * tb + (int64_t)tch0 * DHW + v0;
+      }
+    }
+    if constexpr (ABX) {
+      wsb = e.src.ws + b * e.src.ws_bstride;
+      tdst = e.src.tail_y + b * e.src.tail_bstride;
+      zlo = zs; zhi = ze;
+    }
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
     locate(y0, x0);
     if constexpr (!BF) { if (tid < 2) lmaxp[tid] = 0u; }  // (ordered before the first atomicMax below by the barrier that follows)
@@ -395,7 +535,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         // note in) joined by plane zfirst.  Written only here, between this pass's two barriers; lmaxp[1] = overflow notes, written
         // only AFTER the second barrier and read behind the z loop's barriers.
         if (tid == 0) { const unsigned note = lmaxp[1]; lmaxp[1] = 0u; if (note) atomicMax(lmaxp, note); }
-        prefetch(xb, zfirst);
+        prefetch(xb, zfirst); mat(zfirst);
         const float wm = x3_wave_max(local_max());
         if (lane == 0) atomicMax(lmaxp, __float_as_uint(wm));
         __syncthreads();
@@ -403,7 +543,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         cap_bits = __float_as_uint(X3_F16_CAP / mul);      // (mul in [2^-101, 2^99]: finite)
         if (tid < 32) par[tid] = par[96 + tid] * (1.f / mul);       // the epilogue's scale undoes the column's 2^-e
         commit(zfirst % 3);
-        prefetch(xb, zfirst - 1); note_overflow(); commit((zfirst - 1 + 3) % 3);
+        prefetch(xb, zfirst - 1); mat(zfirst - 1); note_overflow(); commit((zfirst - 1 + 3) % 3);
         prefetch(xb, zfirst + 1);
       } else {
         prefetch(xb, zs - 1); commit((zs - 1 + 3) % 3);
@@ -416,6 +556,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       __syncthreads();                                 // plane z-2 (same ring slot as z+1) is no longer read
       X3_STAMP(0);
       if constexpr (TAILS == 2) { if (z > zs && !(z & 1)) down_finish(z - 1, b, y0, x0); }     // planes z-2, z-1 are complete (segments start even)
+      mat(z + 1);
       if constexpr (!BF) note_overflow();
       commit((z + 1) % 3);
       X3_STAMP(1);
@@ -428,7 +569,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       }
       // unconditional (also past the segment end: the addresses are clamped): the loads stay straight-line code ahead of the
       // MFMA block, a branch here made the compiler drain them (s_waitcnt vmcnt(0)) before the first LDS read
-      prefetch(xb, z + 2);
+      if constexpr (!ABX) prefetch(xb, z + 2);
       __builtin_amdgcn_sched_barrier(0);               // ...and the scheduler must not sink them below the MFMAs either
       X3_STAMP(3);
       f32x4 acc[NSET][X3_NT];
@@ -498,12 +639,10 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(ltail)[r * 64 + lane], v[r], tacc, 0, 0, 0);
-          // destination of this lane quarter's tail: a select between the two (wave-uniform) descriptors, not an indexed load
-          const int my_tail_cout = kb < a.ntail ? (tsel ? a.tail_cout[1] : a.tail_cout[0]) : 0;
+          // destination of this lane quarter's tail: `tbase` (per item: sample, first channel, this lane's voxel of tile 0 in plane 0)
+          // + the plane and the tile — one 64-bit pointer in registers instead of the descriptor fields it was built from
           if (my_tail_cout > 0 && inside && !(dg_nostore && tacc[0] != 12345.f)) {
-            T* const my_tail = static_cast<T*>(tsel ? a.tail_y[1] : a.tail_y[0]);
-            const int64_t tb = tsel ? a.tail_bstride[1] : a.tail_bstride[0];
-            const int tch0 = tsel ? a.tail_ch0[1] : a.tail_ch0[0], trelu = tsel ? a.tail_relu[1] : a.tail_relu[0];
+            const int trelu = my_trelu;
             const float4 tsc = *reinterpret_cast<const float4*>(par + 64 + 4 * kb), tsh = *reinterpret_cast<const float4*>(par + 80 + 4 * kb);
             const float sc4[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, sh4[4] = {tsh.x, tsh.y, tsh.z, tsh.w};
             if (!BF && a.tail_g4) {      // G4 destination (four output channels: fill_tails): one 16-byte store per voxel
@@ -511,9 +650,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
 #pragma unroll
               for (int r = 0; r < 4; ++r) { const float u = fmaf(tacc[r], sc4[r], sh4[r]); u4[r] = trelu ? fmaxf(u, 0.f) : u; }
               if constexpr (!BF)
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(my_tail) + b * tb + ((int64_t)(tch0 >> 2) * DHW + vox) * 4) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(tbase) + ((int64_t)z * HW + (nt & 1) * 16) * 4) = make_float4(u4[0], u4[1], u4[2], u4[3]);
             } else {
-              T* pt = my_tail + b * tb + (int64_t)tch0 * DHW + vox;
+              T* pt = tbase + (int64_t)z * HW + (nt & 1) * 16;
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 if (r < my_tail_cout) {
@@ -541,6 +680,15 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
             }
           }
         }
+      }
+      if constexpr (ABX) {
+        // the plane source's six 16-byte loads per voxel come from L2 (the planes are a few MB): requested HERE, behind the epilogue,
+        // their 24 registers are live neither under the MFMAs nor in the epilogue (in front of the matrix block, where the tensor
+        // loads sit, the kernel spilled 13 registers; behind it, 15, two of them reloaded in every epilogue.  Half of them — the A
+        // terms — in front of or behind the matrix block does fit, and measured the same step time: the staging's cost is its
+        // arithmetic, not the wait)
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch(xb, z + 2);
       }
       X3_STAMP(5);
 #ifdef RAGMI_DIAG
@@ -992,18 +1140,20 @@ int x3_g4_caps(const K3Args& a, int nset, int dtype) {
   return (a.Cout <= 16 ? 2 : 0) | ((nset == 1 && ncg == 3 && a.ndown == 0) ? 1 : 0);
 }
 
-template <class T, int NCG, int NSET, int TAILS, bool G4X = false>
+template <class T, int NCG, int NSET, int TAILS, int XSRC = 0>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
-  if constexpr (!G4X && std::is_same<T, float>::value && NCG == 3 && NSET == 1 && TAILS < 2) {
-    if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, true>(a, e, grid, lds, st);      // stem3d1 on a G4 input
+  if constexpr (XSRC == 0 && std::is_same<T, float>::value && NCG == 3 && NSET == 1 && TAILS < 2) {
+    if (e.src.ws != nullptr) return x3_launch_tails<T, NCG, NSET, TAILS, 2>(a, e, grid, lds + (2 * NCG + 4 * NCG + 2) * sizeof(float4), st);      // stem3d1 expanding stem3d0's planes
+    if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, 1>(a, e, grid, lds, st);      // stem3d1 on a G4 input
   }
+  if (e.src.ws != nullptr && XSRC != 2) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: the plane source is built for 12 -> Cout fp32 launches without down-sampling tails");
   static LaunchState state;     // per device, mutex-guarded (common.h)
   // persistent grid = the workgroups the chip holds at once (occupancy x CUs): measured on the level-3 launches (1664 work items)
   // with both on one box: 512 workgroups 1.219 ms per step, 1024 1.226, 768 1.296, 1536 1.250
-  const int slots = state.slots((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS, G4X>, X3_THREADS, lds, 160 * 1024);
+  const int slots = state.slots((const void*)conv3d_x3_kernel<T, NCG, NSET, TAILS, XSRC>, X3_THREADS, lds, 160 * 1024);
   if (slots <= 0) return fail(RAGMI_ELAUNCH, "conv3d_x3: cannot raise the dynamic LDS limit");
   grid.x = (unsigned)std::max<int64_t>(1, std::min<int64_t>(grid.x, std::max(256, slots) / (int)grid.y));
-  hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET, TAILS, G4X>), grid, dim3(X3_THREADS), lds, st, a, e);
+  hipLaunchKernelGGL((conv3d_x3_kernel<T, NCG, NSET, TAILS, XSRC>), grid, dim3(X3_THREADS), lds, st, a, e);
   return check_launch("conv3d_x3");
 }
 template <class T, int NCG, int NSET>
@@ -1028,12 +1178,13 @@ extern "C" __attribute__((visibility("default"))) int ragmi_diag_x3_stamp_buffer
 #endif
 
 // a: as filled for the fp32 kernel (wp[s] = packed weights: fp32-MFMA section followed by the bf16x3 fragments)
-int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
+int x3_launch(K3Args a, int nset, int dtype, hipStream_t st, const X3StemSrc* src) {
 #ifdef RAGMI_DIAG
   static const int diag_x3 = [] { const char* v = getenv("RAGMI_X3_DIAG"); return v ? atoi(v) : 0; }();   // 1 no stores, 2 no MFMA block, 4 no commit, 8 no loads, 16 operand reads at one address, 32 in-kernel stamps, 64 / 128 (quad-ring kernel) no finishing step / no parking of the down-sampling tails
   a.relu |= diag_x3 << 8;
 #endif
   X3Extra e{};
+  if (src) e.src = *src;
   x3_weight_sections(e, a, nset, dtype);
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0), ncgs = ncg / nset, nsls = (ncgs * 27 + 7) / 8, nsl = nset * nsls;
   a.tiles_x = (int)ceil_div(a.W, X3_TX); a.tiles_y = (int)ceil_div(a.H, X3_TY);
@@ -1083,7 +1234,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st) {
   RAGMI_REQUIRE(lds <= 160 * 1024, RAGMI_EUNSUPPORTED, "conv3d_x3: tile does not fit the LDS");
   const dim3 grid((unsigned)std::min<int64_t>(nwork, 1 << 20), ncog);      // x is cut to the resident slots where the kernel is known
 #ifndef RAGMI_NO_X3Q
-  if (xq_takes(a, nset, dtype)) return xq_launch(a, e, nset, grid, st);     // one 4-channel group per set, fp32 storage: conv3d_x3q.hip
+  if (!src && xq_takes(a, nset, dtype)) return xq_launch(a, e, nset, grid, st);     // one 4-channel group per set, fp32 storage: conv3d_x3q.hip
 #endif
   if (nset == 2) {
     switch (ncg) {

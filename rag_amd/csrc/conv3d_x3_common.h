@@ -174,7 +174,28 @@ __device__ __forceinline__ void x3_pack_one(const float* __restrict__ w, uint4* 
   wf[((int64_t)(cog * nsls + s) * 2 + 1) * 64 + lane] = pk(lo);
 }
 
+// stem3d0 expanded in the consumer's staging (XSRC == 2 of conv3d_x3_kernel; costvol_stem.hip): the variant planes of
+// ragmi_costvol_stem_fwd ([y][xi][Cm] per plane set, fp32) and what the combine kernel would apply to them
+struct X3StemSrc {
+  const float* ws;           // workspace of the planes (per sample: + b * ws_bstride)
+  int64_t ws_bstride;
+  int off_afull[4], off_aband[4], off_b0[4], off_b1[4];      // float offsets of the plane sets per z-border class
+  int wband, wb1, u1_0;
+  const float* scale;        // stem3d0's folded BatchNorm (may be null: identity)
+  const float* shift;
+  int relu;
+  // one consumer 1x1x1 conv of stem3d0's output (4 output channels: cell 0's pre_preprocess), computed by the staging thread that
+  // owns the voxel (ntail == 0: none)
+  int ntail, tail_relu, tail_ch0, tail_g4;
+  const float* tail_w;       // [4][Cm]
+  const float* tail_scale;   // [4] (may be null)
+  const float* tail_shift;
+  float* tail_y;
+  int64_t tail_bstride;
+};
+
 struct X3Extra {
+  X3StemSrc src;             // XSRC == 2 only
   const uint4* wf[2];        // packed fragments per accumulator set (the section of the storage type: bf16 or scaled fp16)
   const float* wmul[2];      // fp16 section: per-output-channel multiplier 2^-k that undoes the weight scale (null for bf16 storage)
   int nseg, seg_len, nwork, bf16;   // bf16 != 0: bf16 activation storage (kernel instantiation selector)

@@ -159,13 +159,21 @@ __global__ __launch_bounds__(CS_NT) void costvol_stem_planes_kernel(PlanesArgs a
   if (d.right) body(std::integral_constant<int, 5>{}); else body(std::integral_constant<int, 3>{});
   const int y = yb + yy;
   if (y >= a.H) return;
-  float* out = a.ws + b * a.ws_bstride + d.out_off + (int64_t)y * d.width + xb + xx;
+  // workspace layout (round 5): a plane set is [y][xi][Cout] — the channels of a pixel contiguous — so that the consumers (the combine
+  // kernel, and stem3d1's staging when stem3d0 is expanded there: conv3d_x3.hip) fetch a pixel's channels with 16-byte loads
+  float* out = a.ws + b * a.ws_bstride + d.out_off + ((int64_t)y * d.width + xb + xx) * a.Cout;
 #pragma unroll
-  for (int co = 0; co < NCO; ++co) {
-    if (co >= a.Cout) break;
+  for (int p = 0; p < CS_PX; ++p) {
+    if (xb + xx + p >= d.width) continue;
+    if constexpr (COUT4 > 0) {
 #pragma unroll
-    for (int p = 0; p < CS_PX; ++p)
-      if (xb + xx + p < d.width) out[(int64_t)co * a.H * d.width + p] = acc[p][co];
+      for (int q = 0; q < COUT4; ++q)
+        *reinterpret_cast<float4*>(out + p * a.Cout + 4 * q) = make_float4(acc[p][4 * q], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
+        if (co < a.Cout) out[p * a.Cout + co] = acc[p][co];
+    }
   }
 }
 
@@ -290,7 +298,6 @@ __device__ __forceinline__ void costvol_stem_planes_mfma_body(const PlanesArgs& 
   float osc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) osc[r] = wmul_all[v * 16 + 4 * kb + r] * inv;
-  const int64_t plane = (int64_t)a.H * d.width;
   float* const out = a.ws + b * a.ws_bstride + d.out_off;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -306,10 +313,9 @@ __device__ __forceinline__ void costvol_stem_planes_mfma_body(const PlanesArgs& 
       acc = x3_mma<false>(al[s], bh, acc);
     }
     const int y = yb + row, xi = xb + col;
-    if (y < a.H && xi < d.width) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * kb + r < a.Cout) out[(int64_t)(4 * kb + r) * plane + (int64_t)y * d.width + xi] = acc[r] * osc[r];
+    if (y < a.H && xi < d.width && 4 * kb < a.Cout) {      // [y][xi][Cout] (Cout a multiple of 4 here): this lane's four channels are 16 bytes
+      *reinterpret_cast<float4*>(out + ((int64_t)y * d.width + xi) * a.Cout + 4 * kb) =
+          make_float4(acc[0] * osc[0], acc[1] * osc[1], acc[2] * osc[2], acc[3] * osc[3]);
     }
   }
 }
@@ -391,29 +397,48 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
       // (plane offsets are 32-bit: a batch item's workspace is < 2^31 floats, checked on the host).  An absent plane is read at
       // the workspace base and DISCARDED by a select (not multiplied by 0: a non-finite value there must not leak into voxels that
       // have no A term) — unconditional loads, no branch per channel
-      int oa = 0, sa = 0;
+      int oa = 0;
       bool ha = false;
-      if (tc == 2) { oa = a.off_afull[cls] + y * a.W + x; sa = a.H * a.W; ha = true; }
-      else if (tc > -3) { oa = a.off_aband[cls] + (tc + 2) * Cout * a.H * a.wband + y * a.wband + x - (tc == 1 ? 1 : 0); sa = a.H * a.wband; ha = true; }
+      if (tc == 2) { oa = a.off_afull[cls] + (y * a.W + x) * Cout; ha = true; }
+      else if (tc > -3) { oa = a.off_aband[cls] + (tc + 2) * Cout * a.H * a.wband + (y * a.wband + x - (tc == 1 ? 1 : 0)) * Cout; ha = true; }
+      if constexpr (NC > 0) {
 #pragma unroll
-      for (int co = 0; co < MC; ++co) {
-        const float wa = co < Cout ? ws[oa + co * sa] : 0.f;
-        av[co] = ha ? wa : 0.f;
+        for (int q = 0; q < MC / 4; ++q) {
+          const float4 wa = *reinterpret_cast<const float4*>(ws + oa + 4 * q);
+          av[4 * q] = ha ? wa.x : 0.f; av[4 * q + 1] = ha ? wa.y : 0.f; av[4 * q + 2] = ha ? wa.z : 0.f; av[4 * q + 3] = ha ? wa.w : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int co = 0; co < MC; ++co) {
+          const float wa = co < Cout ? ws[oa + co] : 0.f;
+          av[co] = ha ? wa : 0.f;
+        }
       }
     }
     // B: indexed by u = x - i (>= -2 to contribute); the right-border variant lives on u in [u1_0, W-1]
-    int ob = 0, sb = 0;
+    int ob = 0;
     bool hb = false;
     if (t >= -2) {
       hb = true;
-      if (xr) { ob = a.off_b1[cls] + y * a.wb1 + (t - a.u1_0); sb = a.H * a.wb1; }
-      else { ob = a.off_b0[cls] + y * (a.W + 2) + (t + 2); sb = a.H * (a.W + 2); }
+      if (xr) ob = a.off_b1[cls] + (y * a.wb1 + (t - a.u1_0)) * Cout;
+      else ob = a.off_b0[cls] + (y * (a.W + 2) + (t + 2)) * Cout;
+    }
+    float bv[MC];
+    if constexpr (NC > 0) {
+#pragma unroll
+      for (int q = 0; q < MC / 4; ++q) {
+        const float4 wb4 = *reinterpret_cast<const float4*>(ws + ob + 4 * q);
+        bv[4 * q] = wb4.x; bv[4 * q + 1] = wb4.y; bv[4 * q + 2] = wb4.z; bv[4 * q + 3] = wb4.w;
+      }
+    } else {
+#pragma unroll
+      for (int co = 0; co < MC; ++co) bv[co] = co < Cout ? ws[ob + co] : 0.f;
     }
     float v[MC];
 #pragma unroll
     for (int co = 0; co < MC; ++co) {
       if (co < Cout) {
-        const float wb = ws[ob + co * sb];
+        const float wb = bv[co];
         float s = (hb ? wb : 0.f) + av[co];                        // A + B; an absent plane's (unconditional) load is discarded
         s = fmaf(s, par[co], par[CS_MAXC + co]);
         v[co] = (a.relu & 1) ? fmaxf(s, 0.f) : s;
@@ -425,7 +450,9 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
     // G4 destinations (include/rag_amd.h: [B][C/4][D][H][W][4], fp32; the host checks Cout % 4 == 0 and 4-channel tails): a thread
     // owns every channel of its voxel, so a group is ONE 16-byte store (a wave: 1 KB contiguous) instead of four 4-byte stores into
     // four planes
-    if constexpr (std::is_same<T, float>::value && NC > 0) {
+    if (a.y == nullptr) {
+      // (tails only: stem3d0's own output is expanded from the planes inside stem3d1's staging and never written)
+    } else if constexpr (std::is_same<T, float>::value && NC > 0) {
       if (a.relu & RAGMI_CONV_Y_G4) {
         float* const py4 = static_cast<float*>(a.y) + b * a.y_bstride + vox * 4;
 #pragma unroll
@@ -523,11 +550,78 @@ extern "C" int64_t ragmi_costvol_stem_workspace_elems(int B, int C, int Cout, in
   return l.per_batch * B;
 }
 
+// the planes (+ the combine kernel unless there is nothing for it to write); `lay` receives the workspace layout
+static int stem_run(const void* left, const void* right, const void* variants, const void* scale, const void* shift,
+                    int relu, void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
+                    int ntail, const ragmi_tail_t* tails, int dtype, void* stream, ragmi::StemLayout* lay);
+
 extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const void* variants, const void* scale, const void* shift,
                                       int relu, void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
                                       int ntail, const ragmi_tail_t* tails, int dtype, void* stream) {
+  RAGMI_REQUIRE(y || ntail > 0, RAGMI_EINVAL, "costvol_stem: y may be NULL only when tails consume the result");
+  return stem_run(left, right, variants, scale, shift, relu, y, y_bstride, workspace, B, C, Cout, D, H, W, ntail, tails, dtype, stream, nullptr);
+}
+
+// stem3d0 + stem3d1 with stem3d0's output never written (include/rag_amd.h)
+extern "C" int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right, const void* variants, const void* scale0, const void* shift0,
+                                             int relu0, void* workspace, int ntail0, const ragmi_tail_t* tails0,
+                                             const void* packed_weight, const void* scale, const void* shift, int relu,
+                                             void* y, int64_t y_bstride, const int32_t* y_group_ch, int store_main, int ntail,
+                                             const ragmi_tail_t* tails, int B, int C, int Cmid, int Cout, int D, int H, int W, int dtype,
+                                             void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(left && right && variants && y && workspace, RAGMI_EINVAL, "costvol_stem: null pointer");
+  RAGMI_REQUIRE(dtype == RAGMI_F32X3, RAGMI_EUNSUPPORTED, "costvol_stem_conv3d: RAGMI_F32X3 only (fp32 storage, split-operand convolution)");
+  RAGMI_REQUIRE(packed_weight && (y || !store_main), RAGMI_EINVAL, "costvol_stem_conv3d: null pointer");
+  RAGMI_REQUIRE(Cmid == 12 && C % 4 == 0 && C <= 12, RAGMI_EUNSUPPORTED, "costvol_stem_conv3d: built for 12 intermediate channels (stem3d0 -> stem3d1)");
+  RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "costvol_stem_conv3d: scale/shift must both be given or both NULL");
+  K3Args a{};
+  static float dummy;      // (never dereferenced: the kernel has no input tensor in this mode)
+  int rc = fill_common(a, &dummy, 0, y ? y : (void*)&dummy, y_bstride, y_group_ch, nullptr, 0, nullptr, B, Cmid, Cout, D, H, W, relu & 1);
+  if (rc != RAGMI_OK) return rc;
+  a.wp[0] = (const float*)packed_weight; a.scale[0] = (const float*)scale; a.shift[0] = (const float*)shift;
+  a.nchunks[0] = (Cmid + CK - 1) / CK;
+  rc = fill_tails(a, store_main, ntail, tails, Cout);
+  if (rc != RAGMI_OK) return rc;
+  RAGMI_REQUIRE(a.ndown == 0 && x3_eligible(a, 1, dtype) && !x3d_eligible(a, 1, dtype) && !x2d_eligible(a, 1, dtype), RAGMI_EUNSUPPORTED,
+                "costvol_stem_conv3d: this shape does not run on the z-marching split-operand kernel (ragmi_costvol_stem_conv3d_supported)");
+  // ONE fused tail of stem3d0 (4 output channels, full resolution: cell 0's pre_preprocess) is computed by stem3d1's staging thread
+  // that owns the voxel — no combine launch at all; anything else goes through the combine kernel (tails only, no main store)
+  RAGMI_REQUIRE(ntail0 >= 0 && ntail0 <= 2 && (ntail0 == 0 || tails0), RAGMI_EINVAL, "costvol_stem_conv3d: at most two tails on stem3d0's output");
+  const bool tail_in_staging = ntail0 == 1 && tails0[0].cout == 4 && !(tails0[0].relu & 2) && tails0[0].weight && tails0[0].y &&
+                               ((tails0[0].scale == nullptr) == (tails0[0].shift == nullptr)) && (!(tails0[0].relu & RAGMI_TAIL_G4) || tails0[0].y_ch0 % 4 == 0);
+  StemLayout l;
+  rc = stem_run(left, right, variants, scale0, shift0, relu0, nullptr, 0, workspace, B, C, Cmid, D, H, W, tail_in_staging ? 0 : ntail0, tails0, dtype,
+                stream, &l);
+  if (rc != RAGMI_OK) return rc;
+  X3StemSrc src{};
+  if (tail_in_staging) {
+    src.ntail = 1; src.tail_relu = tails0[0].relu & 1; src.tail_ch0 = tails0[0].y_ch0; src.tail_g4 = (tails0[0].relu & RAGMI_TAIL_G4) ? 1 : 0;
+    src.tail_w = (const float*)tails0[0].weight; src.tail_scale = (const float*)tails0[0].scale; src.tail_shift = (const float*)tails0[0].shift;
+    src.tail_y = (float*)tails0[0].y; src.tail_bstride = tails0[0].y_bstride;
+  }
+  src.ws = (const float*)workspace; src.ws_bstride = l.per_batch;
+  for (int c = 0; c < CS_NCLS; ++c) {
+    src.off_afull[c] = (int)l.off_afull[c]; src.off_aband[c] = (int)l.off_aband[c];
+    src.off_b0[c] = (int)l.off_b0[c]; src.off_b1[c] = (int)l.off_b1[c];
+  }
+  src.wband = l.wband; src.wb1 = l.wb1; src.u1_0 = l.u1_0;
+  src.scale = (const float*)scale0; src.shift = (const float*)shift0; src.relu = relu0 & 1;
+  return x3_launch(a, 1, dtype, static_cast<hipStream_t>(stream), &src);
+}
+
+extern "C" int ragmi_costvol_stem_conv3d_supported(int C, int Cmid, int Cout, int B, int D, int H, int W, int ntail, int dtype) {
+  using namespace ragmi;
+  if (dtype != RAGMI_F32X3 || Cmid != 12 || C % 4 != 0 || C <= 0 || C > 12 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  K3Args a{};
+  a.B = B; a.Cin = Cmid; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.ntail = ntail; a.nchunks[0] = Cmid / CK; a.store_main = 1;
+  return (x3_eligible(a, 1, dtype) && !x3d_eligible(a, 1, dtype) && !x2d_eligible(a, 1, dtype)) ? 1 : 0;
+}
+
+static int stem_run(const void* left, const void* right, const void* variants, const void* scale, const void* shift,
+                    int relu, void* y, int64_t y_bstride, void* workspace, int B, int C, int Cout, int D, int H, int W,
+                    int ntail, const ragmi_tail_t* tails, int dtype, void* stream, ragmi::StemLayout* lay) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(left && right && variants && workspace, RAGMI_EINVAL, "costvol_stem: null pointer");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "costvol_stem: scale/shift must both be given or both NULL");
   RAGMI_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && B <= 65535, RAGMI_EINVAL, "costvol_stem: bad size");
   RAGMI_REQUIRE(C > 0 && Cout > 0 && C <= CS_MAXC && Cout <= CS_MAXC, RAGMI_EUNSUPPORTED, "costvol_stem: C and Cout must be in 1..%d",
@@ -585,6 +679,8 @@ extern "C" int ragmi_costvol_stem_fwd(const void* left, const void* right, const
   } else if (dtype == RAGMI_BF16) { RAGMI_CS_PLANES(bf16_t) } else { RAGMI_CS_PLANES(float) }
 #undef RAGMI_CS_PLANES
 
+  if (lay) *lay = l;
+  if (y == nullptr && ntail == 0) return check_launch("costvol_stem");      // planes only: the consumer expands them itself
   CombineArgs ca{};
   ca.ws = (const float*)workspace; ca.ws_bstride = l.per_batch; ca.scale = (const float*)scale; ca.shift = (const float*)shift;
   ca.y = y; ca.y_bstride = y_bstride; ca.relu = relu; ca.Cout = Cout; ca.D = D; ca.H = H; ca.W = W;

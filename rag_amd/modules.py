@@ -890,19 +890,38 @@ class MatchingNet(nn.Module):
                 has[j][role] = True
 
         T: Dict[int, Optional[torch.Tensor]] = {}
-        # stem3d0: its output also feeds stem3d1 (3x3x3), so it is always materialised
         specs = tails_for(-2)
-        if x is None:
-            T[-2] = stem0.forward_costvol(features[0], features[1], self.maxdisp, tails=flat(specs), out_g4=t2_g4)
+        specs1 = tails_for(-1)
+        need_main = len(specs1) < len(all_consumers(-1)) or n == 0
+        keep1 = need_main or not specs1
+        # Round 5: stem3d0 and stem3d1 as ONE call whose second kernel expands stem3d0's output from the variant planes in its own
+        # staging (ops.costvol_stem_conv3d): when nothing but stem3d1 and fused tails reads T[-2], that 164 MB tensor is never written.
+        fuse_stems = (x is None and ops.stem_fusion_enabled() and adt == torch.float32 and ops.get_conv_precision() == "f16x3" and n >= 1
+                      and (0, 0, False) in fusable(-2) and stem0.conv.out_channels == 12 and stem1._geometry() == 3 and not stem1._small()
+                      and ops.costvol_stem_conv3d_supported(features[0].shape[1], 12, stem1.conv.out_channels, B, *vol,
+                                                            ntail=len(flat(specs1) or []), dtype=adt))
+        self.last_g4_plan["stems_fused"] = bool(fuse_stems)
+        if fuse_stems:
+            _w0, scale0, shift0 = stem0.prepared()
+            wk1, scale1, shift1 = stem1.prepared()
+            cout1 = stem1.conv.out_channels
+            out1 = torch.empty((B, cout1) + vol, device=dev, dtype=adt) if keep1 else None
+            ops.costvol_stem_conv3d(features[0], features[1], self.maxdisp, stem0.costvol_variants(), 12, scale0, shift0, stem0.relu, flat(specs),
+                                    wk1, cout1, scale1, shift1, stem1.relu, out1, [4 * g for g in range(ops.packed_groups(cout1))],
+                                    tails=flat(specs1), store_main=keep1)
+            T[-2] = None
+            settle(-2, specs, True, None)
         else:
-            T[-2] = stem0(x, tails=flat(specs))
-        settle(-2, specs, True, T[-2])
-        # stem3d1
-        specs = tails_for(-1)
-        need_main = len(specs) < len(all_consumers(-1)) or n == 0
-        out1 = stem1(T[-2], tails=flat(specs), store_main=need_main or not specs, x_g4=t2_g4)
-        T[-1] = out1 if (need_main or not specs) else None
-        settle(-1, specs, True, out1)
+            # stem3d0: its output also feeds stem3d1 (3x3x3), so it is materialised
+            if x is None:
+                T[-2] = stem0.forward_costvol(features[0], features[1], self.maxdisp, tails=flat(specs), out_g4=t2_g4)
+            else:
+                T[-2] = stem0(x, tails=flat(specs))
+            settle(-2, specs, True, T[-2])
+            # stem3d1
+            out1 = stem1(T[-2], tails=flat(specs1), store_main=keep1, x_g4=t2_g4)
+        T[-1] = out1 if keep1 else None
+        settle(-1, specs1, True, out1)
         def shared_pre(i):
             """Cells i and i+1 both resample T[i-1] (the `prev` of one, the `prev_prev` of the other) to the SAME size: cell i's two
             1x1x1 convs and cell i+1's pre_preprocess as ONE launch — T[i-1] is gathered by both in the same launch (the second gather

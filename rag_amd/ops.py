@@ -117,6 +117,18 @@ CONV_X_G4, CONV_Y_G4, TAIL_G4 = 2, 4, 4
 _G4 = [os.environ.get("RAGMI_G4", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling); set_g4 chooses afterwards
 
 
+_FUSE_STEMS = [os.environ.get("RAGMI_FUSE_STEMS", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling)
+
+
+def set_stem_fusion(enabled: bool) -> None:
+    """Whether the fused executor may run stem3d0 + stem3d1 as ops.costvol_stem_conv3d (stem3d0's output never written)."""
+    _FUSE_STEMS[0] = bool(enabled)
+
+
+def stem_fusion_enabled() -> bool:
+    return _FUSE_STEMS[0]
+
+
 def set_g4(enabled: bool) -> None:
     """Whether the fused executor (MatchingNet._run_chain) may keep its private level-3 tensors channel-group-interleaved."""
     _G4[0] = bool(enabled)
@@ -240,6 +252,39 @@ def costvol_stem(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, 
     check(lib.ragmi_costvol_stem_fwd(left_fea.data_ptr(), right_fea.data_ptr(), variants.data_ptr(), p(scale), p(shift), int(relu) | (CONV_Y_G4 if out_g4 else 0),
                                      out.data_ptr(), _planes(out), ws.data_ptr(), B, C, cout, d, h, w, ntail, tarr, _conv_dt(dt), _stream()),
           "costvol_stem")
+    return out
+
+
+def costvol_stem_conv3d_supported(C: int, cmid: int, cout: int, B: int, d: int, h: int, w: int, ntail: int = 0,
+                                  dtype: torch.dtype = torch.float32) -> bool:
+    return bool(load_library().ragmi_costvol_stem_conv3d_supported(C, cmid, cout, B, d, h, w, ntail, _conv_dt(_DT[dtype])))
+
+
+def costvol_stem_conv3d(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp: int, variants: torch.Tensor, cmid: int,
+                        scale0: Optional[torch.Tensor], shift0: Optional[torch.Tensor], relu0: bool, tails0: Optional[Sequence[Tail]],
+                        packed: torch.Tensor, cout: int, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool,
+                        out: Optional[torch.Tensor], out_group_ch: Optional[Sequence[int]] = None,
+                        tails: Optional[Sequence[Tail]] = None, store_main: bool = True) -> Optional[torch.Tensor]:
+    """stem3d0 (folded with the cost volume) and stem3d1 in one call, stem3d0's output never written: ragmi_costvol_stem_conv3d_fwd.
+    `tails0` ride on stem3d0's output, `tails` on stem3d1's; `out` may be None when store_main is False."""
+    _need_gpu(variants, scale0, shift0, packed, scale, shift)
+    dt = _act(left_fea, right_fea, out, *[t.out for t in (tails0 or [])], *[t.out for t in (tails or [])])
+    if left_fea.shape != right_fea.shape or left_fea.dim() != 4:
+        raise ValueError("costvol_stem_conv3d: left/right features must both be [B, C, h, w]")
+    if out is None and store_main:
+        raise ValueError("costvol_stem_conv3d: store_main needs an output buffer")
+    left_fea, right_fea = left_fea.contiguous(), right_fea.contiguous()
+    B, C, h, w = left_fea.shape
+    d = int(maxdisp / 3)
+    lib = load_library()
+    ws = torch.empty((lib.ragmi_costvol_stem_workspace_elems(B, C, cmid, d, h, w),), device=left_fea.device, dtype=torch.float32)
+    n0, t0 = _tail_array(tails0)
+    n1, t1 = _tail_array(tails)
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(lib.ragmi_costvol_stem_conv3d_fwd(left_fea.data_ptr(), right_fea.data_ptr(), variants.data_ptr(), p(scale0), p(shift0), int(relu0),
+                                            ws.data_ptr(), n0, t0, packed.data_ptr(), p(scale), p(shift), int(relu),
+                                            p(out), _planes(out) if out is not None else 0, _i32_array(out_group_ch), int(store_main), n1, t1,
+                                            B, C, cmid, cout, d, h, w, _conv_dt(dt), _stream()), "costvol_stem_conv3d")
     return out
 
 

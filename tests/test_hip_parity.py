@@ -1577,8 +1577,9 @@ def test_g4_is_refused_where_the_kernel_does_not_take_it(ra):
 @pytest.mark.parametrize("hwd", [(384, 1248, 192), (192, 384, 96)])
 def test_matchingnet_g4_plan_and_bitwise(ra, x3_on, hwd):
     """The fused executor with its private level-3 tensors channel-group-interleaved (round 5) against the same forward on channel
-    planes: same kernels, same arithmetic, other loads and stores — the disparity maps agree bit for bit; and the plan really is G4
-    for stem3d0's output and the three level-3 cells at the headline shape (rag_model.py:341-351)."""
+    planes, and with stem3d0 + stem3d1 as one call that never writes stem3d0's output against the two separate launches: same kernels,
+    same arithmetic, other loads and stores — the disparity maps agree bit for bit; and the plan really is G4 for stem3d0's output and
+    the three level-3 cells, with the stems fused, at the headline shape (rag_model.py:341-351)."""
     H, W, D = hwd
     rows = O.ALL_CONV
     sd = O.random_matching_state_dict(rows, seed=0)
@@ -1588,16 +1589,19 @@ def test_matchingnet_g4_plan_and_bitwise(ra, x3_on, hwd):
     lf, rf = torch.randn((2, 12, H // 3, W // 3), generator=gen(541)), torch.randn((2, 12, H // 3, W // 3), generator=gen(542))
     outs = {}
     try:
-        for g4 in (True, False):
+        for g4, fuse in ((True, True), (True, False), (False, False), (False, True)):
             ra.ops.set_g4(g4)
+            ra.ops.set_stem_fusion(fuse)
             with torch.no_grad():
-                outs[g4] = net(gpu(lf), gpu(rf))
+                outs[(g4, fuse)] = net(gpu(lf), gpu(rf))
             plan = net.last_g4_plan
-            assert plan["stem0_out"] == g4 and [plan["pre"][j] for j in (0, 1, 2)] == [g4] * 3, plan
+            assert plan["stem0_out"] == g4 and [plan["pre"][j] for j in (0, 1, 2)] == [g4] * 3 and plan["stems_fused"] == fuse, plan
             assert not any(plan["pre"][j] for j in range(3, 8))
     finally:
         ra.ops.set_g4(True)
-    assert torch.equal(outs[True], outs[False])
+        ra.ops.set_stem_fusion(True)
+    for k in outs:       # G4 or planes, stems fused or not: the same bits
+        assert torch.equal(outs[k], outs[(False, False)]), k
 
 
 def test_x3_down_tail_clamped_pair_ignores_a_non_finite_even_source(ra, x3_on):
@@ -1627,3 +1631,49 @@ def test_x3_down_tail_clamped_pair_ignores_a_non_finite_even_source(ra, x3_on):
     ref = torch.einsum("oc,bcdhw->bodhw", tw, F.interpolate(main[:, :, 15:16], (1, H // 2, W // 2), mode="trilinear", align_corners=True))
     ref = torch.cat([torch.zeros_like(ref)] * 7 + [ref], dim=2)      # (plane 7 = source plane 15 alone; planes 0..6 are not compared)
     np.testing.assert_allclose(got[:, :, 7].numpy(), ref[:, :, 7].numpy(), rtol=3e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize("B,h,w,maxdisp", [(1, 128, 160, 48), (2, 72, 132, 96)])
+def test_costvol_stem_conv3d_fused_bitwise(ra, x3_on, B, h, w, maxdisp):
+    """stem3d0 + stem3d1 as one call that never writes stem3d0's output (ragmi_costvol_stem_conv3d_fwd; rag_model.py:234-235, 341-343,
+    375-383) against the two separate calls (costvol_stem -> conv3d_k3 with the same tails): stem3d1's staging evaluates the combine
+    kernel's arithmetic, so the fused tails AND stem3d1's own output agree bit for bit; the separate path is itself checked against
+    ATen in float64."""
+    C, cmid, cout = 12, 12, 12
+    g1 = gen(561)
+    L, R = torch.randn((B, C, h, w), generator=g1), torch.randn((B, C, h, w), generator=g1)
+    w0 = torch.randn((cmid, 2 * C, 3, 3, 3), generator=g1) * 0.05
+    w1 = torch.randn((cout, cmid, 3, 3, 3), generator=g1) * 0.1
+    s0, h0 = torch.rand(cmid, generator=g1) + 0.5, torch.randn(cmid, generator=g1) * 0.1
+    s1, h1 = torch.rand(cout, generator=g1) + 0.5, torch.randn(cout, generator=g1) * 0.1
+    tw0 = torch.randn((4, cmid), generator=g1) * 0.3
+    tw1 = [torch.randn((4, cout), generator=g1) * 0.3 for _ in range(2)]
+    d = maxdisp // 3
+    with ra.ops.conv_precision("f16x3"):
+        assert ra.ops.costvol_stem_conv3d_supported(C, cmid, cout, B, d, h, w, ntail=2)
+        var = ra.ops.costvol_stem_prepare(gpu(w0))
+        pk = ra.ops.conv3d_k3_pack(gpu(w1))
+        outs = {}
+        for fused in (False, True, "again", "once more"):      # (repeats: the fused tail once differed from run to run, NOTES.md round 5)
+            pre0 = torch.full((B, 8, d, h, w), float("nan"), device=DEV)
+            pre1 = torch.full((B, 8, d, h, w), float("nan"), device=DEV)
+            t0 = [ra.ops.Tail(gpu(tw0), None, None, True, pre0, 0, g4=True)]
+            t1 = [ra.ops.Tail(gpu(tw1[0]), None, None, True, pre0, 4, g4=True), ra.ops.Tail(gpu(tw1[1]), None, None, False, pre1, 0, g4=True)]
+            y = torch.full((B, cout, d, h, w), float("nan"), device=DEV)
+            if fused:
+                ra.ops.costvol_stem_conv3d(gpu(L), gpu(R), maxdisp, var, cmid, gpu(s0), gpu(h0), True, t0, pk, cout, gpu(s1), gpu(h1), True, y,
+                                           None, tails=t1, store_main=True)
+            else:
+                mid = ra.ops.costvol_stem(gpu(L), gpu(R), maxdisp, var, cmid, gpu(s0), gpu(h0), True, tails=t0, out_g4=True)
+                ra.ops.conv3d_k3(mid, pk, cout, gpu(s1), gpu(h1), True, y, None, tails=t1, x_g4=True)
+            outs[fused] = (y, ra.ops.from_g4(pre0), ra.ops.from_g4(pre1))
+    for run in (True, "again", "once more"):
+        for a_, b_ in zip(outs[run], outs[False]):
+            assert torch.equal(torch.nan_to_num(a_, nan=-7.0), torch.nan_to_num(b_, nan=-7.0))
+    assert torch.isnan(outs[True][2][:, 4:]).all() and not torch.isnan(outs[True][1]).any()
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    torch.set_num_threads(16)
+    mid = F.relu(F.conv3d(O.cost_volume(L, R, maxdisp).double(), w0.double(), padding=1) * v(s0.double()) + v(h0.double()))
+    ref = F.relu(F.conv3d(mid, w1.double(), padding=1) * v(s1.double()) + v(h1.double()))
+    np.testing.assert_allclose(outs[True][0].cpu().double().numpy(), ref.numpy(), rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(outs[True][1][:, 0:4].cpu().double().numpy(), F.relu(torch.einsum("oc,bcdhw->bodhw", tw0.double(), mid)).numpy(), rtol=3e-4, atol=3e-4)
