@@ -86,7 +86,7 @@ def test_disp_vs_oracle(ra, B, d, h, w, maxdisp, scale):
         # the cost magnitude, gated on average like every end-to-end comparison
         worst = float((out.cpu() - ref).abs().max())
         print(f"disp vs oracle at |cost| ~ {scale:g}: max |err| {worst:.3e} px = {worst / scale:.2e} x scale (bound 5e-6 x scale)")
-        assert worst <= 5e-6 * scale              # measured 2.0e-6 x scale on 2 of 972 pixels at 1e4
+        assert worst <= 5e-6 * scale              # measured 2.0e-6 x scale on 2 of 972 pixels at 1e4.  Loosened once (round 4); may not grow.
     assert O.epe(out.cpu(), ref) < EPE_GATE
 
 
@@ -554,7 +554,7 @@ def _net_from_golden(ra, g, maxdisp):
 # random weights, fp32 cancellation).  Strict fp32 (RAGMI_F32): the reassociation class.  f16x3 (RAGMI_F32X3, the default): each
 # of the ~20 convolutions adds <= 3 * 2^-16 of its sum |w x| (include/rag_amd.h) — the deep levels of these small goldens run the
 # box-tile f16x3 form.  The gate that matters, EPE <= 1e-3 px, is the same for both.
-MAT_ATOL = {"fp32": 2e-6, "f16x3": 1.5e-5}
+MAT_ATOL = {"fp32": 2e-6, "f16x3": 1.5e-5}      # (f16x3: loosened to the measurement in round 4 — 7.5x the strict path's; may not grow)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "f16x3"])
@@ -761,7 +761,7 @@ def test_bf16_matchingnet_epe_report(ra):
     assert d16.dtype == torch.float32 and torch.isfinite(d16).all() and e32 <= EPE_GATE and e16 < 0.33
 
 
-BF16_FULL_GATE = 0.12     # px: measured 0.0993 / 0.0973 at the full configs[2] workload (two runs); the analysis of where it comes from is
+BF16_FULL_GATE = 0.12     # px (loosened to the measurement in round 4; may not grow): measured 0.0993 / 0.0973 at the full configs[2] workload (two runs); the analysis of where it comes from is
                           # tests/analysis_bf16_stage_epe.py + DESIGN.md 4.2 (every bf16-stored stage contributes; fp32 `mat` is already kept)
 
 
