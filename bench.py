@@ -593,7 +593,8 @@ def other_configs(net, lf, rf, out_f32, ref, device, use_graph, dist):
             "workload": f"BASELINE configs[2]: 8 stereo pairs/GPU/step, {H}x{W}, D={MAXDISP}, bf16 storage / f32 accumulate, all-conv genotype",
             "epe_bf16_vs_fp32_px": float((out[:1].double() - out_f32[:1].double()).abs().flatten(1).mean(dim=1).mean()),
             "epe_gpu_vs_cpu_px": O.epe(out[:1].float().cpu(), ref) if ref is not None else None,
-            "epe_gate_px": 0.12, "epe_note": "seeded random weights drive |cost| to 1e4-1e5: softmin is nearly an argmin (DESIGN.md 4.2)"}
+            "epe_gate_px": 0.05, "storage": "bf16 for the full-resolution (level-3) tensors, fp32 from the first cell below that resolution on (mixed storage, DESIGN.md 4.4)",
+            "epe_note": "seeded random weights drive |cost| to 1e4-1e5: softmin is nearly an argmin (DESIGN.md 4.2)"}
         log(f"  configs[2] bf16 B=8: {res['config2_bf16_b8']['value']} maps/s, EPE vs fp32 build {res['config2_bf16_b8']['epe_bf16_vs_fp32_px']:.3e}")
         del out, lf8, rf8
 
@@ -914,7 +915,7 @@ def main():
                       "the 16-bit matrix cores, hi*hi + hi*lo + lo*hi, fp32 accumulate: fp32-class accuracy, bound in include/rag_amd.h; "
                       "strict_fp32 holds the RAGMI_F32 number)"
                       if (args.dtype == "f32" and rag_amd.ops.get_conv_precision() == "f16x3") else
-                      "f32" if args.dtype == "f32" else "bf16 storage / f32 accumulate"), "data": "synthetic",
+                      "f32" if args.dtype == "f32" else "bf16 storage of the full-resolution tensors (deep levels fp32) / f32 accumulate"), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if (H, W) == (480, 960) else 1 if args.dtype == 'f32' else 2}]: {B} stereo pair(s)/GPU/step, {H}x{W}, D={MAXDISP}, {args.dtype}, "
                                    "all-conv genotype, (left_fea,right_fea)->disp, inputs resident in HBM",
                        "global_batch": n_gpus * B, "sharding": "batch split, no collective",

@@ -160,6 +160,13 @@ int ragmi_down2_tail_supported(int D, int H, int W);
 #define RAGMI_CONV_X_G4 2
 #define RAGMI_CONV_Y_G4 4
 #define RAGMI_TAIL_G4 4
+/* Mixed storage (round 5, BASELINE configs[2]): bf16 storage is kept for the full-resolution (level-3) tensors only — the deep levels and
+ * the head are fp32 (tests/analysis_bf16_stage_epe.py: they carry most of the bf16 error and almost none of the bytes).  Two edges cross:
+ *   ragmi_tail_t.relu bit 3 (RAGMI_TAIL_F32): the destination of this DOWN-SAMPLING tail is fp32 (y_bstride in floats) although the
+ *                  call's storage is RAGMI_BF16 (ignored under fp32 storage; RAGMI_EINVAL on a full-resolution tail);
+ *   dtype RAGMI_BF16 | RAGMI_OUT_F32 of ragmi_conv3d_k1_resample_fwd: x is bf16, y is fp32 (same arithmetic: fp32 on chip). */
+#define RAGMI_TAIL_F32 8
+#define RAGMI_OUT_F32 0x100
 /* bit mask: 1 = this call accepts a G4 input, 2 = it can write G4 full-resolution tails (arguments as ragmi_conv3d_k3_uses_x3) */
 int ragmi_conv3d_k3_g4_caps(int Cin, int Cout, int B, int D, int H, int W, int nset, int ntail, int ndown, int dtype);
 

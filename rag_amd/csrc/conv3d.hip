@@ -79,6 +79,7 @@ int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* tails, 
   a.ntail = 0;
   a.ndown = 0;
   a.tail_g4 = 0;
+  a.down_f32 = 0;
   if (ntail == 0 && store_main) return RAGMI_OK;
   RAGMI_REQUIRE(ntail >= 0 && ntail <= 4 && (ntail == 0 || tails != nullptr), RAGMI_EINVAL, "conv3d_k3: 0..4 tails");
   RAGMI_REQUIRE(ntail > 0 || store_main, RAGMI_EINVAL, "conv3d_k3: store_main = 0 needs at least one tail");
@@ -98,11 +99,13 @@ int fill_tails(K3Args& a, int store_main, int ntail, const ragmi_tail_t* tails, 
       a.down_shift[k] = (const float*)tails[t].shift; a.down_y[k] = tails[t].y;
       a.down_bstride[k] = tails[t].y_bstride; a.down_ch0[k] = tails[t].y_ch0; a.down_cout[k] = tails[t].cout;
       a.down_relu[k] = tails[t].relu & 1;
+      if (tails[t].relu & RAGMI_TAIL_F32) a.down_f32 |= 1 << k;
       ++a.ndown;
       continue;
     }
     const int k = a.ntail;
     RAGMI_REQUIRE(k < 2, RAGMI_EUNSUPPORTED, "conv3d_k3: at most two full-resolution tails");
+    RAGMI_REQUIRE(!(tails[t].relu & RAGMI_TAIL_F32), RAGMI_EINVAL, "conv3d_k3: RAGMI_TAIL_F32 is for down-sampling tails");
     const int g4 = (tails[t].relu & RAGMI_TAIL_G4) ? 1 : 0;
     RAGMI_REQUIRE(k == 0 || g4 == a.tail_g4, RAGMI_EUNSUPPORTED, "conv3d_k3: the full-resolution tails of a call share one layout");
     RAGMI_REQUIRE(!g4 || (tails[t].cout == 4 && tails[t].y_ch0 % 4 == 0), RAGMI_EINVAL, "conv3d_k3: a G4 tail has 4 output channels and a group-aligned y_ch0");

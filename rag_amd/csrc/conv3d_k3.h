@@ -93,6 +93,7 @@ struct K3Args {
   void* down_y[2];
   int64_t down_bstride[2];
   int down_ch0[2], down_cout[2], down_relu[2];
+  int down_f32;                   // bit k: down-sampling tail k stores fp32 although the launch's storage is bf16 (RAGMI_TAIL_F32)
   int tail_g4;     // 1: the full-resolution tails write channel-group-interleaved tensors (RAGMI_TAIL_G4; include/rag_amd.h)
   int w_in_lds;    // 1: the workgroup's weights (all chunks, both sets) are cached in LDS behind the tile
   int y_ch[RAGMI_MAX_GROUPS];    // destination channel base of each output group

@@ -461,12 +461,15 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         const int dcout = dl ? a.down_cout[1] : a.down_cout[0], drelu = dl ? a.down_relu[1] : a.down_relu[0];
         const int Y = (y0 >> 1) + yp, X = (x0 >> 1) + xp;
         if (Y < Ho && X < Wo && Z < Do && r < dcout) {
-          T* const dy = static_cast<T*>(dl ? a.down_y[1] : a.down_y[0]) + b * (dl ? a.down_bstride[1] : a.down_bstride[0]) +
-                        (int64_t)((dl ? a.down_ch0[1] : a.down_ch0[0]) + r) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
+          void* const dbase = dl ? a.down_y[1] : a.down_y[0];
+          const int64_t doff = b * (dl ? a.down_bstride[1] : a.down_bstride[0]) +
+                               (int64_t)((dl ? a.down_ch0[1] : a.down_ch0[0]) + r) * ovol + ((int64_t)Z * Ho + Y) * Wo + X;
           const bool yclamp = yt.z != 0.f, zclamp = lz.i0 != 2 * Z;      // clamped pairs read the odd source twice
           const float ye = lerp2(yt.x, yclamp ? e1 : e0, yt.y, e1), yo = lerp2(yt.x, yclamp ? o1 : o0, yt.y, o1);
           const float uu = fmaf(lerp2(wz0, zclamp ? yo : ye, wz1, yo), sc, sh);
-          st(dy, drelu ? fmaxf(uu, 0.f) : uu);
+          // (mixed storage: a bf16 launch whose half-resolution consumer keeps fp32 — RAGMI_TAIL_F32; wave-uniform)
+          if (BF && ((a.down_f32 >> dl) & 1)) static_cast<float*>(dbase)[doff] = drelu ? fmaxf(uu, 0.f) : uu;
+          else st(static_cast<T*>(dbase) + doff, drelu ? fmaxf(uu, 0.f) : uu);
         }
       }
     }

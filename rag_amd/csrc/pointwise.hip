@@ -25,6 +25,7 @@ struct K1Args {
   int64_t dhw;
   int relu;
   int w_sco, w_sci;
+  int y_f32;       // bf16 storage kernels only: y is fp32 (RAGMI_BF16 | RAGMI_OUT_F32: the resample launch that crosses into the fp32 levels)
 };
 
 template <class T, int NCO, bool VEC>
@@ -204,13 +205,16 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
       }
     }
   }
-  T* yp = static_cast<T*>(a.y) + b * a.y_bstride + o;
+  const int64_t yo = b * a.y_bstride + o;
+  const bool yf32 = !std::is_same<T, float>::value && a.y_f32;
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
     const int co = co0 + j;
     if (co >= a.Cout) break;
     float v = a.scale ? fmaf(acc[j], a.scale[co], a.shift[co]) : acc[j];
-    st(yp + (int64_t)(a.y_ch0 + co) * ovol, a.relu ? fmaxf(v, 0.f) : v);
+    v = a.relu ? fmaxf(v, 0.f) : v;
+    const int64_t off = yo + (int64_t)(a.y_ch0 + co) * ovol;
+    if (yf32) static_cast<float*>(a.y)[off] = v; else st(static_cast<T*>(a.y) + off, v);
   }
 }
 
@@ -368,10 +372,13 @@ extern "C" int ragmi_conv3d_k1_resample_fwd(const void* x, int64_t x_bstride, in
                                             int y_ch0, int B, int Cin, int Cout, int Do, int Ho, int Wo, int align_corners,
                                             int dtype, void* stream) {
   using namespace ragmi;
+  const bool out_f32 = dtype == (RAGMI_BF16 | RAGMI_OUT_F32);      // mixed storage: bf16 in, fp32 out (include/rag_amd.h)
+  if (out_f32) dtype = RAGMI_BF16;
   RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1_resample: dtype %d not built", dtype);
   K1RArgs r{};
   const int rc = fill_k1r(r, x, x_bstride, Di, Hi, Wi, weight, scale, shift, relu, y, y_bstride, y_ch0, B, Cin, Cout, Do, Ho, Wo, align_corners);
   if (rc != RAGMI_OK) return rc;
+  r.k.y_f32 = out_f32 ? 1 : 0;
   return dtype == RAGMI_BF16 ? launch_k1r<bf16_t>(&r, 1, B, static_cast<hipStream_t>(stream))
                              : launch_k1r<float>(&r, 1, B, static_cast<hipStream_t>(stream));
 }

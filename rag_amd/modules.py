@@ -212,14 +212,21 @@ class _ConvBR(nn.Module):
         squeeze = x.dim() == 4
         if squeeze:
             x = x.unsqueeze(2)
-        if resample_to is not None and tuple(resample_to) == tuple(x.shape[2:]):
+        # mixed storage (MatchingNet._run_chain): a bf16 input into an fp32 buffer is taken by the resample + 1x1x1 launch only
+        # (an input already at the output size is its identity case)
+        mixed = out is not None and out.dtype != x.dtype
+        if mixed:
+            if k != 1 or x.dtype != torch.bfloat16 or out.dtype != torch.float32:
+                raise RuntimeError("rag_amd ConvBR: only a 1x1x1 conv crosses from bf16 storage to an fp32 destination")
+            resample_to = tuple(x.shape[2:]) if resample_to is None else resample_to
+        elif resample_to is not None and tuple(resample_to) == tuple(x.shape[2:]):
             resample_to = None
         if resample_to is not None:
             if k != 1:
                 raise NotImplementedError("ConvBR: fused resample is built for the 1x1x1 form only")
             if out is None:
                 out = torch.empty((x.shape[0], cout) + tuple(int(v) for v in resample_to), device=x.device, dtype=x.dtype)
-            if _volume(resample_to) > _volume(x.shape[2:]) and cout <= x.shape[1]:
+            if not mixed and _volume(resample_to) > _volume(x.shape[2:]) and cout <= x.shape[1]:
                 # upsampling: mix the channels (and fold the BatchNorm) on the SMALL volume, then interpolate the Cout maps and
                 # apply the ReLU — both steps are affine and the taps sum to one, so only the rounding order differs
                 low = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
@@ -472,8 +479,9 @@ class _Cell(nn.Module):
 
     def _run(self, prev_prev_input, prev_input, pre: Optional[torch.Tensor] = None, pre_has=(False, False),
              tails: Optional[Sequence["ops.Tail"]] = None, store_main: bool = True, size: Optional[Sequence[int]] = None,
-             pre_g4: bool = False):
-        """forward() plus the cross-cell fusion hooks used by MatchingNet.matching:
+             pre_g4: bool = False, dtype: Optional[torch.dtype] = None):
+        """forward() plus the cross-cell fusion hooks used by MatchingNet.matching (`dtype`: this cell's storage type when it is not
+        its inputs' — mixed storage, MatchingNet._run_chain):
         `pre`/`pre_has`: the [B, 2C, ...] buffer in which the producers of the inputs have already written s0 (ch 0..C)
         and/or s1 (ch C..2C) as fused tails; `tails`/`store_main`: consumer 1x1x1 convs to compute in THIS cell's final
         conv launch (possible when one dual launch produces all new states).  Returns (concat or None, tails_applied)."""
@@ -510,7 +518,7 @@ class _Cell(nn.Module):
             raise RuntimeError("rag_amd.Cell_3d: a G4 input buffer must arrive complete from its producers' fused tails")
         if pre is None:
             B, dev = s1.shape[0], s1.device
-            pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=s1.dtype)
+            pre = torch.empty((B, 2 * C, D, H, W), device=dev, dtype=dtype or s1.dtype)
         B, dev, adt = pre.shape[0], pre.device, pre.dtype
         n_states = 2 + self._steps
         first_cat = n_states - self.block_multiplier             # first state that lands in the concat buffer
@@ -535,7 +543,7 @@ class _Cell(nn.Module):
         # down-sampling or an input already at the cell's size — shares one paired launch (measured: splitting an
         # identity + down-sampling pair into two launches costs 43 us instead of 27)
         grows = any(s is not None and _volume(size) > _volume(s.shape[2:]) and C <= s.shape[1] for s in (s0, s1))
-        if not pre_has[0] and not pre_has[1] and s0.shape[1] != C and not grows:
+        if not pre_has[0] and not pre_has[1] and s0.shape[1] != C and not grows and s0.dtype == s1.dtype == adt:
             # both 1x1x1 convs (each with its own fused resample) as ONE launch
             w0, sc0, sh0 = self.pre_preprocess.prepared()
             w1, sc1, sh1 = self.preprocess.prepared()
@@ -770,13 +778,26 @@ class MatchingNet(nn.Module):
             sizes[i] = c.out_size(sizes[i - 1])
         ref = x if x is not None else features[0]
         B, dev, adt = ref.shape[0], ref.device, ref.dtype
+        # Storage type per cell (round 5, mixed storage of BASELINE configs[2]): under bf16 storage only the FULL-RESOLUTION tensors stay
+        # bf16 — a cell that works below the cost volume's resolution (at most 1/8 of its voxels), and every cell behind one, keeps fp32
+        # (ops.set_bf16_deep_fp32: the level-12 cells and the head carry most of the bf16 error, the deep levels ~4 % of the bytes;
+        # tests/analysis_bf16_stage_epe.py).  cdt[j] = dtype of cell j's s0|s1 buffer
+        # and of its output; the stems' outputs keep `adt`.  The edges that cross are bf16 -> fp32 only: down-sampling tails
+        # (RAGMI_TAIL_F32) and the resample + 1x1x1 launch (RAGMI_OUT_F32).
+        cdt: Dict[int, torch.dtype] = {-2: adt, -1: adt}
+        for j in range(n):
+            deep = adt == torch.bfloat16 and ops.bf16_deep_fp32_enabled() and (
+                _volume(sizes[j]) * ops.bf16_deep_fp32_ratio() <= _volume(vol) or cdt[j - 1] == torch.float32 or cdt[j - 2] == torch.float32)
+            cdt[j] = torch.float32 if deep else adt
 
         def down_ok(i, j):
             """cell j's 1x1x1 conv on T[i] as DOWN-SAMPLING tails of T[i]'s producer: cell j works at exactly half of T[i]'s size,
             the source pairs of that x0.5 resampling are aligned, and the producer is a level-3 dual launch on the z-marching
             split-operand kernel (fp32 storage under the default precision, or bf16 storage) — the only form that takes them"""
-            if i < 0 or (adt == torch.float32 and ops.get_conv_precision() != "f16x3"):
+            if i < 0 or (cdt[i] == torch.float32 and ops.get_conv_precision() != "f16x3"):
                 return False
+            if cdt[j] != cdt[i] and not (cdt[i] == torch.bfloat16 and cdt[j] == torch.float32):
+                return False          # (a bf16 producer may write fp32 down-sampling tails: RAGMI_TAIL_F32; nothing else crosses)
             src, dst, prod = sizes[i], sizes[j], cells[i]
             if tuple(2 * v for v in dst) != tuple(src) or not ops.down2_tail_supported(*src):
                 return False
@@ -786,13 +807,14 @@ class MatchingNet(nn.Module):
             # the producer: one dual launch with all its new states (what `_run` calls single_dual), 12 output channels, on the x3 form
             if prod.downup_sample != 0 or prod.C_out * prod._steps > 16 or prod.C_out != 4:
                 return False
-            return ops.conv3d_k3_uses_x3(2 * prod.C_out, prod.C_out * prod._steps, B, *src, nset=2, ntail=1, dtype=adt)
+            return ops.conv3d_k3_uses_x3(2 * prod.C_out, prod.C_out * prod._steps, B, *src, nset=2, ntail=1, dtype=cdt[i])
 
         def fusable(i):
             """consumers of T[i] that can ride on its producer: [(cell index j, role 0 = pre_preprocess / 1 = preprocess, down)]"""
             out = []
             j = i + 1
-            if 0 <= j < n and cells[j].downup_sample == 0 and cells[j].C_out <= 4 and cells[j].C_out % 4 == 0:
+            same = lambda jj: cdt[jj] == cdt[i]  # noqa: E731  (full-resolution tails store the producer's own type)
+            if 0 <= j < n and cells[j].downup_sample == 0 and cells[j].C_out <= 4 and cells[j].C_out % 4 == 0 and same(j):
                 out.append((j, 1, False))
             elif 0 <= j < n and cells[j].downup_sample == -1 and down_ok(i, j):
                 out.append((j, 1, True))
@@ -801,7 +823,7 @@ class MatchingNet(nn.Module):
             # not cells[-1], the LAST cell)
             mid_same = j - 1 < 0 or (j - 1 < n and cells[j - 1].downup_sample == 0)
             if (0 <= j < n and cells[j].downup_sample == 0 and mid_same and cells[j].C_out <= 4
-                    and cells[j].C_out % 4 == 0 and cells[j].C_prev_prev != cells[j].C_out):
+                    and cells[j].C_out % 4 == 0 and cells[j].C_prev_prev != cells[j].C_out and same(j)):
                 out.append((j, 0, False))
             elif (0 <= j < n and cells[j].downup_sample == -1 and mid_same and cells[j].C_prev_prev != cells[j].C_out
                   and down_ok(i, j)):
@@ -869,7 +891,7 @@ class MatchingNet(nn.Module):
             specs = []
             for (j, role, down) in fusable(i):
                 if j not in pre:
-                    pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=adt)
+                    pre[j] = torch.empty((B, 2 * cells[j].C_out) + sizes[j], device=dev, dtype=cdt[j])
                     has[j] = [False, False]
                 mod = cells[j].preprocess if role == 1 else cells[j].pre_preprocess
                 ch0 = cells[j].C_out if role == 1 else 0
@@ -933,11 +955,13 @@ class MatchingNet(nn.Module):
             ci, cj = cells[i], cells[j]
             if s0 is None or s1 is None or s0.shape[1] == ci.C_out or s1.shape[1] == cj.C_out or tuple(s1.shape[2:]) == sizes[i]:
                 return
+            if len({s0.dtype, s1.dtype, cdt[i], cdt[j]}) > 1:
+                return        # (mixed storage: the crossing launches stay with their cells)
             if any(_volume(sizes[i]) > _volume(t.shape[2:]) for t in (s0, s1)):
                 return        # an up-sampling input runs conv-first (two launches): stays with its cell
             for k in (i, j):
                 if k not in pre:
-                    pre[k] = torch.empty((B, 2 * cells[k].C_out) + sizes[k], device=dev, dtype=adt)
+                    pre[k] = torch.empty((B, 2 * cells[k].C_out) + sizes[k], device=dev, dtype=cdt[k])
                     has[k] = [False, False]
             ops.conv3d_k1_resample_multi([(s0,) + ci.pre_preprocess.prepared() + (ci.pre_preprocess.relu, pre[i], 0),
                                           (s1,) + ci.preprocess.prepared() + (ci.preprocess.relu, pre[i], ci.C_out),
@@ -950,7 +974,7 @@ class MatchingNet(nn.Module):
             specs = tails_for(i)
             need_main = i == n - 1 or len(specs) < len(all_consumers(i))   # the head reads the last cell's output
             cat, applied = c._run(T[i - 2], T[i - 1], pre=pre.get(i), pre_has=tuple(has.get(i, (False, False))),
-                                  tails=flat(specs), store_main=need_main, size=sizes[i], pre_g4=g4[i])
+                                  tails=flat(specs), store_main=need_main, size=sizes[i], pre_g4=g4[i], dtype=cdt[i])
             settle(i, specs, applied, cat)
             T[i] = cat
             T.pop(i - 2, None)

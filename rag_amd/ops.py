@@ -95,6 +95,15 @@ def _act(*ts: torch.Tensor) -> int:
     return _DT[dt]
 
 
+def _act_with_tails(x, out, res, tails) -> int:
+    """_act over a 3x3x3 call's tensors; a DOWN-SAMPLING tail of a bf16 call may have an fp32 destination (RAGMI_TAIL_F32)."""
+    dt = _act(x, out, res, *[t.out for t in (tails or []) if not (t.down and x.dtype == torch.bfloat16 and t.out.dtype == torch.float32)])
+    for t in (tails or []):
+        if not t.out.is_cuda:
+            raise RuntimeError("rag_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback")
+    return dt
+
+
 def _planes(t: torch.Tensor) -> int:
     """Check t is [B, C, ...] with dense channel planes (a channel-slice view of a contiguous
     buffer is fine) and return its batch stride in elements."""
@@ -114,6 +123,29 @@ def _i32_array(vals: Optional[Sequence[int]]):
 
 # bits of the `relu` argument / of ragmi_tail_t.relu (include/rag_amd.h): channel-group-interleaved ("G4") tensors
 CONV_X_G4, CONV_Y_G4, TAIL_G4 = 2, 4, 4
+TAIL_F32, OUT_F32 = 8, 0x100      # mixed storage (include/rag_amd.h): a bf16 launch's down-sampling tail / resample launch writing fp32
+_BF16_DEEP_F32 = [os.environ.get("RAGMI_BF16_DEEP_F32", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling)
+
+
+def set_bf16_deep_fp32(enabled: bool) -> None:
+    """bf16 activation storage (BASELINE configs[2]) for the FULL-RESOLUTION tensors only: the fused executor keeps the cells that work
+    below the cost volume's resolution, and everything behind them, in fp32 (tests/analysis_bf16_stage_epe.py: the level-12 cells
+    and the head carry most of the bf16 error and ~2 % of the bytes).  False = every stored tensor bf16 (rounds 1-4)."""
+    _BF16_DEEP_F32[0] = bool(enabled)
+
+
+def bf16_deep_fp32_enabled() -> bool:
+    return _BF16_DEEP_F32[0]
+
+
+_BF16_DEEP_RATIO = [int(os.environ.get("RAGMI_BF16_DEEP_RATIO", "8"))]      # (A/B tooling: 64 = the first level-6 cell stays bf16)
+
+
+def bf16_deep_fp32_ratio() -> int:
+    """A cell keeps fp32 under mixed storage when its volume is at most 1/ratio of the cost volume's (8: level 6 and below.  Measured
+    with 64 — the first level-6 cell bf16, fp32 from level 12 on: 0.029 / 0.097 px against 0.025 / 0.073 at the two cost scales of
+    test_bf16_storage_epe_at_two_cost_scales and no faster, 1 368 vs 1 376 maps/s: its consumers then need two crossing launches)."""
+    return _BF16_DEEP_RATIO[0]
 _G4 = [os.environ.get("RAGMI_G4", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling); set_g4 chooses afterwards
 
 
@@ -186,7 +218,8 @@ class Tail:
 
     def spec(self) -> TailSpec:
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        return TailSpec(p(self.weight2d), p(self.scale), p(self.shift), int(self.relu) | (2 if self.down else 0) | (TAIL_G4 if self.g4 else 0), self.out.data_ptr(),
+        f32 = TAIL_F32 if (self.down and self.out.dtype == torch.float32) else 0      # (only read by bf16-storage launches)
+        return TailSpec(p(self.weight2d), p(self.scale), p(self.shift), int(self.relu) | (2 if self.down else 0) | (TAIL_G4 if self.g4 else 0) | f32, self.out.data_ptr(),
                         _planes(self.out), int(self.out_ch0), int(self.weight2d.shape[0]))
 
 
@@ -337,7 +370,7 @@ def conv3d_k3(x: torch.Tensor, packed: torch.Tensor, cout: int, scale: Optional[
     if x_g4 and not x.is_contiguous():
         raise ValueError("conv3d_k3: a G4 input is a contiguous buffer")
     _need_gpu(packed, scale, shift)
-    dt = _act(x, out, res, *[t.out for t in (tails or [])])
+    dt = _act_with_tails(x, out, res, tails)
     B, Cin, D, H, W = x.shape
     xb = _planes(x)
     yb = _planes(out)
@@ -393,7 +426,7 @@ def conv3d_k3_dual(x: torch.Tensor, cin_a: int, packed_a: torch.Tensor, scale_a,
     if x_g4 and not x.is_contiguous():
         raise ValueError("conv3d_k3_dual: a G4 input is a contiguous buffer")
     _need_gpu(packed_a, packed_b, scale_a, shift_a, scale_b, shift_b)
-    dt = _act(x, out, res, *[t.out for t in (tails or [])])
+    dt = _act_with_tails(x, out, res, tails)
     B, Cx, D, H, W = x.shape
     ng = packed_groups(cout)
     if out_group_ch is not None and len(out_group_ch) != ng:
@@ -438,9 +471,14 @@ def conv3d_k1(x: torch.Tensor, weight2d: torch.Tensor, scale: Optional[torch.Ten
 def conv3d_k1_resample(x: torch.Tensor, size: Sequence[int], align_corners: bool, weight2d: torch.Tensor,
                        scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool, out: torch.Tensor,
                        out_ch0: int = 0) -> torch.Tensor:
-    """act(bn(conv1x1x1(F.interpolate(x, size, 'trilinear', align_corners)))) without materialising the resampled tensor."""
+    """act(bn(conv1x1x1(F.interpolate(x, size, 'trilinear', align_corners)))) without materialising the resampled tensor.
+    x bf16 with an fp32 `out` is the one mixed-storage form (RAGMI_BF16 | RAGMI_OUT_F32: same fp32 arithmetic on chip)."""
     _need_gpu(weight2d, scale, shift)
-    dt = _act(x, out)
+    if x.dtype == torch.bfloat16 and out.dtype == torch.float32:
+        dt = _act(x) | OUT_F32
+        _act(out)
+    else:
+        dt = _act(x, out)
     B, Cin, Di, Hi, Wi = x.shape
     Do, Ho, Wo = [int(v) for v in size]
     Cout = weight2d.shape[0]

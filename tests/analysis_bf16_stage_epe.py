@@ -61,17 +61,20 @@ def main():
     H, W, maxdisp = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (192, 384, 96)
     rows = O.ALL_CONV
     torch.set_num_threads(8)
-    for seed in (0, 4):
+    for seed, f in ((0, 1.0), (4, 1.0), (0, 1e-3)):       # (f: last_3_3d's weight scaled — |cost| ~ 10-100, a trained net's cost scale)
         sd = O.random_matching_state_dict(rows, seed=seed)
+        sd["last_3_3d.0.conv.weight"] = sd["last_3_3d.0.conv.weight"] * f
         g = torch.Generator().manual_seed(1234)
         lf, rf = torch.randn((1, 12, H // 3, W // 3), generator=g), torch.randn((1, 12, H // 3, W // 3), generator=g)
         ref, mat = run(lf, rf, sd, rows, maxdisp, set())
-        print(f"seed {seed}: {H}x{W} D={maxdisp}; |mat| max {float(mat.abs().max()):.3g}, std {float(mat.std()):.3g}")
+        print(f"seed {seed}, last_3_3d weight x {f:g}: {H}x{W} D={maxdisp}; |mat| max {float(mat.abs().max()):.3g}, std {float(mat.std()):.3g}")
         everything = {"input", "stems", "l3", "l6", "l12", "head", "mat"}
         for name, st in [("all stored tensors bf16", everything), ("all but mat", everything - {"mat"}),
                          ("all but mat and head", everything - {"mat", "head"}),
                          ("only mat", {"mat"}), ("only head", {"head"}), ("only input", {"input"}), ("only stems", {"stems"}),
-                         ("only level-3 cells", {"l3"}), ("only level-6 cells", {"l6"}), ("only level-12 cells", {"l12"})]:
+                         ("only level-3 cells", {"l3"}), ("only level-6 cells", {"l6"}), ("only level-12 cells", {"l12"}),
+                         ("MIXED: input + stems + level 3", {"input", "stems", "l3"}),
+                         ("MIXED: ... + level 6", {"input", "stems", "l3", "l6"})]:
             out, _ = run(lf, rf, sd, rows, maxdisp, st)
             print(f"   {name:28s} EPE vs fp32 = {O.epe(out, ref):.4e} px")
 

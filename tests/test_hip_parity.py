@@ -756,13 +756,17 @@ def test_bf16_matchingnet_epe_report(ra):
     ref = O.matching_net_forward(lf, rf, sd, rows, 96)
     e32, e16, e16_32 = O.epe(d32, ref), O.epe(d16, ref), O.epe(d16, d32)
     print(f"EPE fp32 vs oracle {e32:.3e}; bf16 vs oracle {e16:.3e}; bf16 vs fp32 build {e16_32:.3e} px (maxdisp 96)")
-    # bf16 storage at this reduced size: measured 0.219 / 0.221 px (two boxes); the bound is the measurement + 50 %.  The stated
-    # tolerance of the bf16 configuration is enforced on the full workload below (BF16_FULL_GATE).
-    assert d16.dtype == torch.float32 and torch.isfinite(d16).all() and e32 <= EPE_GATE and e16 < 0.33
+    # bf16 storage at this reduced size: 0.219 / 0.221 px with every tensor bf16 (rounds 2-4); 0.039 px with the mixed storage of round 5
+    # (full-resolution tensors bf16, deep levels and head fp32).  The stated tolerance of the bf16 configuration is enforced on the
+    # full workload below (BF16_FULL_GATE).
+    assert d16.dtype == torch.float32 and torch.isfinite(d16).all() and e32 <= EPE_GATE and e16 < 0.08
 
 
-BF16_FULL_GATE = 0.12     # px (loosened to the measurement in round 4; may not grow): measured 0.0993 / 0.0973 at the full configs[2] workload (two runs); the analysis of where it comes from is
-                          # tests/analysis_bf16_stage_epe.py + DESIGN.md 4.2 (every bf16-stored stage contributes; fp32 `mat` is already kept)
+BF16_FULL_GATE = 0.05     # px — SURVEY's gate for configs[2].  Round 5 (mixed storage: bf16 for the full-resolution tensors, fp32 from the first
+                          # cell below the cost volume's resolution on — ops.set_bf16_deep_fp32): measured 0.0249 px at the full configs[2]
+                          # workload.  Rounds 2-4 stored every tensor bf16: 0.0993 / 0.0973 px under a gate of 0.12 (still checked below as
+                          # BF16_ALL_GATE, which may not grow).  Where the error comes from: tests/analysis_bf16_stage_epe.py.
+BF16_ALL_GATE = 0.12
 
 
 def test_bf16_config3_full_workload_gate(ra):
@@ -789,6 +793,16 @@ def test_bf16_config3_full_workload_gate(ra):
     assert d16.dtype == torch.float32 and torch.isfinite(d16).all()
     assert e32 <= EPE_GATE, e32
     assert e16 <= BF16_FULL_GATE, e16
+    # every stored tensor bf16 (rounds 2-4; ops.set_bf16_deep_fp32(False)): the old form keeps its old gate
+    ra.ops.set_bf16_deep_fp32(False)
+    try:
+        with torch.no_grad():
+            dall = net(gpu(lf[:1]).to(BF), gpu(rf[:1]).to(BF)).cpu()
+    finally:
+        ra.ops.set_bf16_deep_fp32(True)
+    eall = O.epe(dall, ref)
+    print(f"configs[2] full size, every stored tensor bf16: EPE vs oracle {eall:.3e} px")
+    assert e16 < eall <= BF16_ALL_GATE, (e16, eall)
 
 
 def test_bf16_storage_epe_at_two_cost_scales(ra):
@@ -821,8 +835,11 @@ def test_bf16_storage_epe_at_two_cost_scales(ra):
         print(f"last_3_3d weight x {f:g}: max |cost| {out[f][0]:.3g}; bf16 storage vs fp32 build: max |mat err| / max |mat| {rel:.2e}, "
               f"EPE {out[f][1]:.3e} px (max {out[f][2]:.3f} px)")
     assert out[1.0][0] > 1e3 and out[1e-3][0] < 1e3                    # the two regimes
-    assert out[1.0][1] <= BF16_FULL_GATE and out[1e-3][1] <= 0.5       # the stated gates of configs[2]
-    assert max(out[1.0][3], out[1e-3][3]) <= 2e-2                       # the relative error of `mat` under bf16 storage
+    # the stated gates of configs[2] (<= 0.05 px at the benchmark's weights, <= 0.1 px at the trained-net cost scale).
+    # Round 5, mixed storage: measured 0.0252 / 0.0730 px, relative error of `mat` 4.2e-3 (rounds 2-4, every tensor bf16: 0.075-0.097 /
+    # 0.29 px, 1.1e-2)
+    assert out[1.0][1] <= BF16_FULL_GATE and out[1e-3][1] <= 0.1
+    assert max(out[1.0][3], out[1e-3][3]) <= 8e-3                       # the relative error of `mat` under bf16 storage
 
 
 # --------------------------------------------------------------------------- grown model: checkpoint round trip + serving (N4)
@@ -1223,6 +1240,94 @@ def test_x3_down_sampling_tails_bf16_storage(ra):
     got = out.float().cpu().double()
     assert torch.isnan(got[:, 0]).all() and torch.isnan(got[:, 9:]).all()
     np.testing.assert_allclose(got[:, 1:9].numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
+
+
+def test_mixed_storage_edges_round_to_the_bf16_results(ra):
+    """The two launches that cross from bf16 storage into the fp32 levels (round 5, include/rag_amd.h "Mixed storage"): a
+    down-sampling tail with an fp32 destination (RAGMI_TAIL_F32) and the resample + 1x1x1 launch with an fp32 output
+    (RAGMI_BF16 | RAGMI_OUT_F32) do the arithmetic of their bf16-destination twins and skip the final rounding — so rounding their
+    output to bf16 gives the twins' bits; nothing else of the launch changes."""
+    B, D, H, W = 1, 16, 128, 128
+    C, cout = 4, 12
+    g1 = gen(233)
+    x = torch.randn((B, 2 * C, D, H, W), generator=g1).to(torch.bfloat16)
+    wa, wb = (torch.randn((cout, C, 3, 3, 3), generator=g1) * 0.2 for _ in range(2))
+    sa, sb = (torch.rand(cout, generator=g1) + 0.5 for _ in range(2))
+    ha, hb = (torch.randn(cout, generator=g1) * 0.1 for _ in range(2))
+    half = (D // 2, H // 2, W // 2)
+    tw, ts, th = torch.randn((8, cout), generator=g1) * 0.3, torch.rand(8, generator=g1) + 0.5, torch.randn(8, generator=g1) * 0.1
+    gw, gs, gh = gpu(tw), gpu(ts), gpu(th)
+    pa, pb = ra.ops.conv3d_k3_pack(gpu(wa)), ra.ops.conv3d_k3_pack(gpu(wb))
+    res = {}
+    for odt in (torch.bfloat16, torch.float32):
+        out = torch.full((B, 10) + half, float("nan"), device=DEV, dtype=odt)
+        tails = [ra.ops.Tail(gw[c0:c0 + 4], gs[c0:c0 + 4], gh[c0:c0 + 4], True, out, 1 + c0, down=True) for c0 in (0, 4)]
+        y = torch.full((B, cout, D, H, W), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ra.ops.conv3d_k3_dual(gpu(x), C, pa, gpu(sa), gpu(ha), pb, gpu(sb), gpu(hb), cout, True, y, tails=tails)
+        res[odt] = (y, out)
+    assert torch.equal(res[torch.float32][0], res[torch.bfloat16][0])
+    o32, o16 = res[torch.float32][1], res[torch.bfloat16][1]
+    assert o32.dtype == torch.float32 and torch.isnan(o32[:, 0]).all() and torch.isnan(o32[:, 9:]).all()
+    assert torch.equal(o32[:, 1:9].to(torch.bfloat16), o16[:, 1:9])
+    assert not torch.equal(o32[:, 1:9], o16[:, 1:9].float())           # (the fp32 destination really keeps more bits)
+    # a full-resolution tail cannot cross: loud failure, not a reinterpretation of the buffer
+    bad = ra.ops.Tail(gw[:4], gs[:4], gh[:4], True, torch.empty((B, 4, D, H, W), device=DEV), 0)
+    with pytest.raises(RuntimeError):
+        ra.ops.conv3d_k3_dual(gpu(x), C, pa, gpu(sa), gpu(ha), pb, gpu(sb), gpu(hb), cout, True,
+                              torch.empty((B, cout, D, H, W), device=DEV, dtype=torch.bfloat16), tails=[bad])
+    # resample + 1x1x1: x0.25 (cell 4's pre_preprocess), x0.5, and an input already at the output size
+    xin = torch.randn((2, 12, 16, 40, 48), generator=g1).to(torch.bfloat16)
+    w2 = torch.randn((16, 12), generator=g1) * 0.3
+    s2, h2 = torch.rand(16, generator=g1) + 0.5, torch.randn(16, generator=g1) * 0.1
+    for size in ((4, 10, 12), (8, 20, 24), (16, 40, 48)):
+        o16 = torch.full((2, 18) + size, float("nan"), device=DEV, dtype=torch.bfloat16)
+        o32 = torch.full((2, 18) + size, float("nan"), device=DEV)
+        ra.ops.conv3d_k1_resample(gpu(xin), size, True, gpu(w2), gpu(s2), gpu(h2), True, o16, 1)
+        ra.ops.conv3d_k1_resample(gpu(xin), size, True, gpu(w2), gpu(s2), gpu(h2), True, o32, 1)
+        assert torch.isnan(o32[:, 0]).all() and torch.isnan(o32[:, 17]).all()
+        assert torch.equal(o32[:, 1:17].to(torch.bfloat16), o16[:, 1:17]), size
+        low = F.interpolate(xin.float(), size, mode="trilinear", align_corners=True).double()
+        ref = F.relu(torch.einsum("oc,bcdhw->bodhw", w2.double(), low) * s2.double().view(1, -1, 1, 1, 1) + h2.double().view(1, -1, 1, 1, 1))
+        np.testing.assert_allclose(o32[:, 1:17].cpu().double().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+    with pytest.raises(RuntimeError):       # fp32 -> bf16 is not a crossing the executor makes
+        ra.ops.conv3d_k1_resample(gpu(xin).float(), (8, 20, 24), True, gpu(w2), gpu(s2), gpu(h2), True,
+                                  torch.empty((2, 16, 8, 20, 24), device=DEV, dtype=torch.bfloat16), 0)
+
+
+def test_matchingnet_mixed_storage_plan(ra):
+    """What MatchingNet._run_chain stores in which type under bf16 inputs (ops.set_bf16_deep_fp32): the level-3 cells' buffers bf16,
+    everything from the first cell below the cost volume's resolution on fp32; with the switch off every buffer bf16."""
+    rows = O.ALL_CONV
+    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=48)
+    net.load_state_dict(O.random_matching_state_dict(rows, seed=3), strict=True)
+    net = net.to(DEV).eval()
+    lf, rf = (torch.randn((1, 12, 48, 72), generator=gen(7 + k)) for k in range(2))
+    seen = {}
+    orig = ra.ops.conv3d_k3_dual
+
+    def spy(x, *a, **kw):
+        seen.setdefault(tuple(x.shape[2:]), set()).add(x.dtype)
+        return orig(x, *a, **kw)
+
+    ra.ops.conv3d_k3_dual = spy
+    try:
+        with torch.no_grad():
+            d_mixed = net(gpu(lf).to(BF), gpu(rf).to(BF))
+            mixed = {k: set(v) for k, v in seen.items()}
+            seen.clear()
+            ra.ops.set_bf16_deep_fp32(False)
+            d_all = net(gpu(lf).to(BF), gpu(rf).to(BF))
+            every = {k: set(v) for k, v in seen.items()}
+            d32 = net(gpu(lf), gpu(rf))
+    finally:
+        ra.ops.conv3d_k3_dual = orig
+        ra.ops.set_bf16_deep_fp32(True)
+    full = (16, 48, 72)
+    assert mixed[full] == {torch.bfloat16} and all(v == {torch.float32} for k, v in mixed.items() if k != full) and len(mixed) == 3
+    assert all(v == {torch.bfloat16} for v in every.values()) and len(every) == 3
+    e_mixed, e_all = O.epe(d_mixed.cpu(), d32.cpu()), O.epe(d_all.cpu(), d32.cpu())
+    print(f"EPE vs the fp32 build: mixed storage {e_mixed:.3e} px, every tensor bf16 {e_all:.3e} px")
+    assert e_mixed < e_all
 
 
 def test_x3_dual_tails_and_headline_epe(ra, x3_on):

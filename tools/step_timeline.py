@@ -19,7 +19,7 @@ def short(name: str) -> str:
     return re.sub(r"\(.*$", "", name)
 
 
-def main(root: str, first: str = "costvol_stem_planes_mfma_kernel") -> None:
+def main(root: str, first: str = "costvol_stem_planes_mfma_kernel", must: str = "") -> None:
     files = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)
     if not files:
         raise SystemExit("no *kernel_trace.csv under " + root)
@@ -32,13 +32,15 @@ def main(root: str, first: str = "costvol_stem_planes_mfma_kernel") -> None:
     ends = [i for i, r in enumerate(rows) if "disp_softargmin" in r[2]]
     if not starts or not ends:
         raise SystemExit("no forward pass found")
-    # the last complete pass of that kind (first kernel ... the next soft-argmin)
-    s = starts[-1]
-    later = [i for i in ends if i > s]
-    if not later:
-        s = starts[-2]
-        later = [i for i in ends if i > s]
-    e = later[0]
+    # the last complete pass of that kind (first kernel ... the next soft-argmin) [that holds a kernel whose name contains `must`]
+    s = e = None
+    for cand in reversed(starts):
+        later = [i for i in ends if i > cand]
+        if later and (not must or any(must in r[2] for r in rows[cand:later[0] + 1])):
+            s, e = cand, later[0]
+            break
+    if s is None:
+        raise SystemExit("no complete forward pass found")
     t0 = rows[s][0]
     print("start_us  dur_us  gap_us  kernel")
     prev_end = t0
@@ -52,4 +54,5 @@ def main(root: str, first: str = "costvol_stem_planes_mfma_kernel") -> None:
 
 if __name__ == "__main__":
     # optional second argument: name fragment of the pass's FIRST kernel (conv2d_k3_strided_kernel = the end-to-end pass from images)
-    main(sys.argv[1] if len(sys.argv) > 1 else ".", *(sys.argv[2:3]))
+    # optional third argument: a name fragment some kernel of the pass must contain (e.g. bf16 for the bf16-storage pass)
+    main(sys.argv[1] if len(sys.argv) > 1 else ".", *(sys.argv[2:4]))
