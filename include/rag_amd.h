@@ -166,6 +166,12 @@ int ragmi_down2_tail_supported(int D, int H, int W);
  *                  call's storage is RAGMI_BF16 (ignored under fp32 storage; RAGMI_EINVAL on a full-resolution tail);
  *   dtype RAGMI_BF16 | RAGMI_OUT_F32 of ragmi_conv3d_k1_resample_fwd: x is bf16, y is fp32 (same arithmetic: fp32 on chip). */
 #define RAGMI_TAIL_F32 8
+/* ragmi_costvol_stem_conv3d_fwd only, tails0[0].relu bit 4 (RAGMI_TAIL_ROWS): this tail (4 output channels on stem3d0's 12) is NOT evaluated
+ * from `weight` by the staging thread but falls out of stem3d1's matrix product: the caller packed stem3d1's weight as a SIXTEEN-channel
+ * convolution whose rows 12..15 hold the tail's weights at the centre tap (zero elsewhere) — rows the 12-channel product leaves idle.  Cout
+ * stays 12; the tail's scale / shift / relu / y are used as ever, its products are split-operand ones like the convolution's (the
+ * RAGMI_F32X3 bound) instead of an exact fp32 chain. */
+#define RAGMI_TAIL_ROWS 16
 #define RAGMI_OUT_F32 0x100
 /* bit mask: 1 = this call accepts a G4 input, 2 = it can write G4 full-resolution tails (arguments as ragmi_conv3d_k3_uses_x3) */
 int ragmi_conv3d_k3_g4_caps(int Cin, int Cout, int B, int D, int H, int W, int nset, int ntail, int ndown, int dtype);

@@ -81,6 +81,9 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   const int cog = blockIdx.y;
   const int HW = a.H * a.W;
   float act_floor = (a.relu & 1) ? 0.f : __builtin_nanf("");   // max(u, NaN) = u: the identity, NaN inputs included
+  if constexpr (ABX) {      // rows 12..15 of the product = stem3d0's fused tail (RAGMI_TAIL_ROWS): its own activation
+    if (e.src.tail_rows && kb == 3) act_floor = e.src.tail_relu ? 0.f : __builtin_nanf("");
+  }
   asm volatile("" : "+v"(act_floor));      // opaque: otherwise the compiler turns max(u, floor) back into max(u, 0) + a select per value
   const int64_t DHW = (int64_t)HW * a.D;
 #ifdef RAGMI_DIAG
@@ -148,6 +151,14 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         sh = psh ? psh[co] : 0.f;
       }
     }
+    if constexpr (ABX) {      // rows 12..15: the fused tail's BatchNorm x its rows' weight scale 2^-k (the pack is a 16-channel one)
+      if (e.src.tail_rows && tid >= 12 && tid < 16) {
+        const float* const tsc = e.src.tail_scale;
+        const float* const tsh = e.src.tail_shift;
+        sc = (tsc ? tsc[tid - 12] : 1.f) * e.wmul[0][tid];
+        sh = tsh ? tsh[tid - 12] : 0.f;
+      }
+    }
     par[tid] = sc;
     par[96 + tid] = sc;
     par[32 + tid] = sh;
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const float idv = isshift ? 0.f : 1.f;
       lsrc[tid] = pp ? make_float4(pp[4 * cg], pp[4 * cg + 1], pp[4 * cg + 2], pp[4 * cg + 3]) : make_float4(idv, idv, idv, idv);
     }
-    if (e.src.ntail > 0 && tid >= 64 && tid < 64 + 4 * NCG + 2) {      // the fused tail: w[0..3][c] per input channel c, then its scale and shift
+    if (e.src.ntail > 0 && !e.src.tail_rows && tid >= 64 && tid < 64 + 4 * NCG + 2) {      // the fused tail: w[0..3][c] per input channel c, then its scale and shift
       const int c = tid - 64;
       const float* const tw = e.src.tail_w;
       const float* const tsc = e.src.tail_scale;
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           pf[cg][c] = v[cg][c];
         }
       }
-      if (e.src.ntail > 0 && vinterior && gz >= zlo && gz < zhi) {
+      if (e.src.ntail > 0 && !e.src.tail_rows && vinterior && gz >= zlo && gz < zhi) {
         float u[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4 * NCG; ++c) {
@@ -636,6 +647,17 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
           T* py = static_cast<T*>(a.y) + b * a.y_bstride + (int64_t)my_ych * DHW + vox;
 #pragma unroll
           for (int r = 0; r < 4; ++r) st(py + r * DHW, v[r]);      // whole 4-channel output groups only (x3_eligible)
+        }
+        if constexpr (ABX) {
+          // rows 12..15 (lane quarter 3): stem3d0's fused tail, already through its BatchNorm and activation above
+          if (e.src.tail_rows && g == 3 && inside && !(dg_nostore && v[0] != 12345.f)) {
+            if (e.src.tail_g4) {
+              *reinterpret_cast<float4*>(tdst + ((int64_t)(e.src.tail_ch0 >> 2) * DHW + vox) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tdst[(int64_t)(e.src.tail_ch0 + r) * DHW + vox] = v[r];
+            }
+          }
         }
         if constexpr (TAILS) {
           f32x4 tacc = {0.f, 0.f, 0.f, 0.f};
@@ -1189,6 +1211,7 @@ int x3_launch(K3Args a, int nset, int dtype, hipStream_t st, const X3StemSrc* sr
   X3Extra e{};
   if (src) e.src = *src;
   x3_weight_sections(e, a, nset, dtype);
+  if (src && src->tail_rows) { K3Args t16 = a; t16.Cout = 16; x3_weight_sections(e, t16, nset, dtype); }      // (the caller's pack is a 16-channel one: RAGMI_TAIL_ROWS)
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0), ncgs = ncg / nset, nsls = (ncgs * 27 + 7) / 8, nsl = nset * nsls;
   a.tiles_x = (int)ceil_div(a.W, X3_TX); a.tiles_y = (int)ceil_div(a.H, X3_TY);
   const int ncog = (a.Cout + 15) / 16;

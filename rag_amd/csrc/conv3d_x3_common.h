@@ -192,6 +192,7 @@ struct X3StemSrc {
   const float* tail_shift;
   float* tail_y;
   int64_t tail_bstride;
+  int tail_rows;              // the fused tail of stem3d0 is computed by rows 12..15 of the matrix product (RAGMI_TAIL_ROWS), not by the staging thread
 };
 
 struct X3Extra {

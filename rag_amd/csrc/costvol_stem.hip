@@ -594,6 +594,9 @@ extern "C" int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right
                 stream, &l);
   if (rc != RAGMI_OK) return rc;
   X3StemSrc src{};
+  if (ntail0 >= 1 && (tails0[0].relu & RAGMI_TAIL_ROWS))
+    RAGMI_REQUIRE(tail_in_staging && Cout == 12, RAGMI_EINVAL, "costvol_stem_conv3d: RAGMI_TAIL_ROWS takes ONE 4-channel tail behind a 12-channel stem3d1 (packed as 16 channels)");
+  src.tail_rows = (tail_in_staging && (tails0[0].relu & RAGMI_TAIL_ROWS)) ? 1 : 0;
   if (tail_in_staging) {
     src.ntail = 1; src.tail_relu = tails0[0].relu & 1; src.tail_ch0 = tails0[0].y_ch0; src.tail_g4 = (tails0[0].relu & RAGMI_TAIL_G4) ? 1 : 0;
     src.tail_w = (const float*)tails0[0].weight; src.tail_scale = (const float*)tails0[0].scale; src.tail_shift = (const float*)tails0[0].shift;

@@ -927,10 +927,23 @@ class MatchingNet(nn.Module):
             _w0, scale0, shift0 = stem0.prepared()
             wk1, scale1, shift1 = stem1.prepared()
             cout1 = stem1.conv.out_channels
+            # cell 0's pre_preprocess (the one tail on stem3d0's output) in the four idle rows of stem3d1's 12-channel matrix product
+            t0s = flat(specs)
+            rows = ops.stem_tail_rows_enabled() and cout1 == 12 and t0s is not None and len(t0s) == 1 and t0s[0].weight2d.shape[0] == 4
+            if rows:
+                tmod = cells[0].pre_preprocess
+                key = (stem1.stamp(), tmod.stamp())
+                hit = getattr(stem1, "_rows_cache", None)
+                if hit is None or hit[0] != key:
+                    with torch.no_grad():
+                        hit = (key, ops.conv3d_k3_pack(ops.stem_tail_rows_weight(stem1.conv.weight.detach(), t0s[0].weight2d)))
+                    stem1._rows_cache = hit
+                wk1 = hit[1]
+            self.last_g4_plan["stem_tail_rows"] = bool(rows)
             out1 = torch.empty((B, cout1) + vol, device=dev, dtype=adt) if keep1 else None
             ops.costvol_stem_conv3d(features[0], features[1], self.maxdisp, stem0.costvol_variants(), 12, scale0, shift0, stem0.relu, flat(specs),
                                     wk1, cout1, scale1, shift1, stem1.relu, out1, [4 * g for g in range(ops.packed_groups(cout1))],
-                                    tails=flat(specs1), store_main=keep1)
+                                    tails=flat(specs1), store_main=keep1, tail0_rows=bool(rows))
             T[-2] = None
             settle(-2, specs, True, None)
         else:

@@ -123,6 +123,20 @@ def _i32_array(vals: Optional[Sequence[int]]):
 
 # bits of the `relu` argument / of ragmi_tail_t.relu (include/rag_amd.h): channel-group-interleaved ("G4") tensors
 CONV_X_G4, CONV_Y_G4, TAIL_G4 = 2, 4, 4
+TAIL_ROWS = 16                    # ragmi_costvol_stem_conv3d_fwd: the tail rides in rows 12..15 of stem3d1's matrix product (include/rag_amd.h)
+_STEM_TAIL_ROWS = [os.environ.get("RAGMI_STEM_TAIL_ROWS", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling)
+
+
+def set_stem_tail_rows(enabled: bool) -> None:
+    """Whether the fused stems compute cell 0's pre_preprocess in the four idle rows of stem3d1's 12-channel matrix product (a
+    split-operand product, the RAGMI_F32X3 bound) instead of the exact fp32 chain in the staging thread."""
+    _STEM_TAIL_ROWS[0] = bool(enabled)
+
+
+def stem_tail_rows_enabled() -> bool:
+    return _STEM_TAIL_ROWS[0]
+
+
 TAIL_F32, OUT_F32 = 8, 0x100      # mixed storage (include/rag_amd.h): a bf16 launch's down-sampling tail / resample launch writing fp32
 _BF16_DEEP_F32 = [os.environ.get("RAGMI_BF16_DEEP_F32", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling)
 
@@ -297,9 +311,11 @@ def costvol_stem_conv3d(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp
                         scale0: Optional[torch.Tensor], shift0: Optional[torch.Tensor], relu0: bool, tails0: Optional[Sequence[Tail]],
                         packed: torch.Tensor, cout: int, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool,
                         out: Optional[torch.Tensor], out_group_ch: Optional[Sequence[int]] = None,
-                        tails: Optional[Sequence[Tail]] = None, store_main: bool = True) -> Optional[torch.Tensor]:
+                        tails: Optional[Sequence[Tail]] = None, store_main: bool = True, tail0_rows: bool = False) -> Optional[torch.Tensor]:
     """stem3d0 (folded with the cost volume) and stem3d1 in one call, stem3d0's output never written: ragmi_costvol_stem_conv3d_fwd.
-    `tails0` ride on stem3d0's output, `tails` on stem3d1's; `out` may be None when store_main is False."""
+    `tails0` ride on stem3d0's output, `tails` on stem3d1's; `out` may be None when store_main is False.  tail0_rows: `packed` is the
+    pack of stem3d1's weight EXTENDED to 16 output channels whose rows 12..15 hold tails0[0]'s weights at the centre tap
+    (stem_tail_rows_weight): that tail falls out of the matrix product (RAGMI_TAIL_ROWS)."""
     _need_gpu(variants, scale0, shift0, packed, scale, shift)
     dt = _act(left_fea, right_fea, out, *[t.out for t in (tails0 or [])], *[t.out for t in (tails or [])])
     if left_fea.shape != right_fea.shape or left_fea.dim() != 4:
@@ -313,12 +329,26 @@ def costvol_stem_conv3d(left_fea: torch.Tensor, right_fea: torch.Tensor, maxdisp
     ws = torch.empty((lib.ragmi_costvol_stem_workspace_elems(B, C, cmid, d, h, w),), device=left_fea.device, dtype=torch.float32)
     n0, t0 = _tail_array(tails0)
     n1, t1 = _tail_array(tails)
+    if tail0_rows:
+        if n0 != 1 or cout != 12:
+            raise ValueError("costvol_stem_conv3d: tail0_rows takes exactly one tail behind a 12-channel stem3d1")
+        t0[0].relu |= TAIL_ROWS
     p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     check(lib.ragmi_costvol_stem_conv3d_fwd(left_fea.data_ptr(), right_fea.data_ptr(), variants.data_ptr(), p(scale0), p(shift0), int(relu0),
                                             ws.data_ptr(), n0, t0, packed.data_ptr(), p(scale), p(shift), int(relu),
                                             p(out), _planes(out) if out is not None else 0, _i32_array(out_group_ch), int(store_main), n1, t1,
                                             B, C, cmid, cout, d, h, w, _conv_dt(dt), _stream()), "costvol_stem_conv3d")
     return out
+
+
+def stem_tail_rows_weight(weight: torch.Tensor, tail_weight2d: torch.Tensor) -> torch.Tensor:
+    """[12, Cin, 3, 3, 3] + a [4, Cin] 1x1x1 tail on the conv's INPUT -> the 16-channel weight whose rows 12..15 are the tail at the
+    centre tap (what RAGMI_TAIL_ROWS expects packed)."""
+    if weight.dim() != 5 or weight.shape[0] != 12 or tuple(tail_weight2d.shape) != (4, weight.shape[1]):
+        raise ValueError("stem_tail_rows_weight: a [12, Cin, 3, 3, 3] weight and a [4, Cin] tail")
+    rows = torch.zeros((4,) + tuple(weight.shape[1:]), device=weight.device, dtype=weight.dtype)
+    rows[:, :, 1, 1, 1] = tail_weight2d
+    return torch.cat([weight, rows], dim=0).contiguous()
 
 
 def conv3d_k3_pack(weight: torch.Tensor, transpose: bool = False, for_current_precision: bool = False) -> torch.Tensor:

@@ -1694,6 +1694,7 @@ def test_matchingnet_g4_plan_and_bitwise(ra, x3_on, hwd):
     lf, rf = torch.randn((2, 12, H // 3, W // 3), generator=gen(541)), torch.randn((2, 12, H // 3, W // 3), generator=gen(542))
     outs = {}
     try:
+        ra.ops.set_stem_tail_rows(False)
         for g4, fuse in ((True, True), (True, False), (False, False), (False, True)):
             ra.ops.set_g4(g4)
             ra.ops.set_stem_fusion(fuse)
@@ -1701,12 +1702,26 @@ def test_matchingnet_g4_plan_and_bitwise(ra, x3_on, hwd):
                 outs[(g4, fuse)] = net(gpu(lf), gpu(rf))
             plan = net.last_g4_plan
             assert plan["stem0_out"] == g4 and [plan["pre"][j] for j in (0, 1, 2)] == [g4] * 3 and plan["stems_fused"] == fuse, plan
-            assert not any(plan["pre"][j] for j in range(3, 8))
+            assert not any(plan["pre"][j] for j in range(3, 8)) and not plan.get("stem_tail_rows", False)
+        # the default: stems fused with cell 0's pre_preprocess in the idle rows of stem3d1's matrix product — split-operand products
+        # instead of an exact fp32 chain for that one 1x1x1 conv: not the same bits, the same disparities to the RAGMI_F32X3 class
+        ra.ops.set_g4(True)
+        ra.ops.set_stem_fusion(True)
+        ra.ops.set_stem_tail_rows(True)
+        with torch.no_grad():
+            d_rows = net(gpu(lf), gpu(rf))
+            d_again = net(gpu(lf), gpu(rf))
+        assert net.last_g4_plan["stems_fused"] and net.last_g4_plan["stem_tail_rows"]
     finally:
         ra.ops.set_g4(True)
         ra.ops.set_stem_fusion(True)
+        ra.ops.set_stem_tail_rows(True)
     for k in outs:       # G4 or planes, stems fused or not: the same bits
         assert torch.equal(outs[k], outs[(False, False)]), k
+    assert torch.equal(d_rows, d_again)
+    e = O.epe(d_rows.cpu(), outs[(False, False)].cpu())
+    print(f"stem tail in the matrix product's idle rows vs the exact chain: EPE {e:.3e} px")
+    assert e <= EPE_GATE / 2, e
 
 
 def test_x3_down_tail_clamped_pair_ignores_a_non_finite_even_source(ra, x3_on):
@@ -1775,6 +1790,26 @@ def test_costvol_stem_conv3d_fused_bitwise(ra, x3_on, B, h, w, maxdisp):
     for run in (True, "again", "once more"):
         for a_, b_ in zip(outs[run], outs[False]):
             assert torch.equal(torch.nan_to_num(a_, nan=-7.0), torch.nan_to_num(b_, nan=-7.0))
+    # RAGMI_TAIL_ROWS: stem3d0's tail in rows 12..15 of stem3d1's matrix product (stem3d1's weight packed as 16 channels): stem3d1's
+    # output and its own tails keep their bits; that one tail is a split-operand product now (the RAGMI_F32X3 class), run to run the same
+    with ra.ops.conv_precision("f16x3"):
+        pk16 = ra.ops.conv3d_k3_pack(ra.ops.stem_tail_rows_weight(gpu(w1), gpu(tw0)))
+        rows_runs = []
+        for _ in range(2):
+            pre0 = torch.full((B, 8, d, h, w), float("nan"), device=DEV)
+            pre1 = torch.full((B, 8, d, h, w), float("nan"), device=DEV)
+            t0 = [ra.ops.Tail(gpu(tw0), None, None, True, pre0, 0, g4=True)]
+            t1 = [ra.ops.Tail(gpu(tw1[0]), None, None, True, pre0, 4, g4=True), ra.ops.Tail(gpu(tw1[1]), None, None, False, pre1, 0, g4=True)]
+            y = torch.full((B, cout, d, h, w), float("nan"), device=DEV)
+            ra.ops.costvol_stem_conv3d(gpu(L), gpu(R), maxdisp, var, cmid, gpu(s0), gpu(h0), True, t0, pk16, cout, gpu(s1), gpu(h1), True, y,
+                                       None, tails=t1, store_main=True, tail0_rows=True)
+            rows_runs.append((y, ra.ops.from_g4(pre0), ra.ops.from_g4(pre1)))
+    for a_, b_ in zip(rows_runs[0], rows_runs[1]):
+        assert torch.equal(torch.nan_to_num(a_, nan=-7.0), torch.nan_to_num(b_, nan=-7.0))
+    assert torch.isnan(rows_runs[0][2][:, 4:]).all() and not torch.isnan(rows_runs[0][1]).any()
+    assert torch.equal(rows_runs[0][0], outs[False][0]) and torch.equal(rows_runs[0][2][:, :4], outs[False][2][:, :4])
+    assert torch.equal(rows_runs[0][1][:, 4:], outs[False][1][:, 4:])
+    np.testing.assert_allclose(rows_runs[0][1][:, :4].cpu().numpy(), outs[False][1][:, :4].cpu().numpy(), rtol=2e-6, atol=5e-6)
     assert torch.isnan(outs[True][2][:, 4:]).all() and not torch.isnan(outs[True][1]).any()
     v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
     torch.set_num_threads(16)
