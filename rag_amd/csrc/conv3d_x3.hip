@@ -172,17 +172,6 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const float idv = isshift ? 0.f : 1.f;
       lsrc[tid] = pp ? make_float4(pp[4 * cg], pp[4 * cg + 1], pp[4 * cg + 2], pp[4 * cg + 3]) : make_float4(idv, idv, idv, idv);
     }
-    if (e.src.ntail > 0 && !e.src.tail_rows && tid >= 64 && tid < 64 + 4 * NCG + 2) {      // the fused tail: w[0..3][c] per input channel c, then its scale and shift
-      const int c = tid - 64;
-      const float* const tw = e.src.tail_w;
-      const float* const tsc = e.src.tail_scale;
-      const float* const tsh = e.src.tail_shift;
-      float4 q4;
-      if (c < 4 * NCG) q4 = make_float4(tw[c], tw[4 * NCG + c], tw[8 * NCG + c], tw[12 * NCG + c]);
-      else if (c == 4 * NCG) q4 = tsc ? make_float4(tsc[0], tsc[1], tsc[2], tsc[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
-      else q4 = tsh ? make_float4(tsh[0], tsh[1], tsh[2], tsh[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      lsrc[2 * NCG + c] = q4;
-    }
   }
   // Fused consumer 1x1x1 convs ("tails") on the matrix cores: out_t[k][voxel] = sum_c W_t[k][c] * v[c][voxel] as four 16x16x4 fp32
   // products laid out so that every lane quarter feeds ITS OWN four channels (product r: channel 4 kb + r of each quarter), so no
@@ -234,12 +223,16 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     }
   }
   // staging elements of a thread: (channel group, halo voxel) pairs numbered p * X3_THREADS + tid through the groups — or, with the
-  // plane source (XSRC == 2), ALL groups of the ONE voxel tid (threads past the 340 halo voxels stage nothing): the plane addressing
-  // is per voxel, and the voxel's owner has every channel for the fused tail of stem3d0
-  constexpr int NPE = ABX ? NCG : NPF;
-  auto el_cg = [&](int p) { return ABX ? p : (p * X3_THREADS + tid) / X3_PL; };
-  auto el_r = [&](int p) { return ABX ? min(tid, X3_PL - 1) : (p * X3_THREADS + tid) % X3_PL; };
-  auto el_on = [&](int p) { return ABX ? tid < X3_PL : p * X3_THREADS + tid < NCG * X3_PL; };
+  // plane source (XSRC == 2, three groups), TWO elements per thread that share as much of the plane addressing as possible: thread
+  // t < 340 stages groups 0 and 1 of halo voxel t (one address computation, four 16-byte loads), thread 340 + u (u < 170) group 2 of
+  // the voxels 2u and 2u + 1.  (Until stem3d0's tail moved into the matrix product's idle rows — RAGMI_TAIL_ROWS — a voxel's three
+  // groups had to meet in ONE thread, 340 of 512 threads staging three elements each.)
+  static_assert(!ABX || (NCG == 3 && 2 * (X3_THREADS - X3_PL) >= X3_PL), "plane source: the element mapping below");
+  constexpr int NPE = ABX ? 2 : NPF;
+  const bool abx_pair = tid >= X3_PL;                        // XSRC == 2: this thread stages group 2 of two voxels
+  auto el_cg = [&](int p) { return ABX ? (abx_pair ? 2 : p) : (p * X3_THREADS + tid) / X3_PL; };
+  auto el_r = [&](int p) { return ABX ? (abx_pair ? min(2 * (tid - X3_PL) + p, X3_PL - 1) : tid) : (p * X3_THREADS + tid) % X3_PL; };
+  auto el_on = [&](int p) { return ABX ? (!abx_pair || 2 * (tid - X3_PL) + p < X3_PL) : p * X3_THREADS + tid < NCG * X3_PL; };
   float pf[NPE][4];
   unsigned valid = 0;
   const T* const x = static_cast<const T*>(a.x);
@@ -248,20 +241,21 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   // plane base changes, so the loads are `uniform base + lane offset` with no address arithmetic left in the z loop (per plane it
   // was ~100 VALU instructions per wave next to 48 MFMAs, and VALU issue is additive to MFMA issue on this chip)
   int voff[NPF];
-  int vgy = 0, vgx = 0;                // XSRC == 2: the thread's voxel (clamped row, column) and whether this workgroup OWNS it
-  bool vinterior = false;              // (inside the 8 x 32 tile, not its halo: the fused tail of stem3d0 is stored by the owner)
-  float4 pa[ABX ? NCG : 1], pbv[ABX ? NCG : 1];      // XSRC == 2: the A and B plane values of the plane in flight, per channel group
-  unsigned hflags = 0;                 // XSRC == 2: bit 0: the voxel has an A term in that plane, bit 1: a B term
+  int vgy[ABX ? 2 : 1] = {}, vgx[ABX ? 2 : 1] = {};      // XSRC == 2: the elements' voxels (clamped row, column)
+  float4 pa[ABX ? 2 : 1], pbv[ABX ? 2 : 1];              // XSRC == 2: the A and B plane values of the plane in flight, per element
+  unsigned hflags = 0;                 // XSRC == 2: bits 2p, 2p + 1: element p's voxel has an A term in that plane, a B term
   unsigned vmask = 0;
   auto locate = [&](int y0, int x0) {
     vmask = 0;
     if constexpr (ABX) {
-      const int r = min(tid, X3_PL - 1), xx = r % X3_HX, yy = r / X3_HX;
-      const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
-      const bool ok = tid < X3_PL && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      vmask = ok ? (1u << NPE) - 1u : 0u;
-      vgy = min(max(gy, 0), a.H - 1); vgx = min(max(gx, 0), a.W - 1);
-      vinterior = ok && yy >= 1 && yy <= X3_TY && xx >= 1 && xx <= X3_TX;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int r = el_r(p), xx = r % X3_HX, yy = r / X3_HX;
+        const int gy = y0 - 1 + yy, gx = x0 - 1 + xx;
+        const bool ok = el_on(p) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        vmask |= (ok ? 1u : 0u) << p;
+        vgy[p] = min(max(gy, 0), a.H - 1); vgx[p] = min(max(gx, 0), a.W - 1);
+      }
       return;
     }
 #pragma unroll
@@ -289,18 +283,24 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       auto pick = [&](const int (&o)[4]) { return cls == 0 ? o[0] : cls == 1 ? o[1] : cls == 2 ? o[2] : o[3]; };      // (scalar selects: no argument-segment loads)
       const int ofull = pick(e.src.off_afull), oband = pick(e.src.off_aband), ob0 = pick(e.src.off_b0), ob1 = pick(e.src.off_b1);
       constexpr int CM = 4 * NCG;
-      const int t = vgx - gzc, tc = min(max(t, -3), 2);
-      int oa = ofull;
-      if (tc == 2) oa = ofull + (vgy * a.W + vgx) * CM;
-      else if (tc > -3) oa = oband + (tc + 2) * CM * a.H * e.src.wband + (vgy * e.src.wband + vgx - (tc == 1 ? 1 : 0)) * CM;
-      int ob = ob0;
-      if (t >= -2) ob = vgx == a.W - 1 ? ob1 + (vgy * e.src.wb1 + (t - e.src.u1_0)) * CM : ob0 + (vgy * (a.W + 2) + (t + 2)) * CM;
-      hflags = (tc > -3 ? 1u : 0u) | (t >= -2 ? 2u : 0u);
-      if (tid < X3_PL) {
+      hflags = 0;
+      int oa[2], ob[2];
 #pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) {
-          pa[cg] = *reinterpret_cast<const float4*>(wsb + oa + 4 * cg);
-          pbv[cg] = *reinterpret_cast<const float4*>(wsb + ob + 4 * cg);
+      for (int p = 0; p < 2; ++p) {
+        if (p == 1 && !abx_pair) { oa[1] = oa[0]; ob[1] = ob[0]; hflags |= (hflags & 3u) << 2; continue; }      // (same voxel, the next group)
+        const int t = vgx[p] - gzc, tc = min(max(t, -3), 2);
+        oa[p] = ofull;
+        if (tc == 2) oa[p] = ofull + (vgy[p] * a.W + vgx[p]) * CM;
+        else if (tc > -3) oa[p] = oband + (tc + 2) * CM * a.H * e.src.wband + (vgy[p] * e.src.wband + vgx[p] - (tc == 1 ? 1 : 0)) * CM;
+        ob[p] = ob0;
+        if (t >= -2) ob[p] = vgx[p] == a.W - 1 ? ob1 + (vgy[p] * e.src.wb1 + (t - e.src.u1_0)) * CM : ob0 + (vgy[p] * (a.W + 2) + (t + 2)) * CM;
+        hflags |= ((tc > -3 ? 1u : 0u) | (t >= -2 ? 2u : 0u)) << (2 * p);
+      }
+      if (tid < X3_PL + (X3_PL + 1) / 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          pa[p] = *reinterpret_cast<const float4*>(wsb + oa[p] + 4 * el_cg(p));
+          pbv[p] = *reinterpret_cast<const float4*>(wsb + ob[p] + 4 * el_cg(p));
         }
       }
       return;
@@ -321,52 +321,25 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       }
     }
   };
-  // XSRC == 2: the plane values in flight -> the voxel's channels, exactly as costvol_stem_combine_kernel computes them:
+  // XSRC == 2: the plane values in flight -> the element's four channels, exactly as costvol_stem_combine_kernel computes them:
   // s = (B term or 0) + (A term or 0); s = fma(s, scale, shift); ReLU.  Called where the loads are first needed.
-  // (and the fused tail of stem3d0 — cell 0's pre_preprocess, rag_model.py:125,154 — for the voxels this workgroup owns, in the
-  // planes of its own depth segment: the combine kernel's fmaf chain over the channels in order, BatchNorm, ReLU, one store)
-  int zlo = 0, zhi = 0;                  // XSRC == 2: the item's own planes [zlo, zhi)
-  auto mat = [&](int gz) {
+  // (stem3d0's fused tail — cell 0's pre_preprocess, rag_model.py:125,154 — is NOT formed here: it rides in rows 12..15 of the matrix
+  // product, RAGMI_TAIL_ROWS.  Round 5's first form evaluated it here as a 48-term chain by the voxel's owner; built as v_pk_fma_f32
+  // that chain gave wrong low halves in lanes 48..63 now and then — NOTES.md, round-5 log — and it cost 16 us of the launch.)
+  auto mat = [&](int) {
     if constexpr (ABX) {
-      if (tid >= X3_PL) return;
-      const bool ha = hflags & 1u, hb = (hflags >> 1) & 1u;
-      float v[NCG][4];
 #pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) {
+      for (int p = 0; p < 2; ++p) {
+        const bool ha = (hflags >> (2 * p)) & 1u, hb = (hflags >> (2 * p + 1)) & 1u;
+        const int cg = el_cg(p);
         const float4 sc = lsrc[cg], sh = lsrc[NCG + cg];
-        const float av[4] = {pa[cg].x, pa[cg].y, pa[cg].z, pa[cg].w}, bv[4] = {pbv[cg].x, pbv[cg].y, pbv[cg].z, pbv[cg].w};
+        const float av[4] = {pa[p].x, pa[p].y, pa[p].z, pa[p].w}, bv[4] = {pbv[p].x, pbv[p].y, pbv[p].z, pbv[p].w};
         const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float sv = (hb ? bv[c] : 0.f) + (ha ? av[c] : 0.f);
           sv = fmaf(sv, s4[c], h4[c]);
-          v[cg][c] = e.src.relu ? fmaxf(sv, 0.f) : sv;
-          pf[cg][c] = v[cg][c];
-        }
-      }
-      if (e.src.ntail > 0 && !e.src.tail_rows && vinterior && gz >= zlo && gz < zhi) {
-        float u[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4 * NCG; ++c) {
-          const float4 wk = lsrc[2 * NCG + c];                      // w[0..3][c]
-          // (one scalar v_fma per term, kept apart by opaque statements: paired into v_pk_fma_f32 by the SLP vectoriser this chain
-          // gave WRONG low halves in lanes 48..63 of a wave now and then — run to run different voxels, ~0.1 % of them — on gfx950 with
-          // ROCm 7.2's hipcc; the same source built with -fno-slp-vectorize is exact.  tools/_dbg history: NOTES.md round 5)
-          u[0] = fmaf(wk.x, v[c >> 2][c & 3], u[0]); asm volatile("" : "+v"(u[0]));
-          u[1] = fmaf(wk.y, v[c >> 2][c & 3], u[1]); asm volatile("" : "+v"(u[1]));
-          u[2] = fmaf(wk.z, v[c >> 2][c & 3], u[2]); asm volatile("" : "+v"(u[2]));
-          u[3] = fmaf(wk.w, v[c >> 2][c & 3], u[3]); asm volatile("" : "+v"(u[3]));
-        }
-        const float4 tsc = lsrc[2 * NCG + 4 * NCG], tsh = lsrc[2 * NCG + 4 * NCG + 1];
-        const float ts[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, th[4] = {tsh.x, tsh.y, tsh.z, tsh.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { u[k] = fmaf(u[k], ts[k], th[k]); asm volatile("" : "+v"(u[k])); u[k] = e.src.tail_relu ? fmaxf(u[k], 0.f) : u[k]; }
-        const int64_t vox = (int64_t)gz * HW + vgy * a.W + vgx;
-        if (e.src.tail_g4) {
-          *reinterpret_cast<float4*>(tdst + ((int64_t)(e.src.tail_ch0 >> 2) * DHW + vox) * 4) = make_float4(u[0], u[1], u[2], u[3]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) tdst[(int64_t)(e.src.tail_ch0 + k) * DHW + vox] = u[k];
+          pf[p][c] = e.src.relu ? fmaxf(sv, 0.f) : sv;
         }
       }
     }
@@ -518,7 +491,6 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     if constexpr (ABX) {
       wsb = e.src.ws + b * e.src.ws_bstride;
       tdst = e.src.tail_y + b * e.src.tail_bstride;
-      zlo = zs; zhi = ze;
     }
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
     locate(y0, x0);
@@ -1168,7 +1140,7 @@ int x3_g4_caps(const K3Args& a, int nset, int dtype) {
 template <class T, int NCG, int NSET, int TAILS, int XSRC = 0>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
   if constexpr (XSRC == 0 && std::is_same<T, float>::value && NCG == 3 && NSET == 1 && TAILS < 2) {
-    if (e.src.ws != nullptr) return x3_launch_tails<T, NCG, NSET, TAILS, 2>(a, e, grid, lds + (2 * NCG + 4 * NCG + 2) * sizeof(float4), st);      // stem3d1 expanding stem3d0's planes
+    if (e.src.ws != nullptr) return x3_launch_tails<T, NCG, NSET, TAILS, 2>(a, e, grid, lds + 2 * NCG * sizeof(float4), st);      // stem3d1 expanding stem3d0's planes (+ stem3d0's BatchNorm per group)
     if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, 1>(a, e, grid, lds, st);      // stem3d1 on a G4 input
   }
   if (e.src.ws != nullptr && XSRC != 2) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: the plane source is built for 12 -> Cout fp32 launches without down-sampling tails");

@@ -584,20 +584,21 @@ extern "C" int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right
   if (rc != RAGMI_OK) return rc;
   RAGMI_REQUIRE(a.ndown == 0 && x3_eligible(a, 1, dtype) && !x3d_eligible(a, 1, dtype) && !x2d_eligible(a, 1, dtype), RAGMI_EUNSUPPORTED,
                 "costvol_stem_conv3d: this shape does not run on the z-marching split-operand kernel (ragmi_costvol_stem_conv3d_supported)");
-  // ONE fused tail of stem3d0 (4 output channels, full resolution: cell 0's pre_preprocess) is computed by stem3d1's staging thread
-  // that owns the voxel — no combine launch at all; anything else goes through the combine kernel (tails only, no main store)
+  // ONE fused tail of stem3d0 (4 output channels, full resolution: cell 0's pre_preprocess) can ride in rows 12..15 of stem3d1's matrix
+  // product (RAGMI_TAIL_ROWS: the caller packed it there) — no combine launch at all; any other tail goes through the combine kernel
+  // (tails only, no main store)
   RAGMI_REQUIRE(ntail0 >= 0 && ntail0 <= 2 && (ntail0 == 0 || tails0), RAGMI_EINVAL, "costvol_stem_conv3d: at most two tails on stem3d0's output");
-  const bool tail_in_staging = ntail0 == 1 && tails0[0].cout == 4 && !(tails0[0].relu & 2) && tails0[0].weight && tails0[0].y &&
-                               ((tails0[0].scale == nullptr) == (tails0[0].shift == nullptr)) && (!(tails0[0].relu & RAGMI_TAIL_G4) || tails0[0].y_ch0 % 4 == 0);
+  const bool want_rows = ntail0 >= 1 && (tails0[0].relu & RAGMI_TAIL_ROWS);
+  const bool tail_rows = want_rows && ntail0 == 1 && Cout == 12 && tails0[0].cout == 4 && !(tails0[0].relu & 2) && tails0[0].y &&
+                         ((tails0[0].scale == nullptr) == (tails0[0].shift == nullptr)) && (!(tails0[0].relu & RAGMI_TAIL_G4) || tails0[0].y_ch0 % 4 == 0);
+  RAGMI_REQUIRE(!want_rows || tail_rows, RAGMI_EINVAL, "costvol_stem_conv3d: RAGMI_TAIL_ROWS takes ONE 4-channel full-resolution tail behind a 12-channel stem3d1 (packed as 16 channels)");
   StemLayout l;
-  rc = stem_run(left, right, variants, scale0, shift0, relu0, nullptr, 0, workspace, B, C, Cmid, D, H, W, tail_in_staging ? 0 : ntail0, tails0, dtype,
+  rc = stem_run(left, right, variants, scale0, shift0, relu0, nullptr, 0, workspace, B, C, Cmid, D, H, W, tail_rows ? 0 : ntail0, tails0, dtype,
                 stream, &l);
   if (rc != RAGMI_OK) return rc;
   X3StemSrc src{};
-  if (ntail0 >= 1 && (tails0[0].relu & RAGMI_TAIL_ROWS))
-    RAGMI_REQUIRE(tail_in_staging && Cout == 12, RAGMI_EINVAL, "costvol_stem_conv3d: RAGMI_TAIL_ROWS takes ONE 4-channel tail behind a 12-channel stem3d1 (packed as 16 channels)");
-  src.tail_rows = (tail_in_staging && (tails0[0].relu & RAGMI_TAIL_ROWS)) ? 1 : 0;
-  if (tail_in_staging) {
+  src.tail_rows = tail_rows ? 1 : 0;
+  if (tail_rows) {
     src.ntail = 1; src.tail_relu = tails0[0].relu & 1; src.tail_ch0 = tails0[0].y_ch0; src.tail_g4 = (tails0[0].relu & RAGMI_TAIL_G4) ? 1 : 0;
     src.tail_w = (const float*)tails0[0].weight; src.tail_scale = (const float*)tails0[0].scale; src.tail_shift = (const float*)tails0[0].shift;
     src.tail_y = (float*)tails0[0].y; src.tail_bstride = tails0[0].y_bstride;
