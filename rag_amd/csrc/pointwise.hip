@@ -38,6 +38,15 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
     const int ci = i / NCO, co = a.co0 + i % NCO;
     k1_w[i] = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
   }
+  // the slab's folded BatchNorm beside the weights: read per output channel in the epilogue they were two dependent global loads and
+  // a vmcnt(0) per channel, one after the other — up to NCO serial memory round trips behind the last multiply-add of kernels that
+  // take 5-20 us (round 5, found in the listing)
+  float* const k1_bn = k1_w + a.Cin * NCO;                 // scale[NCO] | shift[NCO]
+  if (threadIdx.x < NCO) {
+    const int co = min(a.co0 + (int)threadIdx.x, a.Cout - 1);
+    k1_bn[threadIdx.x] = a.scale ? a.scale[co] : 1.f;
+    k1_bn[NCO + threadIdx.x] = a.scale ? a.shift[co] : 0.f;
+  }
   __syncthreads();
   const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= a.dhw) return;
@@ -73,8 +82,7 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
   for (int j = 0; j < NCO; ++j) {
     const int co = a.co0 + j;
     if (co >= a.Cout) break;
-    const float sc = a.scale ? a.scale[co] : 1.f;
-    const float sh = a.scale ? a.shift[co] : 0.f;
+    const float sc = k1_bn[j], sh = k1_bn[NCO + j];
     float o[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -122,6 +130,13 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
   for (int i = threadIdx.x; i < a.Cin * NCO; i += 256) {
     const int ci = i / NCO, co = co0 + i % NCO;
     k1r_w[i] = co < a.Cout ? a.w[co * a.w_sco + ci * a.w_sci] : 0.f;
+  }
+  // (the slab's folded BatchNorm beside the weights, as conv_k1_kernel: no per-channel global loads in the epilogue)
+  float* const k1r_bn = k1r_w + a.Cin * NCO;               // scale[NCO] | shift[NCO]
+  if (threadIdx.x < NCO) {
+    const int co = min(co0 + (int)threadIdx.x, a.Cout - 1);
+    k1r_bn[threadIdx.x] = a.scale ? a.scale[co] : 1.f;
+    k1r_bn[NCO + threadIdx.x] = a.scale ? a.shift[co] : 0.f;
   }
   __syncthreads();
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_k1_resample_kernel(K1RPair pr) {
   for (int j = 0; j < NCO; ++j) {
     const int co = co0 + j;
     if (co >= a.Cout) break;
-    float v = a.scale ? fmaf(acc[j], a.scale[co], a.shift[co]) : acc[j];
+    float v = a.scale ? fmaf(acc[j], k1r_bn[j], k1r_bn[NCO + j]) : acc[j];
     v = a.relu ? fmaxf(v, 0.f) : v;
     const int64_t off = yo + (int64_t)(a.y_ch0 + co) * ovol;
     if (yf32) static_cast<float*>(a.y)[off] = v; else st(static_cast<T*>(a.y) + off, v);
@@ -230,7 +245,7 @@ static void launch_k1r_nco(const K1RArgs* r, int n, int B, hipStream_t s) {
     cin_max = std::max(cin_max, pr.c[i].k.Cin);
   }
   dim3 grid((unsigned)ceil_div(ovol, 256), B, (unsigned)nz);
-  const size_t wlds = (size_t)cin_max * NCO * sizeof(float);
+  const size_t wlds = (size_t)(cin_max + 2) * NCO * sizeof(float);
   hipLaunchKernelGGL((conv_k1_resample_kernel<T, NCO>), grid, dim3(256), wlds, s, pr);
 }
 
@@ -305,7 +320,7 @@ template <class T, int NCO, bool VEC>
 static void launch_k1_nco(const K1Args& a, int B, hipStream_t s) {
   constexpr int V = VEC ? 4 : 1;
   dim3 grid((unsigned)ceil_div(ceil_div(a.dhw, V), 256), B, (unsigned)ceil_div(a.Cout, NCO));
-  hipLaunchKernelGGL((conv_k1_kernel<T, NCO, VEC>), grid, dim3(256), (size_t)a.Cin * NCO * sizeof(float), s, a);
+  hipLaunchKernelGGL((conv_k1_kernel<T, NCO, VEC>), grid, dim3(256), (size_t)(a.Cin + 2) * NCO * sizeof(float), s, a);
 }
 
 // Pick the widest output slab per thread that still leaves enough threads to fill the chip:
