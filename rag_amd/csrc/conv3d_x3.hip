@@ -52,7 +52,7 @@ template <class T, int NCG, int NSET, int TAILS, int XSRC = 0>
 __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr bool G4X = XSRC == 1, ABX = XSRC == 2;
-  static_assert(XSRC == 0 || !BF, "G4 tensors and the plane source are fp32");
+  static_assert(XSRC != 1 || !BF, "G4 tensors are fp32");      // (the plane source also feeds bf16 storage: the values are rounded as a store would)
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
   // LDS row / plane / channel-group strides in records (padded against bank conflicts: conv3d_x3_common.h; staging still enumerates X3_PL voxels)
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       if (e.src.tail_rows && tid >= 12 && tid < 16) {
         const float* const tsc = e.src.tail_scale;
         const float* const tsh = e.src.tail_shift;
-        sc = (tsc ? tsc[tid - 12] : 1.f) * e.wmul[0][tid];
+        sc = tsc ? tsc[tid - 12] : 1.f;
+        if constexpr (!BF) sc *= e.wmul[0][tid];
         sh = tsh ? tsh[tid - 12] : 0.f;
       }
     }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
   };
   // issue the loads of input plane gz of the located column: unconditional, the plane index clamped into the volume
   const float* wsb = nullptr;          // XSRC == 2: this sample's planes
-  float* tdst = nullptr;               // ... and the sample of the fused tail's destination
+  T* tdst = nullptr;                   // ... and the sample of the fused tail's destination
   auto prefetch = [&](const T* xb, int gz) {
     if (dg_noload) return;
     valid = (unsigned)gz < (unsigned)a.D ? vmask : 0u;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     }
     if constexpr (ABX) {
       wsb = e.src.ws + b * e.src.ws_bstride;
-      tdst = e.src.tail_y + b * e.src.tail_bstride;
+      tdst = reinterpret_cast<T*>(e.src.tail_y) + b * e.src.tail_bstride;
     }
     __syncthreads();                                   // the previous column's LDS reads are done (and the tables above are written)
     locate(y0, x0);
@@ -532,8 +533,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         prefetch(xb, zfirst - 1); mat(zfirst - 1); note_overflow(); commit((zfirst - 1 + 3) % 3);
         prefetch(xb, zfirst + 1);
       } else {
-        prefetch(xb, zs - 1); commit((zs - 1 + 3) % 3);
-        prefetch(xb, zs); commit(zs % 3);
+        prefetch(xb, zs - 1); mat(zs - 1); commit((zs - 1 + 3) % 3);
+        prefetch(xb, zs); mat(zs); commit(zs % 3);
         prefetch(xb, zs + 1);
       }
       bool again = false;
@@ -623,11 +624,12 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         if constexpr (ABX) {
           // rows 12..15 (lane quarter 3): stem3d0's fused tail, already through its BatchNorm and activation above
           if (e.src.tail_rows && g == 3 && inside && !(dg_nostore && v[0] != 12345.f)) {
-            if (e.src.tail_g4) {
-              *reinterpret_cast<float4*>(tdst + ((int64_t)(e.src.tail_ch0 >> 2) * DHW + vox) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            if (!BF && e.src.tail_g4) {
+              if constexpr (!BF)
+                *reinterpret_cast<float4*>(tdst + ((int64_t)(e.src.tail_ch0 >> 2) * DHW + vox) * 4) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) tdst[(int64_t)(e.src.tail_ch0 + r) * DHW + vox] = v[r];
+              for (int r = 0; r < 4; ++r) st(tdst + (int64_t)(e.src.tail_ch0 + r) * DHW + vox, v[r]);
             }
           }
         }
@@ -1139,9 +1141,11 @@ int x3_g4_caps(const K3Args& a, int nset, int dtype) {
 
 template <class T, int NCG, int NSET, int TAILS, int XSRC = 0>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
-  if constexpr (XSRC == 0 && std::is_same<T, float>::value && NCG == 3 && NSET == 1 && TAILS < 2) {
+  if constexpr (XSRC == 0 && NCG == 3 && NSET == 1 && TAILS < 2) {
     if (e.src.ws != nullptr) return x3_launch_tails<T, NCG, NSET, TAILS, 2>(a, e, grid, lds + 2 * NCG * sizeof(float4), st);      // stem3d1 expanding stem3d0's planes (+ stem3d0's BatchNorm per group)
-    if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, 1>(a, e, grid, lds, st);      // stem3d1 on a G4 input
+    if constexpr (std::is_same<T, float>::value) {
+      if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, 1>(a, e, grid, lds, st);      // stem3d1 on a G4 input
+    }
   }
   if (e.src.ws != nullptr && XSRC != 2) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: the plane source is built for 12 -> Cout fp32 launches without down-sampling tails");
   static LaunchState state;     // per device, mutex-guarded (common.h)

@@ -570,7 +570,7 @@ extern "C" int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right
                                              const ragmi_tail_t* tails, int B, int C, int Cmid, int Cout, int D, int H, int W, int dtype,
                                              void* stream) {
   using namespace ragmi;
-  RAGMI_REQUIRE(dtype == RAGMI_F32X3, RAGMI_EUNSUPPORTED, "costvol_stem_conv3d: RAGMI_F32X3 only (fp32 storage, split-operand convolution)");
+  RAGMI_REQUIRE(dtype == RAGMI_F32X3 || dtype == RAGMI_BF16, RAGMI_EUNSUPPORTED, "costvol_stem_conv3d: RAGMI_F32X3 or RAGMI_BF16 (the split-operand convolution)");
   RAGMI_REQUIRE(packed_weight && (y || !store_main), RAGMI_EINVAL, "costvol_stem_conv3d: null pointer");
   RAGMI_REQUIRE(Cmid == 12 && C % 4 == 0 && C <= 12, RAGMI_EUNSUPPORTED, "costvol_stem_conv3d: built for 12 intermediate channels (stem3d0 -> stem3d1)");
   RAGMI_REQUIRE((scale == nullptr) == (shift == nullptr), RAGMI_EINVAL, "costvol_stem_conv3d: scale/shift must both be given or both NULL");
@@ -591,6 +591,7 @@ extern "C" int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right
   const bool want_rows = ntail0 >= 1 && (tails0[0].relu & RAGMI_TAIL_ROWS);
   const bool tail_rows = want_rows && ntail0 == 1 && Cout == 12 && tails0[0].cout == 4 && !(tails0[0].relu & 2) && tails0[0].y &&
                          ((tails0[0].scale == nullptr) == (tails0[0].shift == nullptr)) && (!(tails0[0].relu & RAGMI_TAIL_G4) || tails0[0].y_ch0 % 4 == 0);
+  RAGMI_REQUIRE(dtype != RAGMI_BF16 || ((!tail_rows || !(tails0[0].relu & RAGMI_TAIL_G4)) && !a.tail_g4), RAGMI_EUNSUPPORTED, "costvol_stem_conv3d: G4 tails are fp32");
   RAGMI_REQUIRE(!want_rows || tail_rows, RAGMI_EINVAL, "costvol_stem_conv3d: RAGMI_TAIL_ROWS takes ONE 4-channel full-resolution tail behind a 12-channel stem3d1 (packed as 16 channels)");
   StemLayout l;
   rc = stem_run(left, right, variants, scale0, shift0, relu0, nullptr, 0, workspace, B, C, Cmid, D, H, W, tail_rows ? 0 : ntail0, tails0, dtype,
@@ -615,7 +616,7 @@ extern "C" int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right
 
 extern "C" int ragmi_costvol_stem_conv3d_supported(int C, int Cmid, int Cout, int B, int D, int H, int W, int ntail, int dtype) {
   using namespace ragmi;
-  if (dtype != RAGMI_F32X3 || Cmid != 12 || C % 4 != 0 || C <= 0 || C > 12 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || Cmid != 12 || C % 4 != 0 || C <= 0 || C > 12 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
   K3Args a{};
   a.B = B; a.Cin = Cmid; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.ntail = ntail; a.nchunks[0] = Cmid / CK; a.store_main = 1;
   return (x3_eligible(a, 1, dtype) && !x3d_eligible(a, 1, dtype) && !x2d_eligible(a, 1, dtype)) ? 1 : 0;

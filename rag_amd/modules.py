@@ -918,7 +918,8 @@ class MatchingNet(nn.Module):
         keep1 = need_main or not specs1
         # Round 5: stem3d0 and stem3d1 as ONE call whose second kernel expands stem3d0's output from the variant planes in its own
         # staging (ops.costvol_stem_conv3d): when nothing but stem3d1 and fused tails reads T[-2], that 164 MB tensor is never written.
-        fuse_stems = (x is None and ops.stem_fusion_enabled() and adt == torch.float32 and ops.get_conv_precision() == "f16x3" and n >= 1
+        fuse_stems = (x is None and ops.stem_fusion_enabled() and n >= 1
+                      and ((adt == torch.float32 and ops.get_conv_precision() == "f16x3") or adt == torch.bfloat16)
                       and (0, 0, False) in fusable(-2) and stem0.conv.out_channels == 12 and stem1._geometry() == 3 and not stem1._small()
                       and ops.costvol_stem_conv3d_supported(features[0].shape[1], 12, stem1.conv.out_channels, B, *vol,
                                                             ntail=len(flat(specs1) or []), dtype=adt))

@@ -1242,6 +1242,51 @@ def test_x3_down_sampling_tails_bf16_storage(ra):
     np.testing.assert_allclose(got[:, 1:9].numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
 
 
+def test_costvol_stem_conv3d_fused_bf16_storage(ra):
+    """The fused stems under bf16 activation storage (BASELINE configs[2]): stem3d1's staging rounds the expanded values to bf16 exactly
+    as the store of the two-launch path does, so stem3d1's output and its own tails have the two-launch path's bits; stem3d0's tail in
+    the product's idle rows (RAGMI_TAIL_ROWS) is formed from the ROUNDED activations (the two-launch path forms it before the store),
+    so it agrees to the storage format's rounding."""
+    B, h, w, maxdisp = 2, 72, 132, 96
+    C, cmid, cout = 12, 12, 12
+    g1 = gen(571)
+    L, R = torch.randn((B, C, h, w), generator=g1).to(BF), torch.randn((B, C, h, w), generator=g1).to(BF)
+    w0 = torch.randn((cmid, 2 * C, 3, 3, 3), generator=g1) * 0.05
+    w1 = torch.randn((cout, cmid, 3, 3, 3), generator=g1) * 0.1
+    s0, h0 = torch.rand(cmid, generator=g1) + 0.5, torch.randn(cmid, generator=g1) * 0.1
+    s1, h1 = torch.rand(cout, generator=g1) + 0.5, torch.randn(cout, generator=g1) * 0.1
+    tw0 = torch.randn((4, cmid), generator=g1) * 0.3
+    tw1 = [torch.randn((4, cout), generator=g1) * 0.3 for _ in range(2)]
+    d = maxdisp // 3
+    assert ra.ops.costvol_stem_conv3d_supported(C, cmid, cout, B, d, h, w, ntail=2, dtype=BF)
+    var = ra.ops.costvol_stem_prepare(gpu(w0))
+    pk = ra.ops.conv3d_k3_pack(gpu(w1))
+    pk16 = ra.ops.conv3d_k3_pack(ra.ops.stem_tail_rows_weight(gpu(w1), gpu(tw0)))
+    outs = {}
+    for mode in ("two launches", "fused", "fused, tail in the rows", "again"):
+        pre0 = torch.full((B, 8, d, h, w), float("nan"), device=DEV, dtype=BF)
+        pre1 = torch.full((B, 8, d, h, w), float("nan"), device=DEV, dtype=BF)
+        t0 = [ra.ops.Tail(gpu(tw0), None, None, True, pre0, 0)]
+        t1 = [ra.ops.Tail(gpu(tw1[0]), None, None, True, pre0, 4), ra.ops.Tail(gpu(tw1[1]), None, None, False, pre1, 0)]
+        y = torch.full((B, cout, d, h, w), float("nan"), device=DEV, dtype=BF)
+        if mode == "two launches":
+            mid = ra.ops.costvol_stem(gpu(L), gpu(R), maxdisp, var, cmid, gpu(s0), gpu(h0), True, tails=t0)
+            ra.ops.conv3d_k3(mid, pk, cout, gpu(s1), gpu(h1), True, y, None, tails=t1)
+        else:
+            rows = mode != "fused"
+            ra.ops.costvol_stem_conv3d(gpu(L), gpu(R), maxdisp, var, cmid, gpu(s0), gpu(h0), True, t0, pk16 if rows else pk, cout, gpu(s1), gpu(h1),
+                                       True, y, None, tails=t1, store_main=True, tail0_rows=rows)
+        outs[mode] = (y, pre0, pre1)
+    eq = lambda a_, b_: torch.equal(torch.nan_to_num(a_.float(), nan=-7.0), torch.nan_to_num(b_.float(), nan=-7.0))  # noqa: E731
+    ref = outs["two launches"]
+    assert all(eq(a_, b_) for a_, b_ in zip(outs["fused"], ref))
+    assert all(eq(a_, b_) for a_, b_ in zip(outs["fused, tail in the rows"], outs["again"]))
+    rows = outs["fused, tail in the rows"]
+    assert eq(rows[0], ref[0]) and eq(rows[2], ref[2]) and eq(rows[1][:, 4:], ref[1][:, 4:])
+    np.testing.assert_allclose(rows[1][:, :4].float().cpu().numpy(), ref[1][:, :4].float().cpu().numpy(), rtol=2e-2, atol=3e-2)
+    assert torch.isnan(rows[2][:, 4:]).all() and not torch.isnan(rows[1]).any()
+
+
 def test_mixed_storage_edges_round_to_the_bf16_results(ra):
     """The two launches that cross from bf16 storage into the fp32 levels (round 5, include/rag_amd.h "Mixed storage"): a
     down-sampling tail with an fp32 destination (RAGMI_TAIL_F32) and the resample + 1x1x1 launch with an fp32 output
