@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void costvol_stem_pack_kernel(const float* __r
 // owns rows 2w, 2w+1 (8 column tiles of 16), its weight fragments (NS slices, hi + lo) sit in registers.
 constexpr int CSM_TX = 64, CSM_TY = 8, CSM_HX = CSM_TX + 4, CSM_HY = CSM_TY + 2, CSM_THREADS = 256;
 constexpr int CSM_RS = CSM_HX + 1;                         // record stride of a halo row (8-byte records)
-template <int NCG, int NTAP>
+template <class TF, int NCG, int NTAP>
 __device__ __forceinline__ void costvol_stem_planes_mfma_body(const PlanesArgs& a, const PlaneDesc& d, const uint4* __restrict__ frag_a,
                                                               const uint4* __restrict__ frag_b, const float* __restrict__ wmul_all,
                                                               uint2* lhi, uint2* llo, unsigned& lmax) {
@@ -239,7 +239,7 @@ __device__ __forceinline__ void costvol_stem_planes_mfma_body(const PlanesArgs& 
   const int b = blockIdx.z / a.ndesc;
   const int xb = blockIdx.x * CSM_TX, yb = blockIdx.y * CSM_TY;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kb = lane >> 4;
-  const float* const src = static_cast<const float*>(d.right ? a.right : a.left) + (int64_t)b * a.C * a.H * a.W;
+  const TF* const src = static_cast<const TF*>(d.right ? a.right : a.left) + (int64_t)b * a.C * a.H * a.W;      // TF: the features' storage type
   if (tid == 0) lmax = 0u;
   // halo records of this thread: 4 channels of one (row, column)
   float pf[NPF][4];
@@ -251,9 +251,9 @@ __device__ __forceinline__ void costvol_stem_planes_mfma_body(const PlanesArgs& 
     const int ty = r / CSM_HX, tx = r % CSM_HX, gy = yb + ty - 1, gx = d.x0 + xb + tx - KH;
     const bool ok = el < NREC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     valid |= (ok ? 1u : 0u) << p;
-    const float* const pc = src + (int64_t)min(cg, NCG - 1) * 4 * HW + (int64_t)min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
+    const TF* const pc = src + (int64_t)min(cg, NCG - 1) * 4 * HW + (int64_t)min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) pf[p][c] = pc[c * HW];              // unconditional (clamped) loads; zeros substituted at the commit
+    for (int c = 0; c < 4; ++c) pf[p][c] = ld(pc + c * HW);         // unconditional (clamped) loads; zeros substituted at the commit
   }
   // weight fragments of this variant -> registers (the same for every tile of the plane set)
   const int v = d.variant;
@@ -322,15 +322,15 @@ __device__ __forceinline__ void costvol_stem_planes_mfma_body(const PlanesArgs& 
 
 // both tap counts in ONE launch (the 3-tap left and the 5-tap right plane sets took 15 + 16 us as two launches, each latency-bound):
 // the descriptor picks the instantiation (wave-uniform)
-template <int NCG>
+template <int NCG, class TF = float>
 __global__ __launch_bounds__(CSM_THREADS, 2) void costvol_stem_planes_mfma_kernel(PlanesArgs a, const uint4* __restrict__ frag_a,
                                                                                  const uint4* __restrict__ frag_b, const float* __restrict__ wmul_all) {
   __shared__ __attribute__((aligned(16))) uint2 lhi[NCG * CSM_HY * CSM_RS], llo[NCG * CSM_HY * CSM_RS];
   __shared__ unsigned lmax;
   const PlaneDesc d = a.d[blockIdx.z % a.ndesc];
   if ((int)blockIdx.x * CSM_TX >= d.width) return;               // uniform: descriptors have different widths
-  if (d.right) costvol_stem_planes_mfma_body<NCG, 5>(a, d, frag_a, frag_b, wmul_all, lhi, llo, lmax);
-  else costvol_stem_planes_mfma_body<NCG, 3>(a, d, frag_a, frag_b, wmul_all, lhi, llo, lmax);
+  if (d.right) costvol_stem_planes_mfma_body<TF, NCG, 5>(a, d, frag_a, frag_b, wmul_all, lhi, llo, lmax);
+  else costvol_stem_planes_mfma_body<TF, NCG, 3>(a, d, frag_a, frag_b, wmul_all, lhi, llo, lmax);
 }
 
 struct CombineArgs {
@@ -635,7 +635,10 @@ static int stem_run(const void* left, const void* right, const void* variants, c
   RAGMI_REQUIRE(ntail >= 0 && ntail <= 2 && (ntail == 0 || tails), RAGMI_EINVAL, "costvol_stem: at most two tails");
   // RAGMI_F32X3: fp32 storage, the variant planes as split-operand products on the matrix cores where the shape allows
   // (whole 4-channel groups, <= 12 feature channels); everything else of this entry point is fp32 either way
-  const bool mfma_planes = dtype == RAGMI_F32X3 && C % 4 == 0 && C <= 12;
+  // (round 5: bf16 features too — the planes are fp32 in the workspace either way, and under bf16 storage everything downstream of them
+  // is rounded to 8 bits)
+  const bool mfma_planes = (dtype == RAGMI_F32X3 || dtype == RAGMI_BF16) && C % 4 == 0 && C <= 12;
+  const bool bf_features = dtype == RAGMI_BF16;
   if (dtype == RAGMI_F32X3) dtype = RAGMI_F32;
   StemLayout l;
   stem_layout(C, Cout, D, H, W, l);
@@ -674,7 +677,9 @@ static int stem_run(const void* left, const void* right, const void* variants, c
     const uint4* const fb = fa + (int64_t)CS_NVA * nsa * 2 * 64;
     const float* const wm = reinterpret_cast<const float*>(fb + (int64_t)CS_NVB * nsb * 2 * 64);
     const dim3 mgrid((unsigned)ceil_div(maxw, CSM_TX), (unsigned)ceil_div(H, CSM_TY), (unsigned)(n * B));
-#define RAGMI_CS_MFMA(NCG_) hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm);
+#define RAGMI_CS_MFMA(NCG_)                                                                                                          \
+  if (bf_features) hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_, bf16_t>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm); \
+  else hipLaunchKernelGGL((costvol_stem_planes_mfma_kernel<NCG_, float>), mgrid, dim3(CSM_THREADS), 0, st, pa, fa, fb, wm);
     switch (C / 4) {
       case 1: RAGMI_CS_MFMA(1) break;
       case 2: RAGMI_CS_MFMA(2) break;
