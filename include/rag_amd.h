@@ -150,7 +150,7 @@ int ragmi_down2_tail_supported(int D, int H, int W);
  * the level-3 tensors its own kernels exchange (the 8-channel s0|s1 inputs of the dual cells, stem3d0's output): every module
  * boundary of the reference (rag_model.py:143-177, 325-366) keeps channel planes.  Why: on gfx950 the vector memory path costs per
  * INSTRUCTION; in G4 a halo voxel of a group is one 16-byte load and a fused tail one 16-byte store instead of four 4-byte ones into
- * four planes (profiles/r05_x3_stamps.md).  Flags (fp32 storage only; RAGMI_EUNSUPPORTED where the kernel a call lands on does not
+ * four planes (profiles/r05_x3_stamps.md).  Flags (fp32 storage, or bf16 storage: four bf16 = one 8-byte access; RAGMI_EUNSUPPORTED where the kernel a call lands on does not
  * take them — ask ragmi_conv3d_k3_g4_caps first):
  *   `relu` argument of ragmi_conv3d_k3_fwd_ex / _dual_fwd_ex:  bit 1 (RAGMI_CONV_X_G4): x is G4 (x_bstride in floats, as ever);
  *   ragmi_tail_t.relu bit 2 (RAGMI_TAIL_G4): the tail's destination y is G4; y_ch0 (a multiple of 4) names the group y_ch0 / 4; the

@@ -52,7 +52,8 @@ template <class T, int NCG, int NSET, int TAILS, int XSRC = 0>
 __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kernel(K3Args a, X3Extra e) {
   constexpr bool BF = std::is_same<T, bf16_t>::value;
   constexpr bool G4X = XSRC == 1, ABX = XSRC == 2;
-  static_assert(XSRC != 1 || !BF, "G4 tensors are fp32");      // (the plane source also feeds bf16 storage: the values are rounded as a store would)
+  // (G4 under bf16 storage: four bf16 of a voxel and group = one 8-byte access; the plane source also feeds bf16 storage — its values are
+  // rounded as a store would)
   constexpr int NCGS = NCG / NSET, NSLS = (NCGS * 27 + 7) / 8, NSL = NSET * NSLS;
   constexpr int NPF = (NCG * X3_PL + X3_THREADS - 1) / X3_THREADS;
   // LDS row / plane / channel-group strides in records (padded against bank conflicts: conv3d_x3_common.h; staging still enumerates X3_PL voxels)
@@ -310,8 +311,14 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
     if constexpr (G4X) {
 #pragma unroll
       for (int p = 0; p < NPF; ++p) {
-        const float4 v = *reinterpret_cast<const float4*>(pb + voff[p]);
-        pf[p][0] = v.x; pf[p][1] = v.y; pf[p][2] = v.z; pf[p][3] = v.w;
+        if constexpr (BF) {
+          const uint2 v = *reinterpret_cast<const uint2*>(pb + voff[p]);
+          pf[p][0] = __uint_as_float(v.x << 16); pf[p][1] = __uint_as_float(v.x & 0xffff0000u);
+          pf[p][2] = __uint_as_float(v.y << 16); pf[p][3] = __uint_as_float(v.y & 0xffff0000u);
+        } else {
+          const float4 v = *reinterpret_cast<const float4*>(pb + voff[p]);
+          pf[p][0] = v.x; pf[p][1] = v.y; pf[p][2] = v.z; pf[p][3] = v.w;
+        }
       }
     } else {
 #pragma unroll
@@ -482,12 +489,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
       const int64_t tb = tsel ? a.tail_bstride[1] : a.tail_bstride[0];
       const int tch0 = tsel ? a.tail_ch0[1] : a.tail_ch0[0];
       const int64_t v0 = (int64_t)(y0 + wave) * a.W + x0 + n;      // this wave's row of the tile (X3_NT == 2: tile i = x half i)
-      if constexpr (!BF) {
-        tbase = a.tail_g4 ? reinterpret_cast<T*>(reinterpret_cast<float*>(my_tail) + b * tb + ((int64_t)(tch0 >> 2) * DHW + v0) * 4)
-                          : my_tail + b * tb + (int64_t)tch0 * DHW + v0;
-      } else {
-        tbase = my_tail + b * tb + (int64_t)tch0 * DHW + v0;
-      }
+      // (G4: the group tch0 / 4 of an interleaved tensor, four elements per voxel)
+      tbase = a.tail_g4 ? my_tail + b * tb + ((int64_t)(tch0 >> 2) * DHW + v0) * 4 : my_tail + b * tb + (int64_t)tch0 * DHW + v0;
     }
     if constexpr (ABX) {
       wsb = e.src.ws + b * e.src.ws_bstride;
@@ -624,9 +627,8 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
         if constexpr (ABX) {
           // rows 12..15 (lane quarter 3): stem3d0's fused tail, already through its BatchNorm and activation above
           if (e.src.tail_rows && g == 3 && inside && !(dg_nostore && v[0] != 12345.f)) {
-            if (!BF && e.src.tail_g4) {
-              if constexpr (!BF)
-                *reinterpret_cast<float4*>(tdst + ((int64_t)(e.src.tail_ch0 >> 2) * DHW + vox) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            if (e.src.tail_g4) {
+              st4(tdst + ((int64_t)(e.src.tail_ch0 >> 2) * DHW + vox) * 4, v);
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) st(tdst + (int64_t)(e.src.tail_ch0 + r) * DHW + vox, v[r]);
@@ -644,12 +646,11 @@ __global__ __launch_bounds__(X3_THREADS, (NCG <= 3 ? 4 : 2)) void conv3d_x3_kern
             const int trelu = my_trelu;
             const float4 tsc = *reinterpret_cast<const float4*>(par + 64 + 4 * kb), tsh = *reinterpret_cast<const float4*>(par + 80 + 4 * kb);
             const float sc4[4] = {tsc.x, tsc.y, tsc.z, tsc.w}, sh4[4] = {tsh.x, tsh.y, tsh.z, tsh.w};
-            if (!BF && a.tail_g4) {      // G4 destination (four output channels: fill_tails): one 16-byte store per voxel
+            if (a.tail_g4) {      // G4 destination (four output channels: fill_tails): one 16-byte (bf16: 8-byte) store per voxel
               float u4[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) { const float u = fmaf(tacc[r], sc4[r], sh4[r]); u4[r] = trelu ? fmaxf(u, 0.f) : u; }
-              if constexpr (!BF)
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(tbase) + ((int64_t)z * HW + (nt & 1) * 16) * 4) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+              st4(tbase + ((int64_t)z * HW + (nt & 1) * 16) * 4, u4);
             } else {
               T* pt = tbase + (int64_t)z * HW + (nt & 1) * 16;
 #pragma unroll
@@ -1131,22 +1132,27 @@ bool x3_eligible(const K3Args& a, int nset, int dtype) {
 
 // which G4 forms (include/rag_amd.h) the kernel this call lands on takes: bit 0 a G4 input, bit 1 G4 full-resolution tails
 int x3_g4_caps(const K3Args& a, int nset, int dtype) {
-  if (dtype != RAGMI_F32X3 || x2d_eligible(a, nset, dtype) || x3d_eligible(a, nset, dtype) || !x3_eligible(a, nset, dtype)) return 0;
+  if ((dtype != RAGMI_F32X3 && dtype != RAGMI_BF16) || x2d_eligible(a, nset, dtype) || x3d_eligible(a, nset, dtype) || !x3_eligible(a, nset, dtype)) return 0;
 #ifndef RAGMI_NO_X3Q
   if (xq_takes(a, nset, dtype)) return 3;
 #endif
   const int ncg = a.nchunks[0] + (nset == 2 ? a.nchunks[1] : 0);
-  return (a.Cout <= 16 ? 2 : 0) | ((nset == 1 && ncg == 3 && a.ndown == 0) ? 1 : 0);
+  // a G4 input: stem3d1's shape (12 channels, one set) in either storage type; under bf16 storage also the level-3 dual cells (4 + 4
+  // channels — fp32 storage runs those on conv3d_x3q_kernel, above)
+  const bool x_g4 = (nset == 1 && ncg == 3 && a.ndown == 0) || (dtype == RAGMI_BF16 && nset == 2 && ncg == 2);
+  return (a.Cout <= 16 ? 2 : 0) | (x_g4 ? 1 : 0);
 }
 
 template <class T, int NCG, int NSET, int TAILS, int XSRC = 0>
 static int x3_launch_tails(const K3Args& a, const X3Extra& e, dim3 grid, size_t lds, hipStream_t st) {
   if constexpr (XSRC == 0 && NCG == 3 && NSET == 1 && TAILS < 2) {
     if (e.src.ws != nullptr) return x3_launch_tails<T, NCG, NSET, TAILS, 2>(a, e, grid, lds + 2 * NCG * sizeof(float4), st);      // stem3d1 expanding stem3d0's planes (+ stem3d0's BatchNorm per group)
-    if constexpr (std::is_same<T, float>::value) {
-      if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, 1>(a, e, grid, lds, st);      // stem3d1 on a G4 input
-    }
+    if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, 1>(a, e, grid, lds, st);      // stem3d1 on a G4 input
   }
+  if constexpr (XSRC == 0 && NCG == 2 && NSET == 2 && std::is_same<T, bf16_t>::value) {
+    if (a.relu & RAGMI_CONV_X_G4) return x3_launch_tails<T, NCG, NSET, TAILS, 1>(a, e, grid, lds, st);      // a level-3 dual cell on a G4 input, bf16 storage
+  }
+  if ((a.relu & RAGMI_CONV_X_G4) && XSRC != 1) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: this launch does not take a G4 input (ragmi_conv3d_k3_g4_caps)");
   if (e.src.ws != nullptr && XSRC != 2) return fail(RAGMI_EUNSUPPORTED, "conv3d_x3: the plane source is built for 12 -> Cout fp32 launches without down-sampling tails");
   static LaunchState state;     // per device, mutex-guarded (common.h)
   // persistent grid = the workgroups the chip holds at once (occupancy x CUs): measured on the level-3 launches (1664 work items)

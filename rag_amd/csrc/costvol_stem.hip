@@ -452,12 +452,14 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
     // four planes
     if (a.y == nullptr) {
       // (tails only: stem3d0's own output is expanded from the planes inside stem3d1's staging and never written)
-    } else if constexpr (std::is_same<T, float>::value && NC > 0) {
+    } else if constexpr (NC > 0) {
       if (a.relu & RAGMI_CONV_Y_G4) {
-        float* const py4 = static_cast<float*>(a.y) + b * a.y_bstride + vox * 4;
+        T* const py4 = static_cast<T*>(a.y) + b * a.y_bstride + vox * 4;
 #pragma unroll
-        for (int g = 0; g < MC / 4; ++g)
-          *reinterpret_cast<float4*>(py4 + g * DHW * 4) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        for (int g = 0; g < MC / 4; ++g) {
+          const float q[4] = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+          st4(py4 + g * DHW * 4, q);                       // 16 bytes (fp32) or 8 bytes (bf16) per voxel and group
+        }
       } else {
         T* py = static_cast<T*>(a.y) + b * a.y_bstride + vox;
 #pragma unroll
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
       const ragmi_tail_t& td = a.tail[tl];
       T* pt = static_cast<T*>(td.y) + b * td.y_bstride + (int64_t)td.y_ch0 * DHW + vox;
       float u4[4] = {0.f, 0.f, 0.f, 0.f};
-      const bool g4 = std::is_same<T, float>::value && (td.relu & RAGMI_TAIL_G4) != 0;
+      const bool g4 = (td.relu & RAGMI_TAIL_G4) != 0;
       for (int k = 0; k < td.cout; ++k) {
         float s = 0.f;
 #pragma unroll
@@ -484,9 +486,7 @@ __global__ __launch_bounds__(256) void costvol_stem_combine_kernel(CombineArgs a
         s = (td.relu & 1) ? fmaxf(s, 0.f) : s;
         if (g4) u4[k & 3] = s; else st(pt + k * DHW, s);
       }
-      if constexpr (std::is_same<T, float>::value) {
-        if (g4) *reinterpret_cast<float4*>(static_cast<float*>(td.y) + b * td.y_bstride + ((int64_t)(td.y_ch0 >> 2) * DHW + vox) * 4) = make_float4(u4[0], u4[1], u4[2], u4[3]);
-      }
+      if (g4) st4(static_cast<T*>(td.y) + b * td.y_bstride + ((int64_t)(td.y_ch0 >> 2) * DHW + vox) * 4, u4);
     }
   }
 }
@@ -591,7 +591,6 @@ extern "C" int ragmi_costvol_stem_conv3d_fwd(const void* left, const void* right
   const bool want_rows = ntail0 >= 1 && (tails0[0].relu & RAGMI_TAIL_ROWS);
   const bool tail_rows = want_rows && ntail0 == 1 && Cout == 12 && tails0[0].cout == 4 && !(tails0[0].relu & 2) && tails0[0].y &&
                          ((tails0[0].scale == nullptr) == (tails0[0].shift == nullptr)) && (!(tails0[0].relu & RAGMI_TAIL_G4) || tails0[0].y_ch0 % 4 == 0);
-  RAGMI_REQUIRE(dtype != RAGMI_BF16 || ((!tail_rows || !(tails0[0].relu & RAGMI_TAIL_G4)) && !a.tail_g4), RAGMI_EUNSUPPORTED, "costvol_stem_conv3d: G4 tails are fp32");
   RAGMI_REQUIRE(!want_rows || tail_rows, RAGMI_EINVAL, "costvol_stem_conv3d: RAGMI_TAIL_ROWS takes ONE 4-channel full-resolution tail behind a 12-channel stem3d1 (packed as 16 channels)");
   StemLayout l;
   rc = stem_run(left, right, variants, scale0, shift0, relu0, nullptr, 0, workspace, B, C, Cmid, D, H, W, tail_rows ? 0 : ntail0, tails0, dtype,
@@ -704,12 +703,12 @@ static int stem_run(const void* left, const void* right, const void* variants, c
     RAGMI_REQUIRE(tails[t].weight && tails[t].y && tails[t].cout >= 1 && tails[t].cout <= 4, RAGMI_EINVAL,
                   "costvol_stem: tail %d needs weight, y and 1..4 output channels", t);
     RAGMI_REQUIRE(!(tails[t].relu & 2), RAGMI_EUNSUPPORTED, "costvol_stem: down-sampling tails are not built here");
-    RAGMI_REQUIRE(!(tails[t].relu & RAGMI_TAIL_G4) || (dtype == RAGMI_F32 && tails[t].cout == 4 && tails[t].y_ch0 % 4 == 0), RAGMI_EUNSUPPORTED,
-                  "costvol_stem: a G4 tail needs fp32 storage, 4 output channels and a group-aligned y_ch0");
+    RAGMI_REQUIRE(!(tails[t].relu & RAGMI_TAIL_G4) || (tails[t].cout == 4 && tails[t].y_ch0 % 4 == 0), RAGMI_EUNSUPPORTED,
+                  "costvol_stem: a G4 tail needs 4 output channels and a group-aligned y_ch0");
     ca.tail[t] = tails[t];
   }
-  RAGMI_REQUIRE(!(relu & RAGMI_CONV_Y_G4) || (dtype == RAGMI_F32 && (Cout == 4 || Cout == 8 || Cout == 12 || Cout == 16)), RAGMI_EUNSUPPORTED,
-                "costvol_stem: a G4 output needs fp32 storage and Cout in {4, 8, 12, 16}");
+  RAGMI_REQUIRE(!(relu & RAGMI_CONV_Y_G4) || (Cout == 4 || Cout == 8 || Cout == 12 || Cout == 16), RAGMI_EUNSUPPORTED,
+                "costvol_stem: a G4 output needs Cout in {4, 8, 12, 16}");
   int ni = CB_NI;
 #ifdef RAGMI_DIAG
   static const int diag_ni = [] { const char* v = getenv("RAGMI_CB_NI"); return v ? atoi(v) : 0; }();

@@ -859,16 +859,16 @@ class MatchingNet(nn.Module):
                 return bool(ops.conv3d_k3_g4_caps(out_channels(-2), out_channels(-1), B, *vol, nset=1, ntail=nt, dtype=adt) & 2)
             c = cells[i]
             return (c.dual_plan(out_channels(i - 2)) and c.C_out * c._steps <= 16
-                    and bool(ops.conv3d_k3_g4_caps(2 * c.C_out, c.C_out * c._steps, B, *sizes[i], nset=2, ntail=nt, ndown=nd, dtype=adt) & 2))
+                    and bool(ops.conv3d_k3_g4_caps(2 * c.C_out, c.C_out * c._steps, B, *sizes[i], nset=2, ntail=nt, ndown=nd, dtype=cdt[i]) & 2))
 
         g4: Dict[int, bool] = {}
-        g4_ok = adt == torch.float32 and ops.get_conv_precision() == "f16x3" and ops.g4_enabled()
+        g4_ok = ((adt == torch.float32 and ops.get_conv_precision() == "f16x3") or adt == torch.bfloat16) and ops.g4_enabled()
         for j in range(n):
             c = cells[j]
             nt, nd = n_tails(j)
             g4[j] = (g4_ok and (j, 1, False) in fusable(j - 1) and (j, 0, False) in fusable(j - 2) and c.dual_plan(out_channels(j - 2))
                      and bool(ops.conv3d_k3_g4_caps(2 * c.C_out, c.C_out * c._steps, B, *sizes[j], nset=2, ntail=nt if c.C_out * c._steps <= 16 else 0,
-                                                    ndown=nd if c.C_out * c._steps <= 16 else 0, dtype=adt) & 1)
+                                                    ndown=nd if c.C_out * c._steps <= 16 else 0, dtype=cdt[j]) & 1)
                      and writes_g4(j - 1) and writes_g4(j - 2))
         changed = True
         while changed:          # one layout per producer launch

@@ -227,8 +227,8 @@ class Tail:
         self.weight2d, self.scale, self.shift, self.relu, self.out, self.out_ch0 = weight2d, scale, shift, relu, out, out_ch0
         self.down = bool(down)
         self.g4 = bool(g4)
-        if self.g4 and (self.down or weight2d.shape[0] != 4 or out_ch0 % 4 or out.dtype != torch.float32 or not out.is_contiguous()):
-            raise ValueError("Tail: a G4 destination takes a full-resolution tail of 4 channels at a group-aligned channel of a contiguous fp32 tensor")
+        if self.g4 and (self.down or weight2d.shape[0] != 4 or out_ch0 % 4 or not out.is_contiguous()):
+            raise ValueError("Tail: a G4 destination takes a full-resolution tail of 4 channels at a group-aligned channel of a contiguous tensor")
 
     def spec(self) -> TailSpec:
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731

@@ -1769,6 +1769,44 @@ def test_matchingnet_g4_plan_and_bitwise(ra, x3_on, hwd):
     assert e <= EPE_GATE / 2, e
 
 
+def test_matchingnet_g4_plan_bf16_storage_bitwise(ra):
+    """The G4 layout of the private level-3 tensors under bf16 activation storage (round 5: four bf16 of a voxel and group = one 8-byte
+    access; the level-3 dual cells on conv3d_x3_kernel<bf16, 2, 2, *, XSRC = 1>): the same bits as channel planes, with the stems fused
+    and not, and the plan says G4 for stem3d0's output and the three level-3 cells (the deep cells are fp32 planes: mixed storage)."""
+    rows = O.ALL_CONV
+    sd = O.random_matching_state_dict(rows, seed=0)
+    net = ra.MatchingNet(ra.Genotype(rows, None, rows, None), maxdisp=96)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    lf, rf = torch.randn((2, 12, 72, 132), generator=gen(581)).to(BF), torch.randn((2, 12, 72, 132), generator=gen(582)).to(BF)
+    outs = {}
+    try:
+        ra.ops.set_stem_tail_rows(False)
+        for g4, fuse in ((True, True), (True, False), (False, False), (False, True)):
+            ra.ops.set_g4(g4)
+            ra.ops.set_stem_fusion(fuse)
+            with torch.no_grad():
+                outs[(g4, fuse)] = net(gpu(lf), gpu(rf))
+            plan = net.last_g4_plan
+            assert [plan["pre"][j] for j in (0, 1, 2)] == [g4] * 3 and plan["stems_fused"] == fuse, plan
+            assert not any(plan["pre"][j] for j in range(3, 8))
+        ra.ops.set_g4(True)
+        ra.ops.set_stem_fusion(True)
+        ra.ops.set_stem_tail_rows(True)
+        with torch.no_grad():
+            d_rows = net(gpu(lf), gpu(rf))
+            d32 = net(gpu(lf).float(), gpu(rf).float())
+    finally:
+        ra.ops.set_g4(True)
+        ra.ops.set_stem_fusion(True)
+        ra.ops.set_stem_tail_rows(True)
+    for k in outs:
+        assert torch.equal(outs[k], outs[(False, False)]), k
+    e_rows, e_ref = O.epe(d_rows.cpu(), d32.cpu()), O.epe(outs[(False, False)].cpu(), d32.cpu())
+    print(f"bf16 storage vs the fp32 build: EPE {e_ref:.3e} px; with stem3d0's tail in the product's idle rows {e_rows:.3e} px")
+    assert e_rows <= 1.5 * e_ref + 1e-3
+
+
 def test_x3_down_tail_clamped_pair_ignores_a_non_finite_even_source(ra, x3_on):
     """Where the last output of an axis clamps, the x0.5 trilinear resample (align_corners=True, rag_model.py:146-150) reads the ODD source
     for both taps: a non-finite value in the even source next to it must not reach that output (0 * Inf = NaN).  D = 16:
