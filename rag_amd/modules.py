@@ -1018,7 +1018,15 @@ class MatchingNet(nn.Module):
             return up_last3(self.last_6_3d[i6](last_output))
         if last_output.size()[3] == h // 4:
             # upsample_12 is fused into last_6_3d's 1x1x1 kernel (conv-first); upsample_6 is fused into last_3_3d's kernel
-            y = self.last_6_3d[i6](self.last_12_3d[i12](last_output), resample_to=(d // 2, h // 2, w // 2))
+            m12 = self.last_12_3d[i12]
+            if (last_output.dtype == torch.bfloat16 and ops.bf16_head_fp32_enabled() and not m12.autograd_mode(last_output)
+                    and m12._geometry() == 1):
+                # bf16 storage: the head keeps fp32 from its first 1x1x1 conv on (the crossing launch: RAGMI_BF16 | RAGMI_OUT_F32)
+                y12 = m12(last_output, out=torch.empty((last_output.shape[0], m12.conv.out_channels) + tuple(last_output.shape[2:]),
+                                                       device=last_output.device, dtype=f32))
+            else:
+                y12 = m12(last_output)
+            y = self.last_6_3d[i6](y12, resample_to=(d // 2, h // 2, w // 2))
             return up_last3(y)
         # the reference reaches `return mat` with mat unbound here (UnboundLocalError)
         raise ValueError("MatchingNet: feature height must be a multiple of 4 (input H a multiple of 12)")

@@ -152,6 +152,18 @@ def bf16_deep_fp32_enabled() -> bool:
     return _BF16_DEEP_F32[0]
 
 
+_BF16_HEAD_F32 = [os.environ.get("RAGMI_BF16_HEAD_F32", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling)
+
+
+def set_bf16_head_fp32(enabled: bool) -> None:
+    """bf16 activation storage with EVERY cell bf16 (set_bf16_deep_fp32(False)): the head still keeps fp32 from last_12_3d on."""
+    _BF16_HEAD_F32[0] = bool(enabled)
+
+
+def bf16_head_fp32_enabled() -> bool:
+    return _BF16_HEAD_F32[0]
+
+
 _BF16_DEEP_RATIO = [int(os.environ.get("RAGMI_BF16_DEEP_RATIO", "8"))]      # (A/B tooling: 64 = the first level-6 cell stays bf16)
 
 
