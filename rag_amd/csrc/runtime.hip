@@ -24,7 +24,7 @@ int check_launch(const char* what) {
 
 }  // namespace ragmi
 
-extern "C" int ragmi_version(void) { return 400; }   // round 4: + ragmi_cell2d_fwd, ragmi_upconv3d_c1_fwd, ragmi_down2_tail_supported, down-sampling tails
+extern "C" int ragmi_version(void) { return 500; }   // round 5: + ragmi_costvol_stem_conv3d_fwd / _supported, ragmi_conv3d_k3_g4_caps, the G4 / RAGMI_TAIL_F32 / RAGMI_TAIL_ROWS / RAGMI_OUT_F32 flags (round 4: 400)
 
 #include <vector>
 extern "C" int ragmi_graph_node_census(void* graph, int32_t* n_kernel, int32_t* n_memcpy, int32_t* n_memset, int32_t* n_other) {
