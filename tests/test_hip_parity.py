@@ -1836,7 +1836,7 @@ def test_x3_down_tail_clamped_pair_ignores_a_non_finite_even_source(ra, x3_on):
     np.testing.assert_allclose(got[:, :, 7].numpy(), ref[:, :, 7].numpy(), rtol=3e-4, atol=3e-4)
 
 
-@pytest.mark.parametrize("B,h,w,maxdisp", [(1, 128, 160, 48), (2, 72, 132, 96)])
+@pytest.mark.parametrize("B,h,w,maxdisp", [(1, 128, 160, 48), (2, 72, 132, 96), (1, 131, 171, 51)])      # (the last: ragged tiles, D = 17)
 def test_costvol_stem_conv3d_fused_bitwise(ra, x3_on, B, h, w, maxdisp):
     """stem3d0 + stem3d1 as one call that never writes stem3d0's output (ragmi_costvol_stem_conv3d_fwd; rag_model.py:234-235, 341-343,
     375-383) against the two separate calls (costvol_stem -> conv3d_k3 with the same tails): stem3d1's staging evaluates the combine
