@@ -249,6 +249,14 @@ int ragmi_conv3d_k1_fwd(const void* x, int64_t x_bstride,
                         int B, int Cin, int Cout, int64_t DHW,
                         int dtype, void* stream);
 
+/* Two 1x1x1 ConvBR_3d in a row as one launch: y = act2(bn2(W2 . act1(bn1(W1 . x)))), the intermediate (Cmid channels) in registers —
+ * the head's last_12_3d followed by the channel mix of last_6_3d (rag_model.py:358-365, :270-271).  Results are those of two
+ * ragmi_conv3d_k1_fwd calls, bit for bit.  Built for Cin <= 64 -> 24 -> 12 channels (ragmi_conv3d_k1_chain_supported). */
+int ragmi_conv3d_k1_chain_supported(int Cin, int Cmid, int Cout);
+int ragmi_conv3d_k1_chain_fwd(const void* x, int64_t x_bstride, const void* weight1, const void* scale1, const void* shift1, int relu1,
+                              int Cmid, const void* weight2, const void* scale2, const void* shift2, int relu2,
+                              void* y, int64_t y_bstride, int y_ch0, int B, int Cin, int Cout, int64_t DHW, int dtype, void* stream);
+
 /* The same with the weight given TRANSPOSED in memory when w_transposed != 0 (weight[ci][co], i.e. [Cin][Cout] row-major): the
  * data gradient of a 1x1x1 conv is this conv with the forward weight read in place — no transposed copy per step. */
 int ragmi_conv3d_k1_fwd_ex(const void* x, int64_t x_bstride, const void* weight, int w_transposed, const void* scale,

@@ -76,6 +76,9 @@ SIGNATURES = {
     "ragmi_conv3d_k3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int32_p, c_int32_p, c_int32_p, c_int]),
     "ragmi_conv3d_k1_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "ragmi_conv3d_k1_chain_supported": (c_int, [c_int] * 3),
+    "ragmi_conv3d_k1_chain_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "ragmi_conv3d_k1_fwd_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                        c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "ragmi_conv3d_k1_resample_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -94,6 +94,64 @@ __global__ __launch_bounds__(256) void conv_k1_kernel(K1Args a) {
   }
 }
 
+// Two 1x1x1 ConvBR_3d in a row as ONE launch (the head's last_12_3d -> the channel mix of last_6_3d, rag_model.py:358-365: the second
+// one runs conv-first, in front of its upsample): y = act2(bn2(W2 . act1(bn1(W1 . x)))) per voxel, the intermediate in registers.  The
+// same fmaf chains, in the same order, as two conv_k1 launches (under bf16 storage the intermediate is rounded as its store would),
+// so the results are theirs bit for bit.  One thread per voxel: these volumes are tiny (level 12: 53 k voxels) and latency-bound.
+template <class T, int CMID, int NCO>
+__global__ __launch_bounds__(256) void conv_k1_chain_kernel(K1Args a, const float* __restrict__ w2, const float* __restrict__ scale2,
+                                                            const float* __restrict__ shift2, int relu2) {
+  extern __shared__ __attribute__((aligned(16))) float kc_w[];      // W1 as [ci][CMID] | W2 as [cm][NCO] | scale1, shift1 [CMID] | scale2, shift2 [NCO]
+  float* const w2l = kc_w + a.Cin * CMID;
+  float* const bn1 = w2l + CMID * NCO;
+  float* const bn2 = bn1 + 2 * CMID;
+  for (int i = threadIdx.x; i < a.Cin * CMID; i += 256) kc_w[i] = a.w[(i % CMID) * a.Cin + i / CMID];
+  for (int i = threadIdx.x; i < CMID * NCO; i += 256) w2l[i] = w2[(i % NCO) * CMID + i / NCO];
+  if (threadIdx.x < CMID) { bn1[threadIdx.x] = a.scale ? a.scale[threadIdx.x] : 1.f; bn1[CMID + threadIdx.x] = a.scale ? a.shift[threadIdx.x] : 0.f; }
+  if (threadIdx.x < NCO) { bn2[threadIdx.x] = scale2 ? scale2[threadIdx.x] : 1.f; bn2[NCO + threadIdx.x] = scale2 ? shift2[threadIdx.x] : 0.f; }
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.dhw) return;
+  const int b = blockIdx.y;
+  const T* xp = static_cast<const T*>(a.x) + b * a.x_bstride + p;
+  float h[CMID];
+#pragma unroll
+  for (int j = 0; j < CMID; ++j) h[j] = 0.f;
+#pragma unroll 4
+  for (int ci = 0; ci < a.Cin; ++ci) {
+    const float xv = ld(xp + (int64_t)ci * a.dhw);
+#pragma unroll
+    for (int j = 0; j < CMID; j += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(kc_w + ci * CMID + j);
+      h[j] = fmaf(q.x, xv, h[j]); h[j + 1] = fmaf(q.y, xv, h[j + 1]); h[j + 2] = fmaf(q.z, xv, h[j + 2]); h[j + 3] = fmaf(q.w, xv, h[j + 3]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CMID; ++j) {
+    float v = a.scale ? fmaf(h[j], bn1[j], bn1[CMID + j]) : h[j];
+    v = a.relu ? fmaxf(v, 0.f) : v;
+    if constexpr (!std::is_same<T, float>::value) { const bf16_t r = to_bf16(v); v = ld(&r); }      // (the store's rounding)
+    h[j] = v;
+  }
+  float acc[NCO];
+#pragma unroll
+  for (int k = 0; k < NCO; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int j = 0; j < CMID; ++j) {
+#pragma unroll
+    for (int k = 0; k < NCO; k += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(w2l + j * NCO + k);
+      acc[k] = fmaf(q.x, h[j], acc[k]); acc[k + 1] = fmaf(q.y, h[j], acc[k + 1]); acc[k + 2] = fmaf(q.z, h[j], acc[k + 2]); acc[k + 3] = fmaf(q.w, h[j], acc[k + 3]);
+    }
+  }
+  T* yp = static_cast<T*>(a.y) + b * a.y_bstride + p;
+#pragma unroll
+  for (int k = 0; k < NCO; ++k) {
+    float v = scale2 ? fmaf(acc[k], bn2[k], bn2[NCO + k]) : acc[k];
+    st(yp + (int64_t)(a.y_ch0 + k) * a.dhw, relu2 ? fmaxf(v, 0.f) : v);
+  }
+}
+
 // Trilinear resample fused into the 1x1x1 ConvBR_3d that consumes it (Cell_3d: s1 = interpolate(prev) ->
 // preprocess, rag_model.py:146-155; head: last_6_3d(upsample_12(.)), :358-365).  A thread owns one OUTPUT voxel:
 // it computes its 3 (index, weight) pairs once, gathers the 8 taps of every input channel (for the x0.5 case each
@@ -380,6 +438,30 @@ extern "C" int ragmi_conv3d_k1_fwd_ex(const void* x, int64_t x_bstride, const vo
     if (vec) launch_k1<float, true>(a, B, s); else launch_k1<float, false>(a, B, s);
   }
   return check_launch("conv3d_k1");
+}
+
+extern "C" int ragmi_conv3d_k1_chain_supported(int Cin, int Cmid, int Cout) { return (Cin >= 1 && Cin <= 64 && Cmid == 24 && Cout == 12) ? 1 : 0; }
+
+extern "C" int ragmi_conv3d_k1_chain_fwd(const void* x, int64_t x_bstride, const void* weight1, const void* scale1, const void* shift1, int relu1,
+                                         int Cmid, const void* weight2, const void* scale2, const void* shift2, int relu2, void* y, int64_t y_bstride,
+                                         int y_ch0, int B, int Cin, int Cout, int64_t DHW, int dtype, void* stream) {
+  using namespace ragmi;
+  RAGMI_REQUIRE(x && weight1 && weight2 && y, RAGMI_EINVAL, "conv3d_k1_chain: null pointer");
+  RAGMI_REQUIRE((scale1 == nullptr) == (shift1 == nullptr) && (scale2 == nullptr) == (shift2 == nullptr), RAGMI_EINVAL,
+                "conv3d_k1_chain: scale/shift must both be given or both NULL");
+  RAGMI_REQUIRE(B > 0 && B <= 65535 && DHW > 0 && y_ch0 >= 0, RAGMI_EINVAL, "conv3d_k1_chain: bad size");
+  RAGMI_REQUIRE(dtype_ok(dtype), RAGMI_EUNSUPPORTED, "conv3d_k1_chain: dtype %d not built", dtype);
+  RAGMI_REQUIRE(ragmi_conv3d_k1_chain_supported(Cin, Cmid, Cout), RAGMI_EUNSUPPORTED,
+                "conv3d_k1_chain: built for Cin <= 64 -> 24 -> 12 channels (the head's last_12_3d -> last_6_3d), got %d -> %d -> %d", Cin, Cmid, Cout);
+  K1Args a{x, x_bstride, (const float*)weight1, (const float*)scale1, (const float*)shift1, y, y_bstride, y_ch0, Cin, Cmid, 0, DHW, relu1, Cin, 1};
+  const dim3 grid((unsigned)ceil_div(DHW, 256), B);
+  const size_t lds = (size_t)(Cin * 24 + 24 * 12 + 2 * 24 + 2 * 12) * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RAGMI_BF16)
+    hipLaunchKernelGGL((conv_k1_chain_kernel<bf16_t, 24, 12>), grid, dim3(256), lds, s, a, (const float*)weight2, (const float*)scale2, (const float*)shift2, relu2);
+  else
+    hipLaunchKernelGGL((conv_k1_chain_kernel<float, 24, 12>), grid, dim3(256), lds, s, a, (const float*)weight2, (const float*)scale2, (const float*)shift2, relu2);
+  return check_launch("conv3d_k1_chain");
 }
 
 extern "C" int ragmi_conv3d_k1_resample_fwd(const void* x, int64_t x_bstride, int Di, int Hi, int Wi, const void* weight,

@@ -1025,6 +1025,20 @@ class MatchingNet(nn.Module):
                 y12 = m12(last_output, out=torch.empty((last_output.shape[0], m12.conv.out_channels) + tuple(last_output.shape[2:]),
                                                        device=last_output.device, dtype=f32))
             else:
+                m6 = self.last_6_3d[i6]
+                half = (d // 2, h // 2, w // 2)
+                if (up is ops.trilinear3d and m12._geometry() == 1 and m6._geometry() == 1 and ops.chain_k1_enabled()
+                        and _volume(half) > _volume(last_output.shape[2:]) and m6.conv.out_channels <= m6.conv.in_channels
+                        and ops.conv3d_k1_chain_supported(m12.conv.in_channels, m12.conv.out_channels, m6.conv.out_channels)):
+                    # last_12_3d and the channel mix of last_6_3d (conv-first, as ConvBR.forward runs an up-sampling 1x1x1) as ONE launch
+                    w1, s1, h1 = m12.prepared()
+                    w2, s2, h2 = m6.prepared()
+                    low = torch.empty((last_output.shape[0], m6.conv.out_channels) + tuple(last_output.shape[2:]), device=last_output.device,
+                                      dtype=last_output.dtype)
+                    ops.conv3d_k1_chain(last_output, w1, s1, h1, m12.relu, w2, s2, h2, False, low)
+                    y = torch.empty((last_output.shape[0], m6.conv.out_channels) + half, device=last_output.device, dtype=last_output.dtype)
+                    ops.trilinear3d_act(low, half, True, m6.relu, y, 0)
+                    return up_last3(y)
                 y12 = m12(last_output)
             y = self.last_6_3d[i6](y12, resample_to=(d // 2, h // 2, w // 2))
             return up_last3(y)

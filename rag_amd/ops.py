@@ -510,6 +510,44 @@ def conv3d_k1(x: torch.Tensor, weight2d: torch.Tensor, scale: Optional[torch.Ten
     return out
 
 
+_CHAIN_K1 = [os.environ.get("RAGMI_CHAIN_K1", "1") != "0"]      # the DEFAULT, read once at import (A/B tooling)
+
+
+def set_chain_k1(enabled: bool) -> None:
+    """Whether the head runs last_12_3d and last_6_3d's channel mix as one launch (conv3d_k1_chain)."""
+    _CHAIN_K1[0] = bool(enabled)
+
+
+def chain_k1_enabled() -> bool:
+    return _CHAIN_K1[0]
+
+
+def conv3d_k1_chain_supported(cin: int, cmid: int, cout: int) -> bool:
+    return bool(load_library().ragmi_conv3d_k1_chain_supported(int(cin), int(cmid), int(cout)))
+
+
+def conv3d_k1_chain(x: torch.Tensor, w1: torch.Tensor, scale1, shift1, relu1: bool, w2: torch.Tensor, scale2, shift2, relu2: bool,
+                    out: torch.Tensor, out_ch0: int = 0) -> torch.Tensor:
+    """Two 1x1x1 ConvBR_3d in a row as one launch (ragmi_conv3d_k1_chain_fwd): out[:, ch0:ch0+Cout] = act2(bn2(w2 @ act1(bn1(w1 @ x))));
+    the bits of two conv3d_k1 calls."""
+    _need_gpu(w1, scale1, shift1, w2, scale2, shift2)
+    dt = _act(x, out)
+    B, Cin = x.shape[:2]
+    Cmid, Cout = w1.shape[0], w2.shape[0]
+    if not (w1.is_contiguous() and w2.is_contiguous()) or w1.shape[1] != Cin or w2.shape[1] != Cmid:
+        raise ValueError("conv3d_k1_chain: weights must be contiguous [Cmid, Cin] and [Cout, Cmid]")
+    dhw = 1
+    for sdim in x.shape[2:]:
+        dhw *= sdim
+    if out_ch0 + Cout > out.shape[1] or tuple(out.shape[2:]) != tuple(x.shape[2:]):
+        raise ValueError("conv3d_k1_chain: output buffer too small / wrong spatial size")
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    check(load_library().ragmi_conv3d_k1_chain_fwd(x.data_ptr(), _planes(x), w1.data_ptr(), p(scale1), p(shift1), int(relu1), Cmid,
+                                                   w2.data_ptr(), p(scale2), p(shift2), int(relu2), out.data_ptr(), _planes(out), out_ch0,
+                                                   B, Cin, Cout, dhw, dt, _stream()), "conv3d_k1_chain")
+    return out
+
+
 def conv3d_k1_resample(x: torch.Tensor, size: Sequence[int], align_corners: bool, weight2d: torch.Tensor,
                        scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], relu: bool, out: torch.Tensor,
                        out_ch0: int = 0) -> torch.Tensor:

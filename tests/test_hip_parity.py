@@ -1287,6 +1287,31 @@ def test_costvol_stem_conv3d_fused_bf16_storage(ra):
     assert torch.isnan(rows[2][:, 4:]).all() and not torch.isnan(rows[1]).any()
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv3d_k1_chain_bitwise(ra, dt):
+    """Two 1x1x1 ConvBR_3d in a row as one launch (the head's last_12_3d -> last_6_3d's channel mix, rag_model.py:358-365) against the
+    two conv3d_k1 launches: the same fmaf chains in the same order (bf16 storage: the intermediate rounded as its store would be) —
+    the same bits; and against float64."""
+    g1 = gen(621)
+    x = torch.randn((2, 48, 9, 20, 31), generator=g1).to(dt)
+    w1, w2 = torch.randn((24, 48), generator=g1) * 0.2, torch.randn((12, 24), generator=g1) * 0.3
+    s1, h1 = torch.rand(24, generator=g1) + 0.5, torch.randn(24, generator=g1) * 0.1
+    s2, h2 = torch.rand(12, generator=g1) + 0.5, torch.randn(12, generator=g1) * 0.1
+    assert ra.ops.conv3d_k1_chain_supported(48, 24, 12) and not ra.ops.conv3d_k1_chain_supported(48, 16, 12)
+    mid = torch.empty((2, 24, 9, 20, 31), device=DEV, dtype=dt)
+    ra.ops.conv3d_k1(gpu(x), gpu(w1), gpu(s1), gpu(h1), True, mid)
+    sep = torch.full((2, 14, 9, 20, 31), float("nan"), device=DEV, dtype=dt)
+    ra.ops.conv3d_k1(mid, gpu(w2), gpu(s2), gpu(h2), False, sep, 1)
+    one = torch.full((2, 14, 9, 20, 31), float("nan"), device=DEV, dtype=dt)
+    ra.ops.conv3d_k1_chain(gpu(x), gpu(w1), gpu(s1), gpu(h1), True, gpu(w2), gpu(s2), gpu(h2), False, one, 1)
+    assert torch.equal(torch.nan_to_num(one.float(), nan=-7.0), torch.nan_to_num(sep.float(), nan=-7.0))
+    v = lambda t: t.view(1, -1, 1, 1, 1)  # noqa: E731
+    hid = F.relu(torch.einsum("oc,bcdhw->bodhw", w1.double(), x.double()) * v(s1.double()) + v(h1.double()))
+    ref = torch.einsum("oc,bcdhw->bodhw", w2.double(), hid) * v(s2.double()) + v(h2.double())
+    tol = 2e-4 if dt == torch.float32 else 3e-2
+    np.testing.assert_allclose(one[:, 1:13].float().cpu().double().numpy(), ref.numpy(), rtol=tol, atol=tol)
+
+
 def test_mixed_storage_edges_round_to_the_bf16_results(ra):
     """The two launches that cross from bf16 storage into the fp32 levels (round 5, include/rag_amd.h "Mixed storage"): a
     down-sampling tail with an fp32 destination (RAGMI_TAIL_F32) and the resample + 1x1x1 launch with an fp32 output
