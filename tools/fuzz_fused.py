@@ -14,9 +14,12 @@ from oracle import matching_oracle as O  # noqa: E402
 DEV = "cuda:0"
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-rows = O.ALL_CONV
+import numpy as np  # noqa: E402
+GENOTYPES = (("all-conv", O.ALL_CONV), ("all-conv", O.ALL_CONV), ("all-skip", O.ALL_SKIP),
+             ("mixed", np.array([[0, 1], [1, 0], [3, 0], [2, 1], [8, 1], [6, 0]])))      # (SURVEY 8 A6's unsorted probe rows)
 bad = 0
 for case in range(n_cases):
+    gname, rows = rng.choice(GENOTYPES)
     B = rng.choice((1, 1, 2, 3))
     h = 4 * rng.randint(10, 40)
     w = 4 * rng.randint(14, 60)
@@ -54,7 +57,7 @@ for case in range(n_cases):
         e = e_all - e_off
     status = "ok" if (ok_bits and fin and ok_e) else "FAIL"
     bad += status != "ok"
-    print(f"case {case:2d}: B={B} {h}x{w} D={maxdisp // 3} {str(dt).split('.')[-1]:8s} fused={plan.get('stems_fused')} rows={plan.get('stem_tail_rows')} "
+    print(f"case {case:2d}: {gname:8s} B={B} {h}x{w} D={maxdisp // 3} {str(dt).split('.')[-1]:8s} fused={plan.get('stems_fused')} rows={plan.get('stem_tail_rows')} "
           f"g4={[plan['pre'].get(j) for j in (0, 1, 2)]}: bits {'same' if ok_bits else 'DIFFER'}, rows EPE {e:+.2e} px ({'vs off' if dt == torch.float32 else 'change of the EPE vs the fp32 build'}) -> {status}", flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)
