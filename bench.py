@@ -184,6 +184,49 @@ def roofline_of(by, args, dt, graphed, steps=None, f32_dtype_is_split=True):
     return roofline
 
 
+def dual_launches_in_graph_us(step, vol, repeats=20, replays=3):
+    """Launch times of the level-3 DUAL convolution launches of `step` as they run INSIDE a replayed hipGraph: one eager pass records the
+    arguments of every conv3d_k3_dual call on a volume of size `vol`; each recorded launch is then captured `repeats` times into a graph
+    of its own (same buffers, same stream discipline as the timed graph) and `replays` back-to-back replays are bracketed by HIP events on
+    the launch stream.  Per-kernel events cannot be recorded inside a captured graph on this runtime (external events are refused), and
+    events around EAGER launches read 10-20 % long (host gaps, idle clocks) — this is the faithful figure.  Returns [us per launch]."""
+    import rag_amd
+    ops = rag_amd.ops
+    calls = []
+    orig = ops.conv3d_k3_dual
+
+    def spy(x, *a, **k):
+        if tuple(x.shape[2:]) == tuple(vol):
+            calls.append((x, a, k))
+        return orig(x, *a, **k)
+
+    ops.conv3d_k3_dual = spy
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv3d_k3_dual = orig
+    out = []
+    for (x, a, k) in calls:
+        def many():
+            for _ in range(repeats):
+                orig(x, *a, **k)
+        graph, _ = try_capture(many)
+        if graph is None:
+            return []
+        for _ in range(2):
+            graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(replays):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3 / (repeats * replays))
+    return out
+
+
 def pmc_traffic_bytes(kernel_name: str):
     """(HBM bytes per launch of `kernel_name`, source file) from the newest committed rocprofv3 PMC summary
     (profiles/r*_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same bench command).
@@ -836,6 +879,30 @@ def main():
         torch.cuda.synchronize()
         by = prof.summary()
         roofline = roofline_of(by, args, dt, graph is not None)
+        if graph is not None and roofline and roofline["kernel"].startswith("conv3d_x3") and "<2," in roofline["kernel"]:
+            # the dominant kernel = the level-3 dual launches: their times INSIDE a replayed graph (dual_launches_in_graph_us) replace the
+            # eager-pass figure in `achieved` / `frac`; the eager one stays beside it
+            try:
+                with torch.no_grad():
+                    us = dual_launches_in_graph_us(step, (MAXDISP // 3, H // 3, W // 3))
+            except Exception as exc:      # noqa: BLE001 (a measurement aid: never fatal)
+                log(f"bench: in-graph launch timing failed ({type(exc).__name__}: {exc})")
+                us = []
+            if us and len(us) == roofline["launches_per_step"]:
+                avg = sum(us) / len(us)
+                roofline["avg_launch_us_eager"] = roofline["avg_launch_us"]
+                roofline["avg_launch_us"] = round(avg, 2)
+                roofline["launch_us_in_graph"] = [round(u, 1) for u in us]
+                roofline["avg_launch_us_source"] = ("HIP events on the launch stream around back-to-back replays of a captured hipGraph holding 20 launches "
+                                                    "of each of this forward's level-3 dual launches with their own buffers (per-kernel events cannot be "
+                                                    "recorded inside a graph on this runtime; events around eager launches — avg_launch_us_eager — read "
+                                                    "10-20 % long); rocprofv3's averages of the replayed graph agree: profiles/r05*_step_timeline.txt")
+                if roofline["bound"] == "hbm":
+                    gbs = roofline["algorithmic_bytes_per_launch"] / (avg * 1e-6) * 1e-9
+                    roofline["achieved"], roofline["frac"] = round(gbs, 1), round(gbs / PEAK_HBM_GBS, 4)
+                    tf = roofline["flops_per_launch"] / (avg * 1e-6) * 1e-12
+                    roofline["mfma"]["achieved_tflops"], roofline["mfma"]["frac"] = round(tf, 2), round(tf / roofline["mfma"]["peak"], 4)
+                roofline["share_of_step"] = round(sum(us) * 1e-6 / (dt / args.steps), 3)
         if by:
             for k, (s_, f_, b_, n_) in sorted(by.items(), key=lambda kv: -kv[1][0]):
                 log(f"  conv3d {'x3 (split operands) channel groups' if k[1] == 'x3' else 'k3 G'}={k[0]} tx={k[1]} R={k[2]} nset={k[3]}: {n_ // args.steps} launches/step, {s_ / args.steps * 1e3:.3f} ms/step, "
